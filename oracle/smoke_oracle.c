@@ -1,0 +1,377 @@
+/*
+ * smoke_oracle.c -- CPU restatement of the SmokePhysAI hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the *checker*: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may call it; the product (smokephysai_amd/) never does.  It restates, in plain scalar C and
+ * in the reference's own operation order (one fp32 rounding per torch elementwise op, no FMA
+ * contraction: build with -ffp-contract=off), the algorithms of
+ *
+ *   /root/reference/src/physics/navier_stokes.py     (NavierStokesSimulator)
+ *   /root/reference/src/physics/fractal_generator.py (FractalGenerator)
+ *   /root/reference/src/physics/smoke_simulator.py   (simulate_step, chaos statistics)
+ *   /root/reference/src/models/smokephys_net.py:24-32,87-91 (input_encoder + pooling; aten ops)
+ *
+ * Each function cites the reference file:line it follows.  Pinning: every function here is
+ * checked against the golden vectors in tests/golden/ (captured by importing the reference on
+ * CPU; generator script committed there) by tests/test_oracle_golden.py.
+ *
+ * Grids are un-batched (one grid per call), exactly like the reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SO_API __attribute__((visibility("default")))
+
+static inline float clampf(float x, float lo, float hi) {
+    /* torch.clamp(x, lo, hi) = min(max(x, lo), hi) */
+    float t = x < lo ? lo : x;
+    return t > hi ? hi : t;
+}
+static inline int64_t clampi(int64_t x, int64_t lo, int64_t hi) {
+    int64_t t = x < lo ? lo : x;
+    return t > hi ? hi : t;
+}
+
+/* torch.linspace(start, end, steps) fp32 CPU kernel (aten RangeFactoriesKernel.cpp, torch 2.10):
+ * step = (end-start)/(steps-1) in fp32; first half start + step*i, second half end - step*(steps-1-i),
+ * each evaluated with ONE rounding (the aten build contracts it to an FMA) -- verified bit-exact against
+ * tests/golden/linspace_probe.npz for 15 lengths x 3 ranges.
+ * Call sites: fractal_generator.py:17-18,38-39. */
+SO_API void so_linspace(float start, float end, int64_t steps, float *out) {
+    if (steps == 1) { out[0] = start; return; }
+    float step = (end - start) / (float)(steps - 1);
+    int64_t half = steps / 2;
+    for (int64_t i = 0; i < steps; ++i) {
+        if (i < half) out[i] = fmaf(step, (float)i, start);
+        else out[i] = fmaf(-step, (float)(steps - i - 1), end);
+    }
+}
+
+/* navier_stokes.py:37-48  add_smoke_source(x, y, radius, intensity); (x,y) = (column,row).
+ * dist = sqrt(float(dx^2+dy^2)) from int64 coords; mask dist<=radius;
+ * density += intensity * exp(-(dist*dist) / (float)(2*(radius/3)^2))   [python double scalar -> fp32 once] */
+SO_API void so_add_source(float *density, int h, int w, int x, int y, int radius, double intensity) {
+    const float denom = (float)(2.0 * ((double)radius / 3.0) * ((double)radius / 3.0));
+    const float fint = (float)intensity;
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            int64_t dx = j - x, dy = i - y;
+            float dist = sqrtf((float)(dx * dx + dy * dy));
+            if (dist <= (float)radius) {
+                float e = expf(-(dist * dist) / denom);
+                density[(size_t)i * w + j] += fint * e;
+            }
+        }
+}
+
+/* navier_stokes.py:50-72  diffusion_step: replicate-pad, lap = ((up+down)+left)+right - 4*c,
+ * out = f + coef*lap with coef = (float)(dt*viscosity) (python double product, cast once). */
+SO_API void so_diffuse(const float *f, float *out, int R, int C, double dt, double visc) {
+    const float coef = (float)(dt * visc);
+    for (int i = 0; i < R; ++i) {
+        int iu = i > 0 ? i - 1 : 0, id = i < R - 1 ? i + 1 : R - 1;
+        for (int j = 0; j < C; ++j) {
+            int jl = j > 0 ? j - 1 : 0, jr = j < C - 1 ? j + 1 : C - 1;
+            float c = f[(size_t)i * C + j];
+            float lap = f[(size_t)iu * C + j] + f[(size_t)id * C + j];
+            lap = lap + f[(size_t)i * C + jl];
+            lap = lap + f[(size_t)i * C + jr];
+            lap = lap - 4.0f * c;
+            out[(size_t)i * C + j] = c + coef * lap;
+        }
+    }
+}
+
+/* navier_stokes.py:154-155  buoyancy: v[:, :-1] += dt * (density * 0.1)  (two fp32 roundings). */
+SO_API void so_buoyancy(float *v, const float *density, int h, int w, double dt) {
+    const float fdt = (float)dt;
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            float b = density[(size_t)i * w + j] * 0.1f;
+            v[(size_t)i * (w + 1) + j] += fdt * b;
+        }
+}
+
+/* navier_stokes.py:136  div = (u[1:]-u[:-1] + v[:,1:]-v[:,:-1]) / dt   (true fp32 divide on CPU). */
+SO_API void so_divergence(const float *u, const float *v, float *div, int h, int w, double dt) {
+    const float fdt = (float)dt;
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            float a = u[(size_t)(i + 1) * w + j] - u[(size_t)i * w + j];
+            a = a + v[(size_t)i * (w + 1) + j + 1];
+            a = a - v[(size_t)i * (w + 1) + j];
+            div[(size_t)i * w + j] = a / fdt;
+        }
+}
+
+/* navier_stokes.py:139-145  `iters` Jacobi sweeps: boundary ring forced to 0, interior
+ * 0.25*((((up+down)+left)+right)-div); p is warm-started (carried across steps). tmp: h*w scratch. */
+SO_API void so_jacobi(float *p, const float *div, float *tmp, int h, int w, int iters) {
+    float *cur = p, *nxt = tmp;
+    for (int it = 0; it < iters; ++it) {
+        memset(nxt, 0, sizeof(float) * (size_t)h * w);
+        for (int i = 1; i < h - 1; ++i)
+            for (int j = 1; j < w - 1; ++j) {
+                float s = cur[(size_t)(i - 1) * w + j] + cur[(size_t)(i + 1) * w + j];
+                s = s + cur[(size_t)i * w + j - 1];
+                s = s + cur[(size_t)i * w + j + 1];
+                s = s - div[(size_t)i * w + j];
+                nxt[(size_t)i * w + j] = 0.25f * s;
+            }
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != p) memcpy(p, cur, sizeof(float) * (size_t)h * w);
+}
+
+/* navier_stokes.py:148-149  u[1:-1,:] -= dt*(p[1:]-p[:-1]);  v[:,1:-1] -= dt*(p[:,1:]-p[:,:-1]). */
+SO_API void so_grad_subtract(float *u, float *v, const float *p, int h, int w, double dt) {
+    const float fdt = (float)dt;
+    for (int i = 1; i < h; ++i)
+        for (int j = 0; j < w; ++j)
+            u[(size_t)i * w + j] -= fdt * (p[(size_t)i * w + j] - p[(size_t)(i - 1) * w + j]);
+    for (int i = 0; i < h; ++i)
+        for (int j = 1; j < w; ++j)
+            v[(size_t)i * (w + 1) + j] -= fdt * (p[(size_t)i * w + j] - p[(size_t)i * w + j - 1]);
+}
+
+/* navier_stokes.py:133-149  pressure_projection with a parameterised sweep count (reference: 20). */
+SO_API void so_project(float *u, float *v, float *p, float *div, float *tmp, int h, int w, double dt, int iters) {
+    so_divergence(u, v, div, h, w, dt);
+    so_jacobi(p, div, tmp, h, w, iters);
+    so_grad_subtract(u, v, p, h, w, dt);
+}
+
+/* navier_stokes.py:111-131  bilinear_interpolate: indices clamped BEFORE the weights are formed
+ * (=> exact 0 at the upper clamp edge); sum order ((wa*f00+wb*f01)+wc*f10)+wd*f11. */
+static inline float bilinear(const float *f, int h, int w, float y, float x, int64_t *ox0, int64_t *oy0) {
+    int64_t x0 = (int64_t)floorf(x), y0 = (int64_t)floorf(y);
+    int64_t x1 = x0 + 1, y1 = y0 + 1;
+    x0 = clampi(x0, 0, w - 1); x1 = clampi(x1, 0, w - 1);
+    y0 = clampi(y0, 0, h - 1); y1 = clampi(y1, 0, h - 1);
+    float wa = ((float)x1 - x) * ((float)y1 - y);
+    float wb = (x - (float)x0) * ((float)y1 - y);
+    float wc = ((float)x1 - x) * (y - (float)y0);
+    float wd = (x - (float)x0) * (y - (float)y0);
+    float r = wa * f[(size_t)y0 * w + x0] + wb * f[(size_t)y0 * w + x1];
+    r = r + wc * f[(size_t)y1 * w + x0];
+    r = r + wd * f[(size_t)y1 * w + x1];
+    if (ox0) { *ox0 = x0; *oy0 = y0; }
+    return r;
+}
+
+SO_API void so_bilinear(const float *f, int h, int w, const float *y, const float *x, float *out, int64_t n) {
+    for (int64_t k = 0; k < n; ++k) out[k] = bilinear(f, h, w, y[k], x[k], 0, 0);
+}
+
+/* navier_stokes.py:74-109  advection_step(field[R,C]; u[h+1,w], v[h,w+1]) on the field's own index grid.
+ * u sampled at (y, clamp(x+0.5, 0, w-1)); v at (clamp(y+0.5, 0, h-1), x);
+ * prev = clamp(X - dt*vel, 0, dim-1); out = bilinear(field, prev_y, prev_x).
+ * Optional x0/y0 (int64) receive the final gather's clamped floor indices (bit-exact checks). */
+SO_API void so_advect(const float *field, float *out, int R, int C, const float *u, const float *v,
+                      int h, int w, double dt, int64_t *x0o, int64_t *y0o) {
+    const float fdt = (float)dt;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            float Y = (float)i, X = (float)j;
+            float xu = clampf(X + 0.5f, 0.0f, (float)(w - 1));          /* u.shape[1]-1 */
+            float ui = bilinear(u, h + 1, w, Y, xu, 0, 0);
+            float yv = clampf(Y + 0.5f, 0.0f, (float)(h - 1));          /* v.shape[0]-1 */
+            float vi = bilinear(v, h, w + 1, yv, X, 0, 0);
+            float px = clampf(X - fdt * ui, 0.0f, (float)(C - 1));
+            float py = clampf(Y - fdt * vi, 0.0f, (float)(R - 1));
+            int64_t x0, y0;
+            out[(size_t)i * C + j] = bilinear(field, R, C, py, px, &x0, &y0);
+            if (x0o) { x0o[(size_t)i * C + j] = x0; y0o[(size_t)i * C + j] = y0; }
+        }
+}
+
+/* navier_stokes.py:151-173  step(): buoyancy, diffuse u/v/density (density: visc*0.1 in double),
+ * project, three sequentially dependent advects, decay.  scratch: >= 3*(h+1)*(w+1) floats. */
+SO_API void so_step(float *u, float *v, float *p, float *density, int h, int w, double dt, double visc,
+                    int jacobi_iters, float *scratch) {
+    const size_t nu = (size_t)(h + 1) * w, nv = (size_t)h * (w + 1), nc = (size_t)h * w;
+    float *t0 = scratch, *t1 = scratch + (size_t)(h + 1) * (w + 1), *t2 = t1 + (size_t)(h + 1) * (w + 1);
+    so_buoyancy(v, density, h, w, dt);
+    so_diffuse(u, t0, h + 1, w, dt, visc);        memcpy(u, t0, nu * sizeof(float));
+    so_diffuse(v, t0, h, w + 1, dt, visc);        memcpy(v, t0, nv * sizeof(float));
+    so_diffuse(density, t0, h, w, dt, visc * 0.1); memcpy(density, t0, nc * sizeof(float));
+    so_project(u, v, p, t1, t2, h, w, dt, jacobi_iters);
+    so_advect(u, t0, h + 1, w, u, v, h, w, dt, 0, 0);       memcpy(u, t0, nu * sizeof(float));
+    so_advect(v, t0, h, w + 1, u, v, h, w, dt, 0, 0);       memcpy(v, t0, nv * sizeof(float));
+    so_advect(density, t0, h, w, u, v, h, w, dt, 0, 0);
+    for (size_t k = 0; k < nc; ++k) density[k] = t0[k] * 0.995f;
+}
+
+/* fractal_generator.py:12-31  generate_perlin_noise: X,Y = meshgrid(linspace(0,10,w), linspace(0,10,h), 'ij')
+ * -> out[i][j] over [w][h], sum_{o<6} amp*sin(f*x[i])*cos(f*y[j]); (noise+1)/2.  Square use only. */
+SO_API void so_perlin(int h, int w, float *out) {
+    float *x = (float *)malloc(sizeof(float) * w), *y = (float *)malloc(sizeof(float) * h);
+    so_linspace(0.0f, 10.0f, w, x);
+    so_linspace(0.0f, 10.0f, h, y);
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < h; ++j) {
+            float noise = 0.0f;
+            double amp = 1.0, freq = 1.0;     /* python floats */
+            for (int o = 0; o < 6; ++o) {
+                float s = sinf((float)freq * x[i]);
+                float c = cosf((float)freq * y[j]);
+                float t = (float)amp * s;
+                t = t * c;
+                noise = noise + t;
+                amp *= 0.5; freq *= 2.0;
+            }
+            out[(size_t)i * h + j] = (noise + 1.0f) / 2.0f;
+        }
+    free(x); free(y);
+}
+
+/* fractal_generator.py:33-51  generate_mandelbrot_field: c = x[i] + 1j*y[j] over [w][h];
+ * per iteration: mask = |z|<=2 ; z = z*z + c (complex mult: re = a*a-b*b, im = a*b+b*a) ; count = it.
+ * Returns the integer escape counts (reference returns count/iterations). */
+SO_API void so_mandelbrot_counts(int h, int w, int iterations, uint8_t *counts) {
+    float *x = (float *)malloc(sizeof(float) * w), *y = (float *)malloc(sizeof(float) * h);
+    so_linspace(-2.5f, 1.5f, w, x);
+    so_linspace(-1.5f, 1.5f, h, y);
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < h; ++j) {
+            float cr = x[i], ci = y[j], zr = 0.0f, zi = 0.0f;
+            int cnt = 0;
+            for (int it = 0; it < iterations; ++it) {
+                float m = sqrtf(zr * zr + zi * zi);
+                if (!(m <= 2.0f)) break;          /* once escaped, |z| stays > 2 is NOT guaranteed by the
+                                                     reference either: it freezes z (masked update), so break is exact */
+                float rr = zr * zr - zi * zi;
+                float ab = zr * zi;
+                float ii = ab + ab;
+                zr = rr + cr; zi = ii + ci;
+                cnt = it;
+            }
+            counts[(size_t)i * h + j] = (uint8_t)cnt;
+        }
+    free(x); free(y);
+}
+
+/* fractal_generator.py:53-62  fractal_field = 0.7*perlin + 0.3*(counts/iterations). */
+SO_API void so_fractal_field(int h, int w, float *out) {
+    size_t n = (size_t)h * w;
+    float *per = (float *)malloc(sizeof(float) * n);
+    uint8_t *cnt = (uint8_t *)malloc(n);
+    so_perlin(h, w, per);
+    so_mandelbrot_counts(h, w, 100, cnt);
+    for (size_t k = 0; k < n; ++k) {
+        float m = (float)cnt[k] / 100.0f;
+        out[k] = 0.7f * per[k] + 0.3f * m;
+    }
+    free(per); free(cnt);
+}
+
+/* fractal_generator.py:62  field + intensity*fractal_field*field  == field + ((float)intensity*F)*field. */
+SO_API void so_apply_fractal(const float *field, const float *fractal, float *out, size_t n, double intensity) {
+    const float fi = (float)intensity;
+    for (size_t k = 0; k < n; ++k) {
+        float t = fi * fractal[k];
+        t = t * field[k];
+        out[k] = field[k] + t;
+    }
+}
+
+/* ------------------------------------------------------------------ chaos statistics
+ * smoke_simulator.py:92-122  box counting of (frame > mean) at scales 2,4,8,16,32. mean is passed in
+ * (torch .mean() is a pairwise fp32 reduction; callers pass the value they want to test against). */
+SO_API void so_box_counts(const float *frame, int h, int w, float mean, int64_t *counts5) {
+    static const int scales[5] = {2, 4, 8, 16, 32};
+    for (int s = 0; s < 5; ++s) {
+        int sc = scales[s], bh = h / sc, bw = w / sc;
+        int64_t c = 0;
+        for (int bi = 0; bi < bh; ++bi)
+            for (int bj = 0; bj < bw; ++bj) {
+                int any = 0;
+                for (int i = bi * sc; i < (bi + 1) * sc && !any; ++i)
+                    for (int j = bj * sc; j < (bj + 1) * sc; ++j)
+                        if (frame[(size_t)i * w + j] > mean) { any = 1; break; }
+                c += any;
+            }
+        counts5[s] = c;
+    }
+}
+
+/* smoke_simulator.py:134-135  torch.histogram(bins=256, range=(0,1)): values outside [0,1] dropped,
+ * exactly 1.0 lands in the last bin.  aten HistogramKernel: pos = (x-lo)/(hi-lo)*bins computed in fp32. */
+SO_API void so_hist256(const float *frame, size_t n, int64_t *hist) {
+    memset(hist, 0, 256 * sizeof(int64_t));
+    for (size_t k = 0; k < n; ++k) {
+        float x = frame[k];
+        if (!(x >= 0.0f && x <= 1.0f)) continue;
+        int64_t pos = (int64_t)((x - 0.0f) / (1.0f - 0.0f) * 256);
+        if (pos == 256) pos = 255;
+        hist[pos] += 1;
+    }
+}
+
+/* ------------------------------------------------------------------ encoder (aten ops, fp64 accumulate)
+ * smokephys_net.py:24-32  Conv2d(1,64,7,p3)+b -> BN(eval) -> ReLU -> Conv2d(64,128,3,p1)+b -> BN(eval) -> ReLU
+ * -> AdaptiveAvgPool2d((D,D)) ; smokephys_net.py:90-91 adaptive_avg_pool2d -> (32,32).
+ * Arithmetic lives in PyTorch aten/oneDNN (third party, torch 2.10.0; summation order unspecified), so this
+ * restatement accumulates in double and is pinned to the captured features at 1e-5 relative. */
+static void conv2d_bn_relu(const float *in, int Cin, int H, int W, const float *wgt, const float *bias, int Cout, int K,
+                           const float *bn_w, const float *bn_b, const float *bn_mean, const float *bn_var,
+                           float *out) {
+    const int P = K / 2;
+    for (int co = 0; co < Cout; ++co) {
+        /* BN eval: (x-mean)/sqrt(var+eps)*w+b, eps=1e-5 (fp32 ops in aten; double here) */
+        double inv = 1.0 / sqrt((double)bn_var[co] + 1e-5);
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                double acc = 0.0;
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int ki = 0; ki < K; ++ki) {
+                        int ii = i + ki - P;
+                        if (ii < 0 || ii >= H) continue;
+                        for (int kj = 0; kj < K; ++kj) {
+                            int jj = j + kj - P;
+                            if (jj < 0 || jj >= W) continue;
+                            acc += (double)in[((size_t)ci * H + ii) * W + jj] *
+                                   (double)wgt[(((size_t)co * Cin + ci) * K + ki) * K + kj];
+                        }
+                    }
+                double x = acc + (double)bias[co];
+                x = (x - (double)bn_mean[co]) * inv * (double)bn_w[co] + (double)bn_b[co];
+                out[((size_t)co * H + i) * W + j] = x > 0.0 ? (float)x : 0.0f;
+            }
+    }
+}
+
+/* F.adaptive_avg_pool2d: window [floor(o*I/O), ceil((o+1)*I/O)). */
+static void adaptive_pool(const float *in, int C, int H, int W, int OH, int OW, float *out) {
+    for (int c = 0; c < C; ++c)
+        for (int oi = 0; oi < OH; ++oi) {
+            int i0 = (int)((int64_t)oi * H / OH), i1 = (int)(((int64_t)(oi + 1) * H + OH - 1) / OH);
+            for (int oj = 0; oj < OW; ++oj) {
+                int j0 = (int)((int64_t)oj * W / OW), j1 = (int)(((int64_t)(oj + 1) * W + OW - 1) / OW);
+                double s = 0.0;
+                for (int i = i0; i < i1; ++i)
+                    for (int j = j0; j < j1; ++j) s += (double)in[((size_t)c * H + i) * W + j];
+                out[((size_t)c * OH + oi) * OW + oj] = (float)(s / (double)((i1 - i0) * (j1 - j0)));
+            }
+        }
+}
+
+/* One frame [H,W] -> features [128,32,32]. params: pointers in state_dict order. input_dim = D. */
+SO_API void so_encoder_frame(const float *frame, int H, int W, int input_dim,
+                             const float *c1w, const float *c1b, const float *bn1w, const float *bn1b,
+                             const float *bn1m, const float *bn1v,
+                             const float *c2w, const float *c2b, const float *bn2w, const float *bn2b,
+                             const float *bn2m, const float *bn2v,
+                             float *conv1_act /* optional [64,H,W] */, float *features /* [128,32,32] */) {
+    float *a1 = (float *)malloc(sizeof(float) * 64 * (size_t)H * W);
+    float *a2 = (float *)malloc(sizeof(float) * 128 * (size_t)H * W);
+    float *pl = (float *)malloc(sizeof(float) * 128 * (size_t)input_dim * input_dim);
+    conv2d_bn_relu(frame, 1, H, W, c1w, c1b, 64, 7, bn1w, bn1b, bn1m, bn1v, a1);
+    if (conv1_act) memcpy(conv1_act, a1, sizeof(float) * 64 * (size_t)H * W);
+    conv2d_bn_relu(a1, 64, H, W, c2w, c2b, 128, 3, bn2w, bn2b, bn2m, bn2v, a2);
+    adaptive_pool(a2, 128, H, W, input_dim, input_dim, pl);
+    adaptive_pool(pl, 128, input_dim, input_dim, 32, 32, features);
+    free(a1); free(a2); free(pl);
+}

@@ -1,0 +1,212 @@
+"""Pins the CPU oracle (oracle/smoke_oracle.c) against golden vectors captured from the reference
+(tests/golden/generate_golden.py).  CPU only.  Stepper stages are compared BIT-EXACT: the oracle restates
+the reference's fp32 operation order, and torch's CPU elementwise kernels round once per op.
+Only transcendental-function call sites (exp in add_smoke_source, sin/cos in perlin) get a tolerance,
+because torch uses SLEEF and the oracle uses libm (<= 2 ulp apart)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import rel_err
+
+STAGES = ["in", "buoy", "diff", "proj", "advu", "advv", "advd", "out"]
+
+
+def _load_state(ns, g, tag):
+    ns.u, ns.v = g[f"{tag}_u"].copy(), g[f"{tag}_v"].copy()
+    ns.p, ns.density = g[f"{tag}_p"].copy(), g[f"{tag}_density"].copy()
+
+
+def _assert_state(ns, g, tag):
+    for k in ("u", "v", "p", "density"):
+        np.testing.assert_array_equal(getattr(ns, k), g[f"{tag}_{k}"], err_msg=f"{tag}_{k}")
+
+
+@pytest.mark.parametrize("tag,shape", [("s1", (64, 64)), ("s2", (64, 64)), ("r1", (40, 56))])
+def test_stepper_stages_bit_exact(golden, tag, shape):
+    g = golden("physics_stages_64.npz")
+    ns = oracle.OracleNS(shape)
+    _load_state(ns, g, f"{tag}_in")
+    ns.buoyancy()
+    _assert_state(ns, g, f"{tag}_buoy")
+    ns.u = ns.diffusion_step(ns.u, ns.viscosity)
+    ns.v = ns.diffusion_step(ns.v, ns.viscosity)
+    ns.density = ns.diffusion_step(ns.density, ns.viscosity * 0.1)
+    _assert_state(ns, g, f"{tag}_diff")
+    np.testing.assert_array_equal(ns.divergence(), g[f"{tag}_div"])
+    ns.pressure_projection()
+    _assert_state(ns, g, f"{tag}_proj")
+    ns.u = ns.advection_step(ns.u, ns.u, ns.v)
+    _assert_state(ns, g, f"{tag}_advu")
+    ns.v = ns.advection_step(ns.v, ns.u, ns.v)
+    _assert_state(ns, g, f"{tag}_advv")
+    ns.density = ns.advection_step(ns.density, ns.u, ns.v)
+    _assert_state(ns, g, f"{tag}_advd")
+    # fused step() from the same input
+    ns2 = oracle.OracleNS(shape)
+    _load_state(ns2, g, f"{tag}_in")
+    ns2.step()
+    _assert_state(ns2, g, f"{tag}_out")
+
+
+def test_upper_edge_quirk(golden):
+    """bilinear returns 0 at the upper clamp edge -> last row/col of every advected field is 0."""
+    g = golden("physics_stages_64.npz")
+    for k in ("u", "v", "density"):
+        a = g[f"s1_out_{k}"]
+        assert not a[-1, :].any() and not a[:, -1].any()
+    f = np.arange(12, dtype=np.float32).reshape(3, 4) + 1
+    out = oracle.bilinear_interpolate(f, np.array([1.0, 2.0, 0.5], np.float32), np.array([3.0, 1.0, 1.5], np.float32))
+    assert out[0] == 0.0 and out[1] == 0.0 and out[2] == np.float32(0.25 * (2 + 3 + 6 + 7))
+
+
+def test_add_source(golden):
+    g = golden("physics_stages_64.npz")
+    ns = oracle.OracleNS((64, 64))
+    ns.add_smoke_source(32, 32, radius=8, intensity=1.0)
+    ref = g["source_density"]
+    assert np.array_equal(ns.density != 0, ref != 0)            # mask is index work: exact
+    assert int((ref != 0).sum()) <= 201
+    assert rel_err(ns.density, ref) < 5e-7                      # expf vs SLEEF
+
+
+def test_backtrace_indices_bit_exact(golden):
+    g = golden("backtrace_64.npz")
+    for st in (1, 2, 50):
+        ns = oracle.OracleNS((64, 64))
+        _load_state(ns, g, f"st{st}_pre")
+        out, x0, y0 = ns.advection_step(ns.u, ns.u, ns.v, want_indices=True)
+        np.testing.assert_array_equal(x0, g[f"st{st}_u_x0"]); np.testing.assert_array_equal(y0, g[f"st{st}_u_y0"])
+        ns.u = out
+        out, x0, y0 = ns.advection_step(ns.v, ns.u, ns.v, want_indices=True)
+        np.testing.assert_array_equal(x0, g[f"st{st}_v_x0"]); np.testing.assert_array_equal(y0, g[f"st{st}_v_y0"])
+        ns.v = out
+        out, x0, y0 = ns.advection_step(ns.density, ns.u, ns.v, want_indices=True)
+        np.testing.assert_array_equal(x0, g[f"st{st}_d_x0"]); np.testing.assert_array_equal(y0, g[f"st{st}_d_y0"])
+    # strong velocities: indices far from the identity map
+    ns = oracle.OracleNS((48, 48))
+    ns.u, ns.v, ns.density = g["big_u"].copy(), g["big_v"].copy(), g["big_density"].copy()
+    for nm, fld in (("u", ns.u), ("v", ns.v), ("d", ns.density)):
+        out, x0, y0 = ns.advection_step(fld, ns.u, ns.v, want_indices=True)
+        np.testing.assert_array_equal(x0, g[f"big_{nm}_x0"]); np.testing.assert_array_equal(y0, g[f"big_{nm}_y0"])
+        np.testing.assert_array_equal(out, g[f"big_{nm}_out"])
+        ident = np.broadcast_to(np.arange(fld.shape[1]), fld.shape)
+        assert (x0 != ident).mean() > 0.5
+
+
+def test_trajectory_from_golden_source_bit_exact(golden):
+    """50/100 steps from the reference's own initial density: bit-exact end state."""
+    g = golden("physics_traj_64_1src_50.npz")
+    ns = oracle.OracleNS((64, 64))
+    ns.density = g["src_density"].copy()
+    sums = []
+    for _ in range(50):
+        sums.append(float(ns.step().astype(np.float64).sum()))
+    for k in ("u", "v", "p", "density"):
+        np.testing.assert_array_equal(getattr(ns, k), g[f"final_{k}"])
+    np.testing.assert_allclose(sums, g["density_sums"], rtol=1e-12)   # fp64 sum order only
+    assert abs(sums[-1] - 34.338299) < 1e-4                     # SURVEY 8c sanity value
+
+
+@pytest.mark.parametrize("N,steps", [(64, 50), (128, 100), (256, 200)])
+def test_two_source_trajectories(golden, N, steps):
+    g = golden(f"physics_traj_{N}_2src_{steps}.npz")
+    # (a) from the reference's initial density: bit-exact
+    ns = oracle.OracleNS((N, N))
+    ns.density = g["src_density"].copy()
+    for _ in range(steps):
+        ns.step()
+    for k in ("u", "v", "p", "density"):
+        np.testing.assert_array_equal(getattr(ns, k), g[f"final_{k}"])
+    frame = oracle.apply_fractal_perturbation(ns.density, 0.05)
+    assert rel_err(frame, g["final_frame_fractal"]) < 1e-6
+    # (b) from the oracle's own add_source (libm expf): within 1e-6 of the reference
+    sim = oracle.OracleSmokeSimulator((N, N))
+    sim.add_incense_source([(N // 2, N // 2), (N // 4, N // 3)], [1.0, 1.7])
+    for _ in range(steps):
+        sim.ns_solver.step()
+    for k in ("u", "v", "p", "density"):
+        assert rel_err(getattr(sim.ns_solver, k), g[f"final_{k}"]) < 2e-6, k
+
+
+@pytest.mark.parametrize("N", [64, 128, 256])
+def test_fractal(golden, N):
+    g = golden(f"fractal_{N}.npz")
+    np.testing.assert_array_equal(oracle.linspace(0.0, 10.0, N), g["lin_perlin"])
+    np.testing.assert_array_equal(oracle.linspace(-2.5, 1.5, N), g["lin_mx"])
+    np.testing.assert_array_equal(oracle.linspace(-1.5, 1.5, N), g["lin_my"])
+    np.testing.assert_array_equal(oracle.mandelbrot_counts(N, N), g["mandel_counts"])   # integer work: exact
+    assert np.abs(oracle.perlin(N, N) - g["perlin"]).max() < 1e-6
+    assert np.abs(oracle.fractal_field(N, N) - g["fractal_field"]).max() < 1e-6
+    ones = np.ones((N, N), np.float32)
+    assert rel_err(oracle.apply_fractal_perturbation(ones, 0.05), g["ones_perturbed"]) < 1e-6
+
+
+def test_linspace_probe(golden):
+    g = golden("linspace_probe.npz")
+    rng = dict(p=(0.0, 10.0), mx=(-2.5, 1.5), my=(-1.5, 1.5))
+    for k, ref in g.items():
+        nm, n = k.split("_")
+        np.testing.assert_array_equal(oracle.linspace(*rng[nm], int(n)), ref, err_msg=k)
+
+
+@pytest.mark.parametrize("N", [64, 128])
+def test_dataset_frame_stream(golden, N):
+    """np.random.seed(0) -> identical source lists and frame sequence."""
+    g = golden(f"dataset_seed0_{N}.npz")
+    np.random.seed(0)
+    nsamp = 2 if N == 64 else 1
+    sim = oracle.OracleSmokeSimulator((N, N), cache_fractal=True)
+    for i in range(nsamp):
+        sim.ns_solver.setup_grid()
+        pos, inten = oracle.draw_sources((N, N))
+        np.testing.assert_array_equal(np.array(pos, dtype=np.int64), g[f"s{i}_positions"])
+        np.testing.assert_array_equal(np.array(inten), g[f"s{i}_intensities"])
+        sim.add_incense_source(pos, inten)
+        seq, chaos = [], []
+        for t in range(20):
+            seq.append(sim.simulate_step())
+            if t >= 10:
+                f = sim.get_chaos_features()
+                if f:
+                    chaos.append(f)
+        seq = np.stack(seq)
+        if N == 64:
+            assert rel_err(seq, g[f"s{i}_sequence"]) < 2e-6
+        else:
+            assert rel_err(seq[[0, 5, 10, 19]], g[f"s{i}_sequence_sel"]) < 2e-6
+        np.testing.assert_allclose(seq.astype(np.float64).sum(axis=(1, 2)), g[f"s{i}_frame_sums"], rtol=2e-6)
+        avg = [np.mean([c[k] for c in chaos]) for k in ("lyapunov_exponent", "fractal_dimension", "entropy")]
+        np.testing.assert_allclose(avg, g[f"s{i}_chaos"], rtol=1e-4, atol=1e-6)
+    if N == 128:
+        assert g["s0_positions"].tolist() == [[67, 84]]          # SURVEY 8c probe values
+        assert abs(g["s0_intensities"][0] - 1.4041450641) < 1e-9
+
+
+def test_chaos_stats_integer_exact(golden):
+    g = golden("chaos_stats_64.npz")
+    sim = oracle.OracleSmokeSimulator((64, 64))
+    sim.history = [f for f in g["frames"]]
+    np.testing.assert_array_equal(sim.box_counts(), g["box_counts"])
+    np.testing.assert_array_equal(sim.hist_counts(), g["hist_counts"])
+    f = sim.get_chaos_features()
+    np.testing.assert_allclose([f["lyapunov_exponent"], f["fractal_dimension"], f["entropy"]], g["feats"],
+                               rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("N", [64, 128])
+def test_encoder_features(golden, N):
+    """CNN features within 1e-4 rel (BASELINE.json tolerance) -- the oracle accumulates in fp64, the
+    reference in fp32 (oneDNN), so they agree to ~1e-6."""
+    w = golden("encoder_weights.npz")
+    g = golden(f"encoder_io_{N}.npz")
+    frames = g["frames"]
+    if N == 64:
+        feats, c1 = oracle.encoder_features(frames[:1], w, want_conv1=True)
+        assert rel_err(c1, g["conv1_act"]) < 1e-5
+        assert rel_err(feats, g["features"][:1]) < 1e-5
+        feats = oracle.encoder_features(frames[-1:], w)
+        assert rel_err(feats, g["features"][-1:]) < 1e-5
+    else:
+        feats = oracle.encoder_features(frames[-1:], w)         # the dense frame
+        assert rel_err(feats, g["features"][-1:]) < 1e-5
