@@ -1,0 +1,153 @@
+/*
+ * smokehip.h -- C ABI of libsmokehip.so: the MI355X (gfx950) implementation of the SmokePhysAI hot path.
+ *
+ * The reference (MengAiDev/SmokePhysAI) has no FFI: its boundary for this path is the Python class API
+ *   src/physics/navier_stokes.py:6-173   NavierStokesSimulator
+ *   src/physics/smoke_simulator.py:8-45  SmokeSimulator.{add_incense_source,simulate_step}
+ *   src/physics/fractal_generator.py:5-62 FractalGenerator
+ *   src/models/smokephys_net.py:24-32,87-91  SmokePhysNet.input_encoder (+ pooling)
+ * Each entry point below names the reference interface it replaces.  Callers are the drop-in Python
+ * classes in smokephysai_amd/ (ctypes); INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 = smk_status; smk_last_error() gives a thread-local message;
+ *  - all device memory for state/frames/weights/features is CALLER-OWNED (torch tensors): the library never
+ *    frees or reallocates it; library-owned scratch lives in the handle and dies with smk_sim_destroy;
+ *  - all work is enqueued on the caller-supplied hipStream_t (passed as void*), no implicit sync;
+ *  - a handle is not thread-safe; distinct handles are independent;
+ *  - fields are fp32, batch-major [B][rows][pitch] with explicit row pitches (in floats):
+ *        u [B][H+1][pitch_c]  v [B][H][pitch_v]  p,density [B][H][pitch_c]     pitch_c >= W, pitch_v >= W+1
+ *    (the reference's shapes are u[H+1,W], v[H,W+1], p/density[H,W]: navier_stokes.py:27-32).
+ */
+#ifndef SMOKEHIP_H
+#define SMOKEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMK_ABI_VERSION 1
+
+typedef enum smk_status {
+    SMK_OK = 0,
+    SMK_ERR_INVALID = -1,      /* bad argument / shape */
+    SMK_ERR_HIP = -2,          /* a HIP runtime call failed (message has hipGetErrorString) */
+    SMK_ERR_UNSUPPORTED = -3,  /* valid in the reference, not built here (message says what) */
+    SMK_ERR_NO_DEVICE = -4
+} smk_status;
+
+int smk_abi_version(void);
+const char *smk_last_error(void);
+
+/* ------------------------------------------------------------------ simulation state */
+typedef struct smk_sim smk_sim; /* opaque: one BATCH of independent grids */
+
+typedef struct smk_sim_desc {
+    int32_t batch, height, width;   /* B grids of H x W (reference: grid_size=(H,W), B=1) */
+    int32_t jacobi_iters;           /* reference hard-codes 20 (navier_stokes.py:139) */
+    double dt, viscosity;           /* doubles: the reference multiplies python floats before casting */
+    int32_t device_id;
+    int32_t pitch_c, pitch_v;       /* row pitches in floats */
+    float *u, *v, *p, *density;     /* caller-owned device pointers, layout above */
+} smk_sim_desc;
+
+/* NavierStokesSimulator.__init__ (navier_stokes.py:9-22): binds the caller's state tensors, allocates
+ * scratch (ping-pong fields, divergence), computes the shape-only fractal constant on the device. Does NOT
+ * zero the state: call smk_sim_reset. */
+int smk_sim_create(const smk_sim_desc *desc, smk_sim **out);
+int smk_sim_destroy(smk_sim *sim);
+
+/* NavierStokesSimulator.setup_grid (navier_stokes.py:24-35): zero u,v,p,density of the grids whose byte in
+ * grid_mask (host, B bytes) is non-zero; NULL = all grids. */
+int smk_sim_reset(smk_sim *sim, const uint8_t *grid_mask, void *stream);
+
+typedef struct smk_source {
+    int32_t grid;       /* batch index */
+    int32_t x, y;       /* (column, row), as add_smoke_source(x, y, ...) */
+    int32_t radius;
+    double intensity;
+} smk_source;
+
+/* NavierStokesSimulator.add_smoke_source (navier_stokes.py:37-48), n sources in one launch; sources of the
+ * same grid are applied in list order (fp32 += is order-sensitive). `sources` is a HOST array. */
+int smk_sim_add_sources(smk_sim *sim, const smk_source *sources, int32_t n, void *stream);
+
+/* NavierStokesSimulator.step x n_steps (navier_stokes.py:151-173) + SmokeSimulator.simulate_step's frame emit
+ * (smoke_simulator.py:31-39).  After step t (0-based) the emitted frame of grid b is written to
+ *     frames + t*frame_stride_t + b*frame_stride_b   as [H][W] contiguous fp32      (frames may be NULL)
+ * with frame = density + (fractal_intensity*F)*density when add_fractal != 0 (fractal_generator.py:53-62, F the
+ * shape-only constant), else frame = density.  Solver state keeps the unperturbed density. */
+int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t frame_stride_b, int64_t frame_stride_t,
+                 int32_t add_fractal, double fractal_intensity, void *stream);
+
+/* Single stages of step() on the handle's state, for per-stage parity tests.  State after each call is
+ * back in the caller's tensors. */
+typedef enum smk_stage {
+    SMK_STAGE_BUOY_DIFFUSE = 0, /* navier_stokes.py:154-160 */
+    SMK_STAGE_PROJECT = 1,      /* navier_stokes.py:133-149 */
+    SMK_STAGE_ADVECT_U = 2,     /* navier_stokes.py:166 */
+    SMK_STAGE_ADVECT_V = 3,     /* navier_stokes.py:167 */
+    SMK_STAGE_ADVECT_D = 4      /* navier_stokes.py:168-171 (advect density + 0.995 decay) */
+} smk_stage;
+int smk_sim_run_stage(smk_sim *sim, int32_t stage, void *stream);
+
+/* Divergence field of the current state (navier_stokes.py:136) -> out [B][H][W] contiguous. */
+int smk_sim_divergence(smk_sim *sim, float *out, void *stream);
+
+/* Back-trace gather indices of advection_step(field; u, v) on the current state (navier_stokes.py:87-92,
+ * 115-123): which = 0 (field=u), 1 (field=v), 2 (field=density). x0,y0: int32 [B][R][C] contiguous. */
+int smk_sim_backtrace(smk_sim *sim, int32_t which, int32_t *x0, int32_t *y0, void *stream);
+
+/* Device pointer to the fractal constants, [W][H] fp32 each (fractal_generator.py:12-51):
+ * kind 0 = perlin, 1 = mandelbrot escape counts/100, 2 = 0.7*perlin+0.3*mandelbrot. Square grids only. */
+int smk_sim_fractal(smk_sim *sim, int32_t kind, const float **dev_ptr);
+
+/* Stand-alone stateless ops (pure functions of the reference) -------------------------------------- */
+/* NavierStokesSimulator.diffusion_step(field, viscosity) (navier_stokes.py:50-72) on [B][R][pitch]. */
+int smk_diffuse(const float *in, float *out, int32_t B, int32_t R, int32_t C, int32_t pitch, double dt,
+                double viscosity, void *stream);
+/* FractalGenerator.apply_fractal_perturbation(field, intensity) (fractal_generator.py:53-62) on n_fields
+ * square [N][N] contiguous fields; computes the constant itself (cached per N per device). */
+int smk_apply_fractal(const float *in, float *out, int32_t n_fields, int32_t N, double intensity, void *stream);
+
+/* NavierStokesSimulator.advection_step(field, u, v) (navier_stokes.py:74-95) as a pure function on caller buffers:
+ * which = 0/1/2 selects the field's shape (u-like [H+1][pitch_c], v-like [H][pitch_v], cell [H][pitch_c]); no decay. */
+int smk_advect(const float *field, float *out, int32_t which, const float *u, const float *v, int32_t B, int32_t H,
+               int32_t W, int32_t pitch_c, int32_t pitch_v, double dt, void *stream);
+/* FractalGenerator.generate_perlin_noise / generate_mandelbrot_field (fractal_generator.py:12-51) for an N x N grid:
+ * writes [N][N] fp32 each (any pointer may be NULL): perlin, mandelbrot (counts/100), 0.7*perlin+0.3*mandelbrot. */
+int smk_fractal_constants(int32_t N, float *perlin, float *mandel, float *field, void *stream);
+
+/* ------------------------------------------------------------------ CNN encoder */
+typedef enum smk_dtype { SMK_F32 = 0, SMK_BF16X3 = 1, SMK_BF16 = 2 } smk_dtype;
+
+/* Eval-mode input_encoder weights (smokephys_net.py:24-32), device pointers, PyTorch layouts:
+ * conv1_w [64][1][7][7], conv2_w [128][64][3][3]; BN as (weight,bias,running_mean,running_var), eps 1e-5. */
+typedef struct smk_encoder_weights {
+    const float *conv1_w, *conv1_b, *bn1_w, *bn1_b, *bn1_mean, *bn1_var;
+    const float *conv2_w, *conv2_b, *bn2_w, *bn2_b, *bn2_mean, *bn2_var;
+} smk_encoder_weights;
+
+typedef struct smk_encoder smk_encoder; /* opaque: folded/re-laid-out weights on the device */
+
+int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *stream, smk_encoder **out);
+int smk_encoder_destroy(smk_encoder *enc);
+
+/* SmokePhysNet.input_encoder + both adaptive pools (smokephys_net.py:87-91):
+ * frames [B][H][W] fp32 (row pitch W, frame stride frame_stride floats) -> features [B][128][32][32] fp32.
+ * Requires H == W, H % 32 == 0, and input_dim a multiple/divisor of H (then the two pools compose to an
+ * (H/32)^2 block mean); anything else returns SMK_ERR_UNSUPPORTED. */
+int smk_encoder_forward(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H,
+                        int32_t W, int32_t input_dim, float *features, int32_t dtype, void *stream);
+
+/* conv1+BN+ReLU activations only (smokephys_net.py:25-27), [B][64][H][W] fp32 -- parity hook. */
+int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H,
+                      int32_t W, float *act, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMOKEHIP_H */

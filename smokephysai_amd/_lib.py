@@ -1,0 +1,104 @@
+"""ctypes binding of libsmokehip.so (C ABI: include/smokehip.h).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmokehip.so")
+
+SMK_F32, SMK_BF16X3, SMK_BF16 = 0, 1, 2
+STAGE_BUOY_DIFFUSE, STAGE_PROJECT, STAGE_ADVECT_U, STAGE_ADVECT_V, STAGE_ADVECT_D = range(5)
+DTYPES = {"f32": SMK_F32, "fp32": SMK_F32, "float32": SMK_F32, "bf16x3": SMK_BF16X3, "bf16": SMK_BF16}
+
+
+class SmkSimDesc(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("jacobi_iters", C.c_int32),
+                ("dt", C.c_double), ("viscosity", C.c_double), ("device_id", C.c_int32),
+                ("pitch_c", C.c_int32), ("pitch_v", C.c_int32),
+                ("u", C.c_void_p), ("v", C.c_void_p), ("p", C.c_void_p), ("density", C.c_void_p)]
+
+
+class SmkSource(C.Structure):
+    _fields_ = [("grid", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("radius", C.c_int32),
+                ("intensity", C.c_double)]
+
+
+class SmkEncoderWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("conv1_w", "conv1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
+                 "conv2_w", "conv2_b", "bn2_w", "bn2_b", "bn2_mean", "bn2_var")]
+
+
+# name -> (argtypes); every function returns int status except the two noted below
+_SIGNATURES = {
+    "smk_sim_create": [C.POINTER(SmkSimDesc), C.POINTER(C.c_void_p)],
+    "smk_sim_destroy": [C.c_void_p],
+    "smk_sim_reset": [C.c_void_p, C.c_char_p, C.c_void_p],
+    "smk_sim_add_sources": [C.c_void_p, C.POINTER(SmkSource), C.c_int32, C.c_void_p],
+    "smk_sim_step": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_void_p],
+    "smk_sim_run_stage": [C.c_void_p, C.c_int32, C.c_void_p],
+    "smk_sim_divergence": [C.c_void_p, C.c_void_p, C.c_void_p],
+    "smk_sim_backtrace": [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "smk_sim_fractal": [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)],
+    "smk_diffuse": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                    C.c_void_p],
+    "smk_apply_fractal": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p],
+    "smk_advect": [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                   C.c_int32, C.c_int32, C.c_double, C.c_void_p],
+    "smk_fractal_constants": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "smk_encoder_create": [C.POINTER(SmkEncoderWeights), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
+    "smk_encoder_destroy": [C.c_void_p],
+    "smk_encoder_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                            C.c_void_p, C.c_int32, C.c_void_p],
+    "smk_encoder_conv1": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
+}
+EXPORTS = ["smk_abi_version", "smk_last_error"] + list(_SIGNATURES)
+
+_lib = None
+
+
+class SmokeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libsmokehip.so (no GPU needed for this); raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C smokephysai_amd/csrc` (or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`). smokephysai_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.smk_abi_version.restype = C.c_int
+        L.smk_last_error.restype = C.c_char_p
+        for name, args in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SmokeHipError(f"libsmokehip error {rc}: {load().smk_last_error().decode()}")
+
+
+def require_cuda(device, what):
+    """The product has no CPU path: anything but a ROCm ('cuda') device is an error."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"{what}: device={device!r} is not a ROCm GPU. smokephysai_amd runs its hot path as HIP "
+                           "kernels on MI355X only; there is no CPU fallback.")
+    if not torch.cuda.is_available():
+        raise RuntimeError(f"{what}: no ROCm device is visible (torch.cuda.is_available() is False); "
+                           "smokephysai_amd has no CPU fallback.")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

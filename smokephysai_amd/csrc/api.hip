@@ -1,0 +1,419 @@
+// C ABI of libsmokehip.so (see include/smokehip.h for the contract and the reference interfaces replaced).
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "encoder.h"
+#include "stencil.h"
+
+namespace smk {
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+}  // namespace smk
+
+using namespace smk;
+
+struct smk_sim {
+    Geom g;
+    StateView s;          // caller-owned
+    StateView t;          // library scratch (u2, v2, p2, d2)
+    float *div = nullptr;
+    float *perlin = nullptr, *mandel = nullptr, *fractal = nullptr;   // [N][N], square grids only
+    uint8_t *dev_mask = nullptr;
+    SrcDev *dev_src = nullptr;
+    int *dev_first = nullptr;
+    int src_cap = 0;
+    int jacobi_iters = 20;
+    int device = 0;
+};
+
+struct smk_encoder {
+    EncoderDev e;
+    float *blob = nullptr;
+    int device = 0;
+};
+
+namespace {
+
+int set_device(int dev) {
+    SMK_HIP_TRY(hipSetDevice(dev));
+    return SMK_OK;
+}
+
+int check_launch(hipError_t e, const char *what) {
+    if (e != hipSuccess) {
+        set_error(std::string(what) + ": " + hipGetErrorString(e));
+        return SMK_ERR_HIP;
+    }
+    return SMK_OK;
+}
+
+int run_stage(smk_sim *sim, int stage, float *frames, int64_t fsb, const float *fractal, float fint, hipStream_t st) {
+    const Geom &g = sim->g;
+    StateView &s = sim->s, &t = sim->t;
+    switch (stage) {
+        case SMK_STAGE_BUOY_DIFFUSE:   // s -> t (u2, v2, d2)
+            return check_launch(launch_buoy_diffuse(g, s, t, st), "buoy_diffuse");
+        case SMK_STAGE_PROJECT: {      // on t.u, t.v with s.p
+            int rc = check_launch(launch_divergence(g, t.u, t.v, sim->div, g.pc, g.sc, st), "divergence");
+            if (rc) return rc;
+            rc = check_launch(launch_jacobi(g, s.p, t.p, sim->div, sim->jacobi_iters, st), "jacobi");
+            if (rc) return rc;
+            return check_launch(launch_grad_subtract(g, t.u, t.v, s.p, st), "grad_subtract");
+        }
+        case SMK_STAGE_ADVECT_U:       // u <- adv(u2; u2, v2)
+            return check_launch(launch_advect(g, 0, t.u, s.u, t.u, t.v, nullptr, 0, nullptr, 0.f, nullptr, nullptr, st),
+                                "advect_u");
+        case SMK_STAGE_ADVECT_V:       // v <- adv(v2; u, v2)
+            return check_launch(launch_advect(g, 1, t.v, s.v, s.u, t.v, nullptr, 0, nullptr, 0.f, nullptr, nullptr, st),
+                                "advect_v");
+        case SMK_STAGE_ADVECT_D:       // density <- adv(d2; u, v) * 0.995 (+ frame emit)
+            return check_launch(launch_advect(g, 2, t.d, s.d, s.u, s.v, frames, fsb, fractal, fint, nullptr, nullptr, st),
+                                "advect_d");
+    }
+    set_error("unknown stage");
+    return SMK_ERR_INVALID;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int smk_abi_version(void) { return SMK_ABI_VERSION; }
+const char *smk_last_error(void) { return g_err.c_str(); }
+
+int smk_sim_create(const smk_sim_desc *d, smk_sim **out) {
+    SMK_REQUIRE(d && out, "null desc/out");
+    SMK_REQUIRE(d->batch >= 1 && d->height >= 3 && d->width >= 3, "batch>=1, height,width>=3");
+    SMK_REQUIRE(d->pitch_c >= d->width && d->pitch_v >= d->width + 1, "pitch_c >= W and pitch_v >= W+1");
+    SMK_REQUIRE(d->jacobi_iters >= 0, "jacobi_iters >= 0");
+    SMK_REQUIRE(d->u && d->v && d->p && d->density, "null state pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible");
+        return SMK_ERR_NO_DEVICE;
+    }
+    int rc = set_device(d->device_id);
+    if (rc) return rc;
+    smk_sim *sim = new smk_sim();
+    Geom &g = sim->g;
+    g.B = d->batch; g.H = d->height; g.W = d->width; g.pc = d->pitch_c; g.pv = d->pitch_v;
+    g.su = (size_t)(g.H + 1) * g.pc; g.sv = (size_t)g.H * g.pv; g.sc = (size_t)g.H * g.pc;
+    g.dt = (float)d->dt;
+    g.coef_uv = (float)(d->dt * d->viscosity);              // navier_stokes.py:72,158-159
+    g.coef_d = (float)(d->dt * (d->viscosity * 0.1));       // navier_stokes.py:160
+    sim->s = {d->u, d->v, d->p, d->density};
+    sim->jacobi_iters = d->jacobi_iters;
+    sim->device = d->device_id;
+    size_t B = g.B;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](float **p, size_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, n * sizeof(float)); };
+    alloc(&sim->t.u, B * g.su); alloc(&sim->t.v, B * g.sv); alloc(&sim->t.p, B * g.sc); alloc(&sim->t.d, B * g.sc);
+    alloc(&sim->div, B * g.sc);
+    if (e == hipSuccess) e = hipMalloc((void **)&sim->dev_mask, B);
+    if (e == hipSuccess) e = hipMalloc((void **)&sim->dev_first, (B + 1) * sizeof(int));
+    if (g.H == g.W && e == hipSuccess) {
+        size_t n = (size_t)g.H * g.W;
+        alloc(&sim->perlin, n); alloc(&sim->mandel, n); alloc(&sim->fractal, n);
+        if (e == hipSuccess) e = launch_fractal_constants(g.H, sim->perlin, sim->mandel, sim->fractal, 0);
+        if (e == hipSuccess) e = hipStreamSynchronize(0);
+    }
+    if (e != hipSuccess) {
+        set_error(std::string("smk_sim_create: ") + hipGetErrorString(e));
+        smk_sim_destroy(sim);
+        return SMK_ERR_HIP;
+    }
+    *out = sim;
+    return SMK_OK;
+}
+
+int smk_sim_destroy(smk_sim *sim) {
+    if (!sim) return SMK_OK;
+    (void)hipSetDevice(sim->device);
+    float *ptrs[] = {sim->t.u, sim->t.v, sim->t.p, sim->t.d, sim->div, sim->perlin, sim->mandel, sim->fractal};
+    for (float *p : ptrs) if (p) (void)hipFree(p);
+    if (sim->dev_mask) (void)hipFree(sim->dev_mask);
+    if (sim->dev_first) (void)hipFree(sim->dev_first);
+    if (sim->dev_src) (void)hipFree(sim->dev_src);
+    delete sim;
+    return SMK_OK;
+}
+
+int smk_sim_reset(smk_sim *sim, const uint8_t *grid_mask, void *stream) {
+    SMK_REQUIRE(sim, "null sim");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = set_device(sim->device);
+    if (rc) return rc;
+    const uint8_t *dm = nullptr;
+    if (grid_mask) {
+        SMK_HIP_TRY(hipMemcpyAsync(sim->dev_mask, grid_mask, sim->g.B, hipMemcpyHostToDevice, st));
+        dm = sim->dev_mask;
+    }
+    return check_launch(launch_zero_state(sim->g, sim->s, dm, st), "zero_state");
+}
+
+int smk_sim_add_sources(smk_sim *sim, const smk_source *src, int32_t n, void *stream) {
+    SMK_REQUIRE(sim && (src || n == 0) && n >= 0, "null sim/sources");
+    if (n == 0) return SMK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = set_device(sim->device);
+    if (rc) return rc;
+    const int B = sim->g.B;
+    std::vector<int> first(B + 1, 0);
+    for (int k = 0; k < n; ++k) {
+        SMK_REQUIRE(src[k].grid >= 0 && src[k].grid < B, "source grid index out of range");
+        SMK_REQUIRE(src[k].radius >= 0, "radius >= 0");
+        first[src[k].grid + 1]++;
+    }
+    for (int b = 0; b < B; ++b) first[b + 1] += first[b];
+    std::vector<SrcDev> host(n);
+    std::vector<int> fill(first.begin(), first.end() - 1);
+    for (int k = 0; k < n; ++k) {      // stable counting sort by grid keeps the caller's order within a grid
+        const smk_source &q = src[k];
+        double r3 = (double)q.radius / 3.0;
+        host[fill[q.grid]++] = SrcDev{q.x, q.y, q.radius, (float)(2.0 * (r3 * r3)), (float)q.intensity};
+    }
+    if (n > sim->src_cap) {
+        if (sim->dev_src) SMK_HIP_TRY(hipFree(sim->dev_src));
+        sim->dev_src = nullptr;
+        SMK_HIP_TRY(hipMalloc((void **)&sim->dev_src, (size_t)n * sizeof(SrcDev)));
+        sim->src_cap = n;
+    }
+    SMK_HIP_TRY(hipMemcpyAsync(sim->dev_src, host.data(), (size_t)n * sizeof(SrcDev), hipMemcpyHostToDevice, st));
+    SMK_HIP_TRY(hipMemcpyAsync(sim->dev_first, first.data(), (size_t)(B + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    rc = check_launch(launch_add_sources(sim->g, sim->s.d, sim->dev_src, sim->dev_first, st), "add_sources");
+    if (rc) return rc;
+    SMK_HIP_TRY(hipStreamSynchronize(st));   // host staging vectors die here
+    return SMK_OK;
+}
+
+int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t fsb, int64_t fst, int32_t add_fractal,
+                 double fractal_intensity, void *stream) {
+    SMK_REQUIRE(sim && n_steps >= 0, "null sim / negative n_steps");
+    if (add_fractal && frames && !sim->fractal) {
+        // fractal_generator.py:44,49: the [w,h] mask indexes an [h,w] buffer -> the reference raises for h != w
+        set_error("fractal perturbation needs a square grid (reference raises an IndexError for H != W)");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = set_device(sim->device);
+    if (rc) return rc;
+    const float *fr = (add_fractal && frames) ? sim->fractal : nullptr;
+    for (int t = 0; t < n_steps; ++t) {
+        float *ft = frames ? frames + (size_t)t * fst : nullptr;
+        for (int stage = SMK_STAGE_BUOY_DIFFUSE; stage <= SMK_STAGE_ADVECT_D; ++stage) {
+            rc = run_stage(sim, stage, stage == SMK_STAGE_ADVECT_D ? ft : nullptr, fsb, fr, (float)fractal_intensity, st);
+            if (rc) return rc;
+        }
+    }
+    return SMK_OK;
+}
+
+int smk_sim_run_stage(smk_sim *sim, int32_t stage, void *stream) {
+    SMK_REQUIRE(sim, "null sim");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = set_device(sim->device);
+    if (rc) return rc;
+    const Geom &g = sim->g;
+    const size_t B = g.B;
+    StateView &s = sim->s, &t = sim->t;
+    // Stand-alone stage semantics: caller state in, caller state out.  Internally the step ping-pongs between the
+    // caller's tensors (s) and scratch (t); here the stage's inputs are first mirrored into the side it reads.
+    auto cp = [&](float *dst, const float *src, size_t n) {
+        return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    };
+    switch (stage) {
+        case SMK_STAGE_BUOY_DIFFUSE:
+            rc = run_stage(sim, stage, nullptr, 0, nullptr, 0.f, st);
+            if (rc) return rc;
+            SMK_HIP_TRY(cp(s.u, t.u, B * g.su)); SMK_HIP_TRY(cp(s.v, t.v, B * g.sv)); SMK_HIP_TRY(cp(s.d, t.d, B * g.sc));
+            return SMK_OK;
+        case SMK_STAGE_PROJECT:
+            SMK_HIP_TRY(cp(t.u, s.u, B * g.su)); SMK_HIP_TRY(cp(t.v, s.v, B * g.sv));
+            rc = run_stage(sim, stage, nullptr, 0, nullptr, 0.f, st);
+            if (rc) return rc;
+            SMK_HIP_TRY(cp(s.u, t.u, B * g.su)); SMK_HIP_TRY(cp(s.v, t.v, B * g.sv));
+            return SMK_OK;
+        case SMK_STAGE_ADVECT_U:      // reads (u, v) -> writes u
+            SMK_HIP_TRY(cp(t.u, s.u, B * g.su)); SMK_HIP_TRY(cp(t.v, s.v, B * g.sv));
+            return run_stage(sim, stage, nullptr, 0, nullptr, 0.f, st);
+        case SMK_STAGE_ADVECT_V:      // reads v (field), u (already advected), v -> writes v
+            SMK_HIP_TRY(cp(t.v, s.v, B * g.sv));
+            return run_stage(sim, stage, nullptr, 0, nullptr, 0.f, st);
+        case SMK_STAGE_ADVECT_D:
+            SMK_HIP_TRY(cp(t.d, s.d, B * g.sc));
+            return run_stage(sim, stage, nullptr, 0, nullptr, 0.f, st);
+    }
+    set_error("unknown stage");
+    return SMK_ERR_INVALID;
+}
+
+int smk_sim_divergence(smk_sim *sim, float *out, void *stream) {
+    SMK_REQUIRE(sim && out, "null sim/out");
+    int rc = set_device(sim->device);
+    if (rc) return rc;
+    const Geom &g = sim->g;
+    return check_launch(launch_divergence(g, sim->s.u, sim->s.v, out, g.W, (size_t)g.H * g.W, (hipStream_t)stream),
+                        "divergence");
+}
+
+int smk_sim_backtrace(smk_sim *sim, int32_t which, int32_t *x0, int32_t *y0, void *stream) {
+    SMK_REQUIRE(sim && x0 && y0 && which >= 0 && which <= 2, "null sim/x0/y0 or which not in 0..2");
+    int rc = set_device(sim->device);
+    if (rc) return rc;
+    const StateView &s = sim->s;
+    const float *field = which == 0 ? s.u : (which == 1 ? s.v : s.d);
+    return check_launch(launch_advect(sim->g, which, field, nullptr, s.u, s.v, nullptr, 0, nullptr, 0.f, x0, y0,
+                                      (hipStream_t)stream), "backtrace");
+}
+
+int smk_sim_fractal(smk_sim *sim, int32_t kind, const float **dev_ptr) {
+    SMK_REQUIRE(sim && dev_ptr && kind >= 0 && kind <= 2, "null sim/dev_ptr or kind not in 0..2");
+    if (!sim->fractal) {
+        set_error("fractal constants exist for square grids only");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    *dev_ptr = kind == 0 ? sim->perlin : (kind == 1 ? sim->mandel : sim->fractal);
+    return SMK_OK;
+}
+
+int smk_diffuse(const float *in, float *out, int32_t B, int32_t R, int32_t C, int32_t pitch, double dt, double viscosity,
+                void *stream) {
+    SMK_REQUIRE(in && out && in != out, "null or aliased in/out");
+    SMK_REQUIRE(B >= 1 && R >= 1 && C >= 1 && pitch >= C, "B,R,C >= 1, pitch >= C");
+    return check_launch(launch_diffuse(in, out, B, R, C, pitch, (float)(dt * viscosity), (hipStream_t)stream), "diffuse");
+}
+
+// fractal constant cache for the stateless smk_apply_fractal: one per (device, N)
+static std::mutex g_fr_mu;
+static std::map<std::pair<int, int>, float *> g_fr_cache;
+
+int smk_apply_fractal(const float *in, float *out, int32_t n_fields, int32_t N, double intensity, void *stream) {
+    SMK_REQUIRE(in && out && n_fields >= 1 && N >= 2, "null in/out or bad sizes");
+    int dev = 0;
+    SMK_HIP_TRY(hipGetDevice(&dev));
+    float *F = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_fr_mu);
+        auto it = g_fr_cache.find({dev, N});
+        if (it == g_fr_cache.end()) {
+            float *blob = nullptr;
+            size_t n = (size_t)N * N;
+            SMK_HIP_TRY(hipMalloc((void **)&blob, 3 * n * sizeof(float)));
+            int rc = check_launch(launch_fractal_constants(N, blob, blob + n, blob + 2 * n, (hipStream_t)stream), "fractal");
+            if (rc) return rc;
+            F = blob + 2 * n;
+            g_fr_cache[{dev, N}] = F;
+        } else {
+            F = it->second;
+        }
+    }
+    return check_launch(launch_apply_fractal(in, out, F, n_fields, N, (float)intensity, (hipStream_t)stream), "apply_fractal");
+}
+
+int smk_advect(const float *field, float *out, int32_t which, const float *u, const float *v, int32_t B, int32_t H,
+               int32_t W, int32_t pitch_c, int32_t pitch_v, double dt, void *stream) {
+    SMK_REQUIRE(field && out && u && v && field != out, "null or aliased pointers");
+    SMK_REQUIRE(which >= 0 && which <= 2 && B >= 1 && H >= 2 && W >= 2, "which in 0..2, B>=1, H,W>=2");
+    SMK_REQUIRE(pitch_c >= W && pitch_v >= W + 1, "pitch_c >= W and pitch_v >= W+1");
+    Geom g{};
+    g.B = B; g.H = H; g.W = W; g.pc = pitch_c; g.pv = pitch_v;
+    g.su = (size_t)(H + 1) * pitch_c; g.sv = (size_t)H * pitch_v; g.sc = (size_t)H * pitch_c;
+    g.dt = (float)dt;
+    // which == 2 here is a plain advect (no decay / frame emit): reuse the u/v-style path via a dedicated flag
+    return check_launch(launch_advect(g, which == 2 ? 3 : which, field, out, u, v, nullptr, 0, nullptr, 0.f, nullptr,
+                                      nullptr, (hipStream_t)stream), "advect");
+}
+
+int smk_fractal_constants(int32_t N, float *perlin, float *mandel, float *field, void *stream) {
+    SMK_REQUIRE(N >= 2, "N >= 2");
+    hipStream_t st = (hipStream_t)stream;
+    size_t n = (size_t)N * N;
+    float *tmp = nullptr;
+    SMK_HIP_TRY(hipMalloc((void **)&tmp, 3 * n * sizeof(float)));
+    int rc = check_launch(launch_fractal_constants(N, tmp, tmp + n, tmp + 2 * n, st), "fractal_constants");
+    hipError_t e = hipSuccess;
+    if (!rc && perlin) e = hipMemcpyAsync(perlin, tmp, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (!rc && e == hipSuccess && mandel) e = hipMemcpyAsync(mandel, tmp + n, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (!rc && e == hipSuccess && field) e = hipMemcpyAsync(field, tmp + 2 * n, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    return check_launch(e, "fractal_constants copy");
+}
+
+// ------------------------------------------------------------------ encoder
+int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *stream, smk_encoder **out) {
+    SMK_REQUIRE(w && out, "null weights/out");
+    const float *const *pp = (const float *const *)w;
+    for (size_t k = 0; k < sizeof(*w) / sizeof(float *); ++k) SMK_REQUIRE(pp[k], "null weight pointer");
+    int rc = set_device(device_id);
+    if (rc) return rc;
+    smk_encoder *enc = new smk_encoder();
+    enc->device = device_id;
+    const size_t n = 64 * 49 + 64 + 64 + 9 * 64 * 128 + 128 + 128;
+    hipError_t e = hipMalloc((void **)&enc->blob, n * sizeof(float));
+    if (e != hipSuccess) {
+        delete enc;
+        set_error(std::string("smk_encoder_create: ") + hipGetErrorString(e));
+        return SMK_ERR_HIP;
+    }
+    float *p = enc->blob;
+    enc->e.w2t = p; p += 9 * 64 * 128;     // 16-byte aligned first
+    enc->e.w1 = p; p += 64 * 49;
+    enc->e.s1 = p; p += 64;
+    enc->e.t1 = p; p += 64;
+    enc->e.s2 = p; p += 128;
+    enc->e.t2 = p;
+    rc = check_launch(launch_fold_weights(*w, enc->e, (hipStream_t)stream), "fold_weights");
+    if (rc) { smk_encoder_destroy(enc); return rc; }
+    *out = enc;
+    return SMK_OK;
+}
+
+int smk_encoder_destroy(smk_encoder *enc) {
+    if (!enc) return SMK_OK;
+    (void)hipSetDevice(enc->device);
+    if (enc->blob) (void)hipFree(enc->blob);
+    delete enc;
+    return SMK_OK;
+}
+
+static int encoder_shape_ok(int32_t B, int32_t H, int32_t W, int32_t input_dim) {
+    SMK_REQUIRE(B >= 1, "B >= 1");
+    if (H != W || H % 32 != 0 || (H / 32 != 2 && H / 32 != 4 && H / 32 != 8)) {
+        set_error("encoder: HIP path is built for square frames of 64, 128 or 256");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    if (input_dim <= 0 || input_dim % 32 != 0 || (input_dim % H != 0 && H % input_dim != 0)) {
+        set_error("encoder: input_dim must be a multiple of 32 and a multiple or divisor of H (pools must compose to a block mean)");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return SMK_OK;
+}
+
+int smk_encoder_forward(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H, int32_t W,
+                        int32_t input_dim, float *features, int32_t dtype, void *stream) {
+    SMK_REQUIRE(enc && frames && features, "null enc/frames/features");
+    SMK_REQUIRE(frame_stride >= (int64_t)H * W, "frame_stride >= H*W");
+    int rc = encoder_shape_ok(B, H, W, input_dim);
+    if (rc) return rc;
+    rc = set_device(enc->device);
+    if (rc) return rc;
+    if (dtype == SMK_F32)
+        return check_launch(launch_encoder_f32(frames, frame_stride, B, H, W, enc->e, features, (hipStream_t)stream), "encoder_f32");
+    set_error("encoder dtype not built (only SMK_F32 in this version)");
+    return SMK_ERR_UNSUPPORTED;
+}
+
+int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H, int32_t W,
+                      float *act, void *stream) {
+    SMK_REQUIRE(enc && frames && act && B >= 1 && H >= 1 && W >= 1, "null enc/frames/act or bad shape");
+    int rc = set_device(enc->device);
+    if (rc) return rc;
+    return check_launch(launch_conv1_only(frames, frame_stride, B, H, W, enc->e, act, (hipStream_t)stream), "conv1");
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

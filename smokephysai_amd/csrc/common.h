@@ -1,0 +1,47 @@
+// Shared host/device helpers of libsmokehip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/smokehip.h"
+
+namespace smk {
+
+void set_error(const std::string &msg);
+
+#define SMK_HIP_TRY(expr)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            smk::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+            return SMK_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+#define SMK_REQUIRE(cond, msg)                                                                    \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            smk::set_error(std::string("invalid argument: ") + (msg));                            \
+            return SMK_ERR_INVALID;                                                               \
+        }                                                                                         \
+    } while (0)
+
+// Geometry of one batch of grids. Plane strides in floats.
+struct Geom {
+    int B, H, W;
+    int pc, pv;          // row pitches of (u,p,density) and of v
+    size_t su, sv, sc;   // plane strides: u (H+1 rows of pc), v (H rows of pv), cell fields (H rows of pc)
+    float dt;            // (float)dt
+    float coef_uv;       // (float)(dt*viscosity)
+    float coef_d;        // (float)(dt*(viscosity*0.1))
+};
+
+struct StateView {
+    float *u, *v, *p, *d;
+};
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace smk

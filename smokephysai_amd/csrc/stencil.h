@@ -1,0 +1,27 @@
+#pragma once
+#include "common.h"
+
+namespace smk {
+
+// All launchers enqueue on `st` and return a hipError_t from hipGetLastError().
+hipError_t launch_zero_state(const Geom &g, StateView s, const uint8_t *dev_mask, hipStream_t st);
+// device-side source record: denom = (float)(2*(radius/3)^2), fint = (float)intensity (host-computed doubles)
+struct SrcDev { int x, y, radius; float denom, fint; };
+// dev_first[b]..dev_first[b+1] indexes the sources of grid b (stable order).
+hipError_t launch_add_sources(const Geom &g, float *density, const SrcDev *dev_src, const int *dev_first, hipStream_t st);
+hipError_t launch_buoy_diffuse(const Geom &g, StateView in, StateView out, hipStream_t st);
+hipError_t launch_diffuse(const float *in, float *out, int B, int R, int C, int pitch, float coef, hipStream_t st);
+hipError_t launch_divergence(const Geom &g, const float *u, const float *v, float *div, int div_pitch, size_t div_stride,
+                             hipStream_t st);
+// `iters` Jacobi sweeps; result ends in p. p2 is scratch of the same layout as p.
+hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, int iters, hipStream_t st);
+hipError_t launch_grad_subtract(const Geom &g, float *u, float *v, const float *p, hipStream_t st);
+// kind 0: field=u (H+1 x W), 1: field=v (H x W+1), 2: density (H x W) with *0.995 decay and optional frame emit.
+hipError_t launch_advect(const Geom &g, int kind, const float *field, float *out, const float *u, const float *v,
+                         float *frames, int64_t frame_stride_b, const float *fractal, float fractal_intensity,
+                         int32_t *x0, int32_t *y0, hipStream_t st);
+hipError_t launch_fractal_constants(int N, float *perlin, float *mandel, float *field, hipStream_t st);
+hipError_t launch_apply_fractal(const float *in, float *out, const float *fractal, int n_fields, int N, float intensity,
+                                hipStream_t st);
+
+}  // namespace smk

@@ -1,0 +1,360 @@
+// Stencil kernels of the batched stable-fluids step (gfx950).
+//
+// Arithmetic contract: every kernel evaluates the reference's fp32 expression tree with ONE rounding per
+// reference elementwise op (file is compiled with -ffp-contract=off; divides/sqrt are the correctly rounded
+// forms), so velocity/pressure/density grids are bit-identical to the torch-CPU reference for identical inputs.
+// Reference: /root/reference/src/physics/navier_stokes.py (lines cited per kernel).
+#include "stencil.h"
+
+namespace smk {
+
+#define TX 64
+#define TY 4
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {
+    float t = x < lo ? lo : x;   // torch.clamp = min(max(x, lo), hi)
+    return t > hi ? hi : t;
+}
+__device__ __forceinline__ int clampi(int x, int lo, int hi) {
+    int t = x < lo ? lo : x;
+    return t > hi ? hi : t;
+}
+
+// ---------------------------------------------------------------- reset (navier_stokes.py:24-35)
+__global__ void k_zero_state(Geom g, StateView s, const uint8_t *mask) {
+    int b = blockIdx.z;
+    if (mask && !mask[b]) return;
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    if (i <= g.H && j < g.pc) s.u[b * g.su + (size_t)i * g.pc + j] = 0.f;
+    if (i < g.H && j < g.pv) s.v[b * g.sv + (size_t)i * g.pv + j] = 0.f;
+    if (i < g.H && j < g.pc) {
+        s.p[b * g.sc + (size_t)i * g.pc + j] = 0.f;
+        s.d[b * g.sc + (size_t)i * g.pc + j] = 0.f;
+    }
+}
+
+hipError_t launch_zero_state(const Geom &g, StateView s, const uint8_t *dev_mask, hipStream_t st) {
+    int maxp = g.pc > g.pv ? g.pc : g.pv;
+    dim3 grid(cdiv(maxp, TX), cdiv(g.H + 1, TY), g.B), block(TX, TY);
+    hipLaunchKernelGGL(k_zero_state, grid, block, 0, st, g, s, dev_mask);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- sources (navier_stokes.py:37-48)
+// dist = sqrt(float(dx^2+dy^2)); mask dist<=radius; density += fint * exp(-(dist*dist)/denom)
+__global__ void k_add_sources(Geom g, float *density, const SrcDev *src, const int *first) {
+    int b = blockIdx.z;
+    int s0 = first[b], s1 = first[b + 1];
+    if (s0 == s1) return;
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    if (i >= g.H || j >= g.W) return;
+    float *cell = density + b * g.sc + (size_t)i * g.pc + j;
+    float d = *cell;
+    for (int s = s0; s < s1; ++s) {
+        SrcDev q = src[s];
+        int dx = j - q.x, dy = i - q.y;
+        float dist = __fsqrt_rn((float)(dx * dx + dy * dy));
+        if (dist <= (float)q.radius) {
+            float e = expf(-__fdiv_rn(dist * dist, q.denom));
+            d = d + q.fint * e;
+        }
+    }
+    *cell = d;
+}
+
+hipError_t launch_add_sources(const Geom &g, float *density, const SrcDev *dev_src, const int *dev_first, hipStream_t st) {
+    dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B), block(TX, TY);
+    hipLaunchKernelGGL(k_add_sources, grid, block, 0, st, g, density, dev_src, dev_first);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- diffusion (navier_stokes.py:50-72)
+// out = c + coef*((((up+down)+left)+right) - 4*c), replicate padding.
+__device__ __forceinline__ float diffuse_at(const float *f, int R, int C, int pitch, int i, int j, float coef) {
+    int iu = i > 0 ? i - 1 : 0, id = i < R - 1 ? i + 1 : R - 1;
+    int jl = j > 0 ? j - 1 : 0, jr = j < C - 1 ? j + 1 : C - 1;
+    float c = f[(size_t)i * pitch + j];
+    float lap = f[(size_t)iu * pitch + j] + f[(size_t)id * pitch + j];
+    lap = lap + f[(size_t)i * pitch + jl];
+    lap = lap + f[(size_t)i * pitch + jr];
+    lap = lap - 4.0f * c;
+    return c + coef * lap;
+}
+
+__global__ void k_diffuse(const float *in, float *out, int R, int C, int pitch, size_t stride, float coef) {
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    if (i >= R || j >= C) return;
+    const float *f = in + blockIdx.z * stride;
+    out[blockIdx.z * stride + (size_t)i * pitch + j] = diffuse_at(f, R, C, pitch, i, j, coef);
+}
+
+hipError_t launch_diffuse(const float *in, float *out, int B, int R, int C, int pitch, float coef, hipStream_t st) {
+    dim3 grid(cdiv(C, TX), cdiv(R, TY), B), block(TX, TY);
+    hipLaunchKernelGGL(k_diffuse, grid, block, 0, st, in, out, R, C, pitch, (size_t)R * pitch, coef);
+    return hipGetLastError();
+}
+
+// buoyancy (navier_stokes.py:154-155) fused into the three diffusions (:158-160).
+// v_b(i,j) = j < W ? v + dt*(density*0.1) : v    -- the buoyancy-updated v that diffusion_step(v) sees.
+__device__ __forceinline__ float vbuoy(const float *v, const float *d, const Geom &g, int i, int j) {
+    float x = v[(size_t)i * g.pv + j];
+    if (j < g.W) {
+        float b = d[(size_t)i * g.pc + j] * 0.1f;
+        x = x + g.dt * b;
+    }
+    return x;
+}
+
+__global__ void k_buoy_diffuse(Geom g, StateView in, StateView out) {
+    int b = blockIdx.z;
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    const float *u = in.u + b * g.su, *v = in.v + b * g.sv, *d = in.d + b * g.sc;
+    if (i <= g.H && j < g.W)
+        out.u[b * g.su + (size_t)i * g.pc + j] = diffuse_at(u, g.H + 1, g.W, g.pc, i, j, g.coef_uv);
+    if (i < g.H && j < g.W)
+        out.d[b * g.sc + (size_t)i * g.pc + j] = diffuse_at(d, g.H, g.W, g.pc, i, j, g.coef_d);
+    if (i < g.H && j <= g.W) {
+        int iu = i > 0 ? i - 1 : 0, id = i < g.H - 1 ? i + 1 : g.H - 1;
+        int jl = j > 0 ? j - 1 : 0, jr = j < g.W ? j + 1 : g.W;
+        float c = vbuoy(v, d, g, i, j);
+        float lap = vbuoy(v, d, g, iu, j) + vbuoy(v, d, g, id, j);
+        lap = lap + vbuoy(v, d, g, i, jl);
+        lap = lap + vbuoy(v, d, g, i, jr);
+        lap = lap - 4.0f * c;
+        out.v[b * g.sv + (size_t)i * g.pv + j] = c + g.coef_uv * lap;
+    }
+}
+
+hipError_t launch_buoy_diffuse(const Geom &g, StateView in, StateView out, hipStream_t st) {
+    dim3 grid(cdiv(g.W + 1, TX), cdiv(g.H + 1, TY), g.B), block(TX, TY);
+    hipLaunchKernelGGL(k_buoy_diffuse, grid, block, 0, st, g, in, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- projection (navier_stokes.py:133-149)
+// div = (((u[i+1,j]-u[i,j]) + v[i,j+1]) - v[i,j]) / dt       (true fp32 divide, as torch CPU)
+__global__ void k_divergence(Geom g, const float *u, const float *v, float *div, int dp, size_t ds) {
+    int b = blockIdx.z;
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    if (i >= g.H || j >= g.W) return;
+    const float *ub = u + b * g.su, *vb = v + b * g.sv;
+    float a = ub[(size_t)(i + 1) * g.pc + j] - ub[(size_t)i * g.pc + j];
+    a = a + vb[(size_t)i * g.pv + j + 1];
+    a = a - vb[(size_t)i * g.pv + j];
+    div[b * ds + (size_t)i * dp + j] = __fdiv_rn(a, g.dt);
+}
+
+hipError_t launch_divergence(const Geom &g, const float *u, const float *v, float *div, int dp, size_t ds,
+                             hipStream_t st) {
+    dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B), block(TX, TY);
+    hipLaunchKernelGGL(k_divergence, grid, block, 0, st, g, u, v, div, dp, ds);
+    return hipGetLastError();
+}
+
+// One Jacobi sweep: ring = 0, interior 0.25*((((up+down)+left)+right) - div)   (:140-145)
+__global__ void k_jacobi_sweep(Geom g, const float *p, float *pn, const float *div) {
+    int b = blockIdx.z;
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    if (i >= g.H || j >= g.W) return;
+    const float *pb = p + b * g.sc;
+    size_t o = (size_t)i * g.pc + j;
+    float r = 0.f;
+    if (i > 0 && i < g.H - 1 && j > 0 && j < g.W - 1) {
+        float s = pb[o - g.pc] + pb[o + g.pc];
+        s = s + pb[o - 1];
+        s = s + pb[o + 1];
+        s = s - div[b * g.sc + o];
+        r = 0.25f * s;
+    }
+    pn[b * g.sc + o] = r;
+}
+
+__global__ void k_copy_cells(Geom g, const float *src, float *dst) {
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    if (i >= g.H || j >= g.W) return;
+    size_t o = blockIdx.z * g.sc + (size_t)i * g.pc + j;
+    dst[o] = src[o];
+}
+
+hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, int iters, hipStream_t st) {
+    dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B), block(TX, TY);
+    float *cur = p, *nxt = p2;
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(k_jacobi_sweep, grid, block, 0, st, g, cur, nxt, div);
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != p) hipLaunchKernelGGL(k_copy_cells, grid, block, 0, st, g, cur, p);
+    return hipGetLastError();
+}
+
+// u[1:-1,:] -= dt*(p[1:]-p[:-1]);  v[:,1:-1] -= dt*(p[:,1:]-p[:,:-1])   (:148-149)
+__global__ void k_grad_subtract(Geom g, float *u, float *v, const float *p) {
+    int b = blockIdx.z;
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    const float *pb = p + b * g.sc;
+    if (i >= 1 && i < g.H && j < g.W) {
+        float *c = u + b * g.su + (size_t)i * g.pc + j;
+        float gr = pb[(size_t)i * g.pc + j] - pb[(size_t)(i - 1) * g.pc + j];
+        *c = *c - g.dt * gr;
+    }
+    if (i < g.H && j >= 1 && j < g.W) {
+        float *c = v + b * g.sv + (size_t)i * g.pv + j;
+        float gr = pb[(size_t)i * g.pc + j] - pb[(size_t)i * g.pc + j - 1];
+        *c = *c - g.dt * gr;
+    }
+}
+
+hipError_t launch_grad_subtract(const Geom &g, float *u, float *v, const float *p, hipStream_t st) {
+    dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B), block(TX, TY);
+    hipLaunchKernelGGL(k_grad_subtract, grid, block, 0, st, g, u, v, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- advection (navier_stokes.py:74-131)
+// bilinear_interpolate (:111-131): indices clamped before the weights are formed.
+__device__ __forceinline__ float bilinear(const float *f, int h, int w, int pitch, float y, float x, int *ox0, int *oy0) {
+    int x0 = (int)floorf(x), y0 = (int)floorf(y);
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = clampi(x0, 0, w - 1); x1 = clampi(x1, 0, w - 1);
+    y0 = clampi(y0, 0, h - 1); y1 = clampi(y1, 0, h - 1);
+    float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
+    float wa = (fx1 - x) * (fy1 - y);
+    float wb = (x - fx0) * (fy1 - y);
+    float wc = (fx1 - x) * (y - fy0);
+    float wd = (x - fx0) * (y - fy0);
+    float r = wa * f[(size_t)y0 * pitch + x0] + wb * f[(size_t)y0 * pitch + x1];
+    r = r + wc * f[(size_t)y1 * pitch + x0];
+    r = r + wd * f[(size_t)y1 * pitch + x1];
+    if (ox0) { *ox0 = x0; *oy0 = y0; }
+    return r;
+}
+
+template <int KIND>
+__global__ void k_advect(Geom g, const float *field, float *out, const float *u, const float *v, float *frames,
+                         int64_t fsb, const float *fractal, float fint, int32_t *x0o, int32_t *y0o) {
+    constexpr bool IS_U = KIND == 0, IS_V = KIND == 1;   // KIND 2: density (+decay, frame emit); 3: plain cell field
+    const int R = IS_U ? g.H + 1 : g.H, C = IS_V ? g.W + 1 : g.W;
+    const int pitch = IS_V ? g.pv : g.pc;
+    const size_t fs = IS_U ? g.su : (IS_V ? g.sv : g.sc);
+    int b = blockIdx.z;
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    if (i >= R || j >= C) return;
+    const float *ub = u + b * g.su, *vb = v + b * g.sv, *fb = field + b * fs;
+    float Y = (float)i, X = (float)j;
+    float xu = clampf(X + 0.5f, 0.f, (float)(g.W - 1));           // interpolate_velocity_u (:97-102)
+    float ui = bilinear(ub, g.H + 1, g.W, g.pc, Y, xu, nullptr, nullptr);
+    float yv = clampf(Y + 0.5f, 0.f, (float)(g.H - 1));           // interpolate_velocity_v (:104-109)
+    float vi = bilinear(vb, g.H, g.W + 1, g.pv, yv, X, nullptr, nullptr);
+    float px = clampf(X - g.dt * ui, 0.f, (float)(C - 1));        // :87-92
+    float py = clampf(Y - g.dt * vi, 0.f, (float)(R - 1));
+    int x0, y0;
+    float r = bilinear(fb, R, C, pitch, py, px, &x0, &y0);
+    if (x0o) {
+        size_t o = ((size_t)b * R + i) * C + j;
+        x0o[o] = x0; y0o[o] = y0;
+    }
+    if (KIND == 2) {
+        r = r * 0.995f;                                           // :171
+        if (frames) {
+            float fr = r;
+            if (fractal) {                                        // fractal_generator.py:62 (F is [W][H], square)
+                float t = fint * fractal[(size_t)i * g.W + j];
+                t = t * r;
+                fr = r + t;
+            }
+            frames[(size_t)b * fsb + (size_t)i * g.W + j] = fr;
+        }
+    }
+    if (out) out[b * fs + (size_t)i * pitch + j] = r;
+}
+
+hipError_t launch_advect(const Geom &g, int kind, const float *field, float *out, const float *u, const float *v,
+                         float *frames, int64_t fsb, const float *fractal, float fint, int32_t *x0, int32_t *y0,
+                         hipStream_t st) {
+    dim3 block(TX, TY);
+    if (kind == 0) {
+        dim3 grid(cdiv(g.W, TX), cdiv(g.H + 1, TY), g.B);
+        hipLaunchKernelGGL(k_advect<0>, grid, block, 0, st, g, field, out, u, v, frames, fsb, fractal, fint, x0, y0);
+    } else if (kind == 1) {
+        dim3 grid(cdiv(g.W + 1, TX), cdiv(g.H, TY), g.B);
+        hipLaunchKernelGGL(k_advect<1>, grid, block, 0, st, g, field, out, u, v, frames, fsb, fractal, fint, x0, y0);
+    } else if (kind == 3) {
+        dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B);
+        hipLaunchKernelGGL(k_advect<3>, grid, block, 0, st, g, field, out, u, v, frames, fsb, fractal, fint, x0, y0);
+    } else {
+        dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B);
+        hipLaunchKernelGGL(k_advect<2>, grid, block, 0, st, g, field, out, u, v, frames, fsb, fractal, fint, x0, y0);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- fractal constants (fractal_generator.py:12-51)
+// torch.linspace fp32 CPU kernel: one rounding per element (FMA form), symmetric halves.
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    float step = __fdiv_rn(end - start, (float)(steps - 1));
+    return i < steps / 2 ? __fmaf_rn(step, (float)i, start) : __fmaf_rn(-step, (float)(steps - i - 1), end);
+}
+
+// out index [i][j] over [W][H] with X = x[i], Y = y[j] (meshgrid 'ij' of (x,y)); N = H = W.
+__global__ void k_fractal_constants(int N, float *perlin, float *mandel, float *field) {
+    int j = blockIdx.x * TX + threadIdx.x, i = blockIdx.y * TY + threadIdx.y;
+    if (i >= N || j >= N) return;
+    // perlin (:12-31): sum_{o<6} (amp*sin(f*x))*cos(f*y); (noise+1)/2
+    float px = linspace_at(0.f, 10.f, N, i), py = linspace_at(0.f, 10.f, N, j);
+    float noise = 0.f, amp = 1.f, freq = 1.f;
+#pragma unroll
+    for (int o = 0; o < 6; ++o) {
+        float t = amp * sinf(freq * px);
+        t = t * cosf(freq * py);
+        noise = noise + t;
+        amp *= 0.5f; freq *= 2.f;      // exact powers of two: same values as the python doubles
+    }
+    float per = __fdiv_rn(noise + 1.0f, 2.0f);
+    // mandelbrot (:33-51): z <- z*z + c while |z| <= 2 (masked update == freeze after escape), count = last it
+    float cr = linspace_at(-2.5f, 1.5f, N, i), ci = linspace_at(-1.5f, 1.5f, N, j);
+    float zr = 0.f, zi = 0.f;
+    int cnt = 0;
+    for (int it = 0; it < 100; ++it) {
+        float m = __fsqrt_rn(zr * zr + zi * zi);
+        if (!(m <= 2.0f)) break;
+        float rr = zr * zr - zi * zi;
+        float ab = zr * zi;
+        float ii = ab + ab;
+        zr = rr + cr; zi = ii + ci;
+        cnt = it;
+    }
+    float man = __fdiv_rn((float)cnt, 100.0f);
+    size_t o = (size_t)i * N + j;
+    perlin[o] = per;
+    mandel[o] = man;
+    field[o] = 0.7f * per + 0.3f * man;   // :58-59
+}
+
+hipError_t launch_fractal_constants(int N, float *perlin, float *mandel, float *field, hipStream_t st) {
+    dim3 grid(cdiv(N, TX), cdiv(N, TY)), block(TX, TY);
+    hipLaunchKernelGGL(k_fractal_constants, grid, block, 0, st, N, perlin, mandel, field);
+    return hipGetLastError();
+}
+
+// field + (intensity*F)*field  (:62)
+__global__ void k_apply_fractal(const float *in, float *out, const float *fractal, size_t per_field, size_t total, float fint) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; k < total; k += step) {
+        float x = in[k];
+        float t = fint * fractal[k % per_field];
+        t = t * x;
+        out[k] = x + t;
+    }
+}
+
+hipError_t launch_apply_fractal(const float *in, float *out, const float *fractal, int n_fields, int N, float intensity,
+                                hipStream_t st) {
+    size_t per = (size_t)N * N, total = per * n_fields;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_apply_fractal, dim3(blocks), dim3(256), 0, st, in, out, fractal, per, total, intensity);
+    return hipGetLastError();
+}
+
+}  // namespace smk
