@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: simulated + encoded frames/s (BASELINE.json metric) on N GPUs of one node.
+
+One "step" = one time step of the batched Navier-Stokes stepper for all B grids of this rank (buoyancy, diffusion,
+Jacobi pressure projection, three advections, fractal frame emit) + the fused CNN encoder over the B emitted frames
+([B,256,256] -> [B,128,32,32]), everything resident in HBM.  Workload at N=1: BASELINE.json configs[2]
+(256^2 grid, batch 64, Jacobi-100).  Grids are independent: ranks own disjoint grids, no data-path collective
+("scaling": "weak", batch 64 per GPU).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `roofline*` use SURVEY.md 8(d)'s algorithmic figures: stencil 4*(27+3J) bytes per
+cell per step against HBM 8 TB/s; encoder 153,728*N^2 flop per frame against the dense MFMA peak of the dtype.
+`cpu_baseline` times the CPU oracle (a scalar C port of the reference path) on a bounded sample on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # dense peaks (MI355X_MICROARCH.md)
+
+
+def encoder_weights(seed=0):
+    """Random-init input_encoder of the reference architecture (smokephys_net.py:24-32) with non-trivial BN stats."""
+    torch.manual_seed(seed)
+    enc = torch.nn.Sequential(torch.nn.Conv2d(1, 64, 7, padding=3), torch.nn.BatchNorm2d(64), torch.nn.ReLU(),
+                              torch.nn.Conv2d(64, 128, 3, padding=1), torch.nn.BatchNorm2d(128), torch.nn.ReLU())
+    g = torch.Generator().manual_seed(seed + 7)
+    with torch.no_grad():
+        for bn in (enc[1], enc[4]):
+            bn.running_mean.copy_(torch.randn(bn.num_features, generator=g) * 0.2)
+            bn.running_var.copy_(torch.rand(bn.num_features, generator=g) * 1.5 + 0.25)
+            bn.weight.copy_(torch.rand(bn.num_features, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(bn.num_features, generator=g) * 0.1)
+    from smokephysai_amd.models.encoder import encoder_weight_dict
+    return {k: v.detach().clone() for k, v in encoder_weight_dict(enc).items()}
+
+
+def draw_sources(B, N, seed):
+    """Per grid the draw order of data_loader.py:49-58 (1-3 sources, x,y in [20,N-20), intensity U(0.5,2))."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for b in range(B):
+        for _ in range(rng.randint(1, 4)):
+            x = rng.randint(20, N - 20)
+            y = rng.randint(20, N - 20)
+            out.append((b, int(x), int(y), 8, float(rng.uniform(0.5, 2.0))))
+    return out
+
+
+def cpu_baseline(N, J, weights, budget_frames):
+    """The CPU oracle (oracle/: scalar C restatement of the reference path) on one grid, looped per frame like the
+    reference: step() + fractal recomputed per frame (fractal_generator.py:55-56) + input_encoder + pools."""
+    import oracle
+    w = {k: v.cpu().numpy() for k, v in weights.items()}
+    sim = oracle.OracleSmokeSimulator((N, N), jacobi_iters=J, cache_fractal=False)
+    sim.ns_solver.add_smoke_source(N // 2, N // 2, 8, 1.0)
+    t0 = time.perf_counter()
+    t_sim = 0.0
+    for _ in range(budget_frames):
+        ts = time.perf_counter()
+        frame = sim.simulate_step(add_fractal=True)
+        t_sim += time.perf_counter() - ts
+        oracle.encoder_features(frame[None], w, input_dim=128)
+    dt = time.perf_counter() - t0
+    return {"value": budget_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{budget_frames} frames of one {N}x{N} grid (Jacobi-{J}, fractal recomputed per frame) simulated and "
+                      f"encoded by the scalar C oracle in {dt:.1f} s ({t_sim / budget_frames * 1e3:.0f} ms/frame sim)",
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=64, help="grids per GPU")
+    ap.add_argument("--jacobi", type=int, default=100)
+    ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from smokephysai_amd.models.encoder import HipEncoder
+    from smokephysai_amd.physics import SmokeSimulator
+
+    B, N, J, K, W = args.batch, args.grid, args.jacobi, args.steps, args.warmup
+    sim = SmokeSimulator((N, N), device=dev, batch_size=B, jacobi_iters=J)
+    sim.ns_solver.add_smoke_sources(draw_sources(B, N, seed=rank))     # each rank owns its own B grids
+    weights = encoder_weights(0)
+    enc = HipEncoder(weights, device=dev)
+    frame = torch.empty(B, N, N, device=dev)
+
+    def step(ev=None):
+        if ev: ev[0].record()
+        sim.ns_solver.step_into(frame, 1, add_fractal=True, fractal_intensity=0.05)
+        if ev: ev[1].record()
+        feats = None if args.no_encode else enc(frame, input_dim=128, dtype=args.encoder_dtype)
+        if ev: ev[2].record()
+        return feats
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(W):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        feats = step(events[k])
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(frame).all() and (feats is None or torch.isfinite(feats).all())
+    ms_sim = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))      # HIP events on the launch stream
+    ms_enc = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+
+    if rank == 0:
+        frames_total = world * B * K
+        stencil_bytes = B * N * N * 4.0 * (27 + 3 * J)          # algorithmic bytes per stencil pass
+        enc_flops = B * 153728.0 * N * N                         # algorithmic flop per encoder launch
+        sten_gbs = stencil_bytes / (ms_sim * 1e-3) / 1e9
+        roof_stencil = {"bound": "hbm", "kernel": "stencil pass (all kernels of one time step, B grids)",
+                        "achieved": sten_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sten_gbs / HBM_PEAK_GBS,
+                        "traffic": None, "ms_per_launch": ms_sim}
+        out = {"metric": "simulated+encoded frames/sec at 256^2 grid, batch 64", "value": frames_total / elapsed,
+               "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.encoder_dtype == "f32" else "bf16", "data": "synthetic",
+               "config": {"workload": f"configs[2]: {N}x{N} grid, batch {B} per GPU, Jacobi-{J} project, fractal frame emit, "
+                                      f"CNN encoder {args.encoder_dtype} -> [B,128,32,32]",
+                          "grid": N, "batch_per_gpu": B, "jacobi_iters": J, "encoder_dtype": args.encoder_dtype,
+                          "parallelism": f"independent grids sharded over {world} GPU(s), no data-path collective"},
+               "sim_only_frames_per_s": B / (ms_sim * 1e-3), "ms_sim_per_step": ms_sim}
+        if not args.no_encode:
+            tf = enc_flops / (ms_enc * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.encoder_dtype]
+            roof_enc = {"bound": "mfma", "kernel": f"k_encoder_{args.encoder_dtype} (fused conv1+conv2+pool, B frames)",
+                        "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                        "ms_per_launch": ms_enc}
+            out.update({"encode_only_frames_per_s": B / (ms_enc * 1e-3), "ms_encode_per_step": ms_enc,
+                        "roofline": roof_enc if ms_enc >= ms_sim else roof_stencil,
+                        "roofline_stencil": roof_stencil, "roofline_encoder": roof_enc})
+        else:
+            out["metric"] += " (DIAGNOSTIC: stencil only, not the headline metric)"
+            out["roofline"] = roof_stencil
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):                                  # filled by tools/pmc_traffic.py from rocprofv3 --pmc passes
+            tr = json.load(open(pmc))
+            for key, kname in (("roofline_stencil", "stencil"), ("roofline_encoder", "encoder")):
+                if key in out and kname in tr:
+                    out[key]["traffic"] = tr[kname]
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,6 @@
+from .smokephys_net import SmokePhysNet, ChaosTransformerLayer
+from .chaos_attention import ChaosAttention
+from .physics_regularizer import PhysicsRegularizer
+from .encoder import HipEncoder
+
+__all__ = ["SmokePhysNet", "ChaosTransformerLayer", "ChaosAttention", "PhysicsRegularizer", "HipEncoder"]

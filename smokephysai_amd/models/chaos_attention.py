@@ -1,0 +1,82 @@
+"""Chaos-aware attention -- drop-in for src/models/chaos_attention.py:6-114 (same parameter/buffer names).
+
+The reference forms two [B,heads,L,L] score tensors, QK^T/sqrt(d) and strength*gate*(C_h K^T)/sqrt(d), and adds them
+(chaos_attention.py:82-100).  Both are linear in the left operand, so  S = ((Q + strength*gate*C_h) K^T)/sqrt(d)
+exactly; the chaos term is folded into Q and one fused scaled-dot-product attention is used.
+The Lorenz chaos field has period 5 along the sequence (chaos_attention.py:61-65), so it is projected once per
+distinct row and tiled.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ChaosAttention(nn.Module):
+    def __init__(self, dim: int, num_heads: int = 8, chaos_strength: float = 0.1, temperature: float = 1.0):
+        super().__init__()
+        self.dim = dim
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.chaos_strength = chaos_strength
+        self.temperature = temperature
+        assert dim % num_heads == 0
+        self.q_proj = nn.Linear(dim, dim)
+        self.k_proj = nn.Linear(dim, dim)
+        self.v_proj = nn.Linear(dim, dim)
+        self.out_proj = nn.Linear(dim, dim)
+        self.chaos_proj = nn.Linear(3, dim)
+        self.chaos_gate = nn.Linear(dim, 1)
+        self.register_buffer("lorenz_sigma", torch.tensor(10.0))
+        self.register_buffer("lorenz_rho", torch.tensor(28.0))
+        self.register_buffer("lorenz_beta", torch.tensor(8.0 / 3.0))
+
+    def lorenz_system(self, x, y, z, dt: float = 0.01):
+        """chaos_attention.py:39-45 (explicit Euler)."""
+        dx = self.lorenz_sigma * (y - x)
+        dy = x * (self.lorenz_rho - z) - y
+        dz = x * y - self.lorenz_beta * z
+        return (x + dt * dx, y + dt * dy, z + dt * dz)
+
+    def chaos_states(self, batch_size: int, device, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The 5 Lorenz states [B,5,3] of generate_chaos_field (chaos_attention.py:47-59).
+        noise: the three randn(B,1) draws stacked as [3,B,1]; None draws them like the reference does."""
+        if noise is None:
+            x = torch.randn(batch_size, 1, device=device) * 0.1
+            y = torch.randn(batch_size, 1, device=device) * 0.1
+            z = torch.randn(batch_size, 1, device=device) * 0.1
+        else:
+            noise = noise.to(device)
+            x, y, z = noise[0] * 0.1, noise[1] * 0.1, noise[2] * 0.1
+        seq = []
+        for _ in range(5):
+            x, y, z = self.lorenz_system(x, y, z)
+            seq.append(torch.cat([x, y, z], dim=-1))
+        return torch.stack(seq, dim=1)
+
+    def generate_chaos_field(self, seq_len: int, batch_size: int, device, noise=None) -> torch.Tensor:
+        """chaos_attention.py:47-66."""
+        field = self.chaos_states(batch_size, device, noise)
+        reps = (seq_len + field.size(1) - 1) // field.size(1)
+        return field.repeat(1, reps, 1)[:, :seq_len, :]
+
+    def forward(self, x: torch.Tensor, mask: torch.Tensor = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, L, D = x.shape
+        H, d = self.num_heads, self.head_dim
+        q = self.q_proj(x)
+        k = self.k_proj(x).view(B, L, H, d).transpose(1, 2)
+        v = self.v_proj(x).view(B, L, H, d).transpose(1, 2)
+        # chaos features on the 5 distinct rows, gate, fold into Q (chaos_attention.py:85-100)
+        c5 = self.chaos_proj(self.chaos_states(B, x.device, noise).to(x.dtype))      # [B,5,D]
+        add5 = self.chaos_strength * torch.sigmoid(self.chaos_gate(c5)) * c5         # [B,5,D]
+        reps = (L + 4) // 5
+        q = (q + add5.repeat(1, reps, 1)[:, :L]).view(B, L, H, d).transpose(1, 2)
+        attn_mask = None
+        if mask is not None:
+            attn_mask = (mask != 0)[:, None, None, :]
+        scale = 1.0 / (math.sqrt(d) * self.temperature)
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, scale=scale)
+        out = out.transpose(1, 2).contiguous().view(B, L, D)
+        return self.out_proj(out)

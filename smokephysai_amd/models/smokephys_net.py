@@ -1,0 +1,121 @@
+"""SmokePhysNet on MI355X -- drop-in for src/models/smokephys_net.py:7-167 (same constructor, forward contract and
+state_dict keys, so a reference best_model.pth loads unchanged).
+
+Inference (eval mode): frames go through the fused HIP encoder (csrc/encoder.hip: conv7x7+BN+ReLU, conv3x3+BN+ReLU
+on MFMA, both adaptive pools as one block mean) -- there is no CPU fallback for it.  The transformer body and the heads
+run as PyTorch-ROCm ops (hipBLASLt GEMMs + fused SDPA with the chaos term folded into Q).
+Training (train mode): the encoder runs as autograd-tracked PyTorch ops with batch-statistics BatchNorm, exactly the
+reference's op sequence (smokephys_net.py:87-91).
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .chaos_attention import ChaosAttention
+from .encoder import HipEncoder, encoder_weight_dict
+from .physics_regularizer import PhysicsRegularizer
+
+
+class SmokePhysNet(nn.Module):
+    def __init__(self, input_dim: int = 128, hidden_dim: int = 512, num_layers: int = 6, num_heads: int = 8,
+                 output_channels: int = 64, chaos_strength: float = 0.1, encoder_dtype: str = "f32"):
+        super().__init__()
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.num_layers = num_layers
+        self.encoder_dtype = encoder_dtype
+        self.input_encoder = nn.Sequential(
+            nn.Conv2d(1, 64, 7, padding=3), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.Conv2d(64, 128, 3, padding=1), nn.BatchNorm2d(128), nn.ReLU(inplace=True),
+            nn.AdaptiveAvgPool2d((input_dim, input_dim)))
+        self.pos_embedding = nn.Parameter(torch.randn(1, input_dim * input_dim, hidden_dim))
+        self.feature_proj = nn.Linear(128, hidden_dim)
+        self.chaos_layers = nn.ModuleList(
+            [ChaosTransformerLayer(hidden_dim, num_heads, chaos_strength=chaos_strength) for _ in range(num_layers)])
+        self.output_decoder = nn.Sequential(nn.Linear(hidden_dim, 256), nn.ReLU(inplace=True), nn.Linear(256, output_channels))
+        self.reconstruction_head = nn.Sequential(
+            nn.ConvTranspose2d(output_channels, 32, 4, stride=2, padding=1), nn.BatchNorm2d(32), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(32, 16, 4, stride=2, padding=1), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
+            nn.Conv2d(16, 1, 3, padding=1), nn.Sigmoid())
+        self.physics_head = nn.Sequential(nn.Linear(hidden_dim, 256), nn.ReLU(inplace=True), nn.Linear(256, 3))
+        self.physics_regularizer = PhysicsRegularizer()
+        self._hip = None          # (HipEncoder, weight fingerprint)
+        self._pos_cache = None    # (fingerprint, tensor)
+
+    # ---- HIP encoder plumbing -------------------------------------------------------------------------------
+    def _encoder_fingerprint(self):
+        ws = encoder_weight_dict(self.input_encoder)
+        return tuple((t.data_ptr(), t._version) for t in ws.values())
+
+    def hip_encoder(self) -> HipEncoder:
+        """Folded-weight HIP encoder for the current input_encoder tensors (rebuilt when they change)."""
+        dev = self.pos_embedding.device
+        fp = self._encoder_fingerprint()
+        if self._hip is None or self._hip[1] != fp:
+            if self._hip is not None:
+                self._hip[0].close()
+            self._hip = (HipEncoder(encoder_weight_dict(self.input_encoder), device=dev), fp)
+        return self._hip[0]
+
+    def encode_frames(self, x: torch.Tensor, dtype: Optional[str] = None) -> torch.Tensor:
+        """input_encoder + both pools (smokephys_net.py:87-91): [B,1,H,W] -> [B,128,32,32]."""
+        if self.training and torch.is_grad_enabled():
+            encoded = self.input_encoder(x)
+            return F.adaptive_avg_pool2d(encoded, (32, 32))
+        return self.hip_encoder()(x, input_dim=self.input_dim, dtype=dtype or self.encoder_dtype)
+
+    def _pos_embed(self, pool_size: int) -> torch.Tensor:
+        """smokephys_net.py:99-105; the bilinear resize is input-independent, so it is cached in eval."""
+        expected = pool_size * pool_size
+        if expected == self.pos_embedding.shape[1]:
+            return self.pos_embedding
+        fp = (self.pos_embedding.data_ptr(), self.pos_embedding._version, pool_size)
+        if not self.training and self._pos_cache is not None and self._pos_cache[0] == fp:
+            return self._pos_cache[1]
+        pe = self.pos_embedding.reshape(1, self.input_dim, self.input_dim, self.hidden_dim).permute(0, 3, 1, 2)
+        pe = F.interpolate(pe, size=(pool_size, pool_size), mode="bilinear", align_corners=False)
+        pe = pe.permute(0, 2, 3, 1).reshape(1, expected, self.hidden_dim)
+        if not self.training:
+            self._pos_cache = (fp, pe.detach())
+        return pe
+
+    def forward(self, x: torch.Tensor, return_features: bool = False, chaos_noise: Optional[torch.Tensor] = None,
+                encoder_dtype: Optional[str] = None) -> dict:
+        """x: [B,1,H,W].  chaos_noise (optional): [num_layers,3,B,1] standard-normal draws replacing the reference's
+        in-forward torch.randn (chaos_attention.py:50-52) so results can be pinned."""
+        B = x.shape[0]
+        encoded = self.encode_frames(x, encoder_dtype)
+        pool_size = 32
+        flattened = encoded.flatten(2).transpose(1, 2)
+        features = self.feature_proj(flattened)
+        features = features + self._pos_embed(pool_size)
+        for li, layer in enumerate(self.chaos_layers):
+            features = layer(features, noise=None if chaos_noise is None else chaos_noise[li])
+        output_features = self.output_decoder(features)
+        output_reshaped = output_features.transpose(1, 2).reshape(B, -1, pool_size, pool_size)
+        reconstructed = self.reconstruction_head(output_reshaped)
+        pooled_features = features.mean(dim=1)
+        physics_pred = self.physics_head(pooled_features)
+        results = {"reconstructed": reconstructed, "physics_features": physics_pred, "latent_features": pooled_features}
+        if return_features:
+            results["intermediate_features"] = features
+        return results
+
+
+class ChaosTransformerLayer(nn.Module):
+    """smokephys_net.py:136-168 (pre-LN block)."""
+
+    def __init__(self, dim: int, num_heads: int, chaos_strength: float = 0.1, dropout: float = 0.1):
+        super().__init__()
+        self.chaos_attention = ChaosAttention(dim, num_heads, chaos_strength)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.ffn = nn.Sequential(nn.Linear(dim, 4 * dim), nn.GELU(), nn.Dropout(dropout), nn.Linear(4 * dim, dim),
+                                 nn.Dropout(dropout))
+
+    def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = x + self.chaos_attention(self.norm1(x), noise=noise)
+        x = x + self.ffn(self.norm2(x))
+        return x
