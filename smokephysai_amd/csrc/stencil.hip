@@ -6,6 +6,9 @@
 // Reference: /root/reference/src/physics/navier_stokes.py (lines cited per kernel).
 #include "stencil.h"
 
+#include <math.h>
+#include <stdlib.h>
+
 namespace smk {
 
 #define TX 64
@@ -176,12 +179,168 @@ __global__ void k_copy_cells(Geom g, const float *src, float *dst) {
     dst[o] = src[o];
 }
 
-hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, int iters, hipStream_t st) {
-    dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B), block(TX, TY);
-    float *cur = p, *nxt = p2;
+// ---- register-resident, temporally blocked Jacobi (one wave = one grid row, VEC = W/64 cells per lane) -------------
+// A workgroup of 16 waves holds a band of TR = 16*RPW full rows of p and div in registers and runs `iters` sweeps
+// without touching HBM: horizontal neighbours come from the adjacent lanes (DPP wave shifts), vertical neighbours
+// across waves through a double-buffered LDS edge exchange (one barrier per sweep).  Each band carries (TR-BR)/2
+// redundant halo rows on every non-physical side, so `iters` <= that many sweeps are exact on the BR owned rows
+// (the garbage front moves one row per sweep).  Per cell the arithmetic is exactly k_jacobi_sweep's.
+__device__ __forceinline__ float wave_shr1(float x) {   // lane i <- lane i-1 (lane 0: unchanged, unused)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
+                                                                  0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float x) {   // lane i <- lane i+1 (lane 63: unchanged, unused)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
+                                                                  0x130, 0xf, 0xf, false));
+}
+
+constexpr int JB_NW = 16;
+
+template <int VEC, int RPW>
+__global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float *__restrict__ p_in,
+                                                            float *__restrict__ p_out, const float *__restrict__ div,
+                                                            int iters, int BR) {
+    constexpr int TR = JB_NW * RPW, ROWF = 64 * VEC;
+    __shared__ float edge[2][JB_NW][2][ROWF];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, own0 = blockIdx.x * BR;
+    const int own1 = own0 + BR < g.H ? own0 + BR : g.H;
+    int r0 = own0 - (TR - BR) / 2;
+    if (r0 > g.H - TR) r0 = g.H - TR;
+    if (r0 < 0) r0 = 0;
+    const int row0 = r0 + wave * RPW, j0 = lane * VEC;
+    const size_t base = b * g.sc + (size_t)row0 * g.pc + j0;
+    float pv[RPW][VEC], dv[RPW][VEC];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            pv[k][c] = p_in[base + (size_t)k * g.pc + c];
+            dv[k][c] = div[base + (size_t)k * g.pc + c];
+        }
+    const bool first_col = lane == 0, last_col = lane == 63;
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(k_jacobi_sweep, grid, block, 0, st, g, cur, nxt, div);
-        float *t = cur; cur = nxt; nxt = t;
+        const int par = it & 1;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            edge[par][wave][0][j0 + c] = pv[0][c];
+            edge[par][wave][1][j0 + c] = pv[RPW - 1][c];
+        }
+        __syncthreads();
+        float up[VEC], below[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            up[c] = wave > 0 ? edge[par][wave - 1][1][j0 + c] : 0.f;
+            below[c] = wave < JB_NW - 1 ? edge[par][wave + 1][0][j0 + c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            float cur[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) cur[c] = pv[k][c];
+            const float lin = wave_shr1(cur[VEC - 1]), rin = wave_shl1(cur[0]);
+            const int gi = row0 + k;
+            const bool ring_row = gi == 0 || gi == g.H - 1;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const float dn = k < RPW - 1 ? pv[k + 1][c] : below[c];
+                const float l = c > 0 ? cur[c - 1] : lin;
+                const float r = c < VEC - 1 ? cur[c + 1] : rin;
+                float s = up[c] + dn;
+                s = s + l;
+                s = s + r;
+                s = s - dv[k][c];
+                float nv = 0.25f * s;
+                if (ring_row || (c == 0 && first_col) || (c == VEC - 1 && last_col)) nv = 0.f;
+                pv[k][c] = nv;
+            }
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) up[c] = cur[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int gi = row0 + k;
+        if (gi >= own0 && gi < own1) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) p_out[base + (size_t)k * g.pc + c] = pv[k][c];
+        }
+    }
+}
+
+// Band plan for the register-resident kernel; false -> use the generic per-sweep kernel.
+struct JacobiPlan { int vec, rpw, br, nb, halo; };
+static bool plan_jacobi(const Geom &g, JacobiPlan &pl) {
+    if (g.W % 64 != 0 || g.W / 64 > 8 || (g.W / 64 & (g.W / 64 - 1)) || g.pc % 4 != 0) return false;
+    const char *off = getenv("SMK_JACOBI_GENERIC");
+    if (off && off[0] == '1') return false;
+    pl.vec = g.W / 64;
+    // candidates: rows/wave; pick the plan with the least estimated time ~ launches*(t0 + iters*waves_of_work)
+    const int rpws[] = {2, 3, 4, 6, 8};
+    double best = 1e30;
+    bool ok = false;
+    const char *env_rpw = getenv("SMK_JACOBI_RPW"), *env_nb = getenv("SMK_JACOBI_BANDS");
+    for (int rpw : rpws) {
+        if (env_rpw && atoi(env_rpw) != rpw) continue;
+        if (pl.vec * rpw > 32) continue;                      // register budget (p + div)
+        const int TR = JB_NW * rpw;
+        if (TR > g.H) continue;
+        for (int nb = 1; nb <= g.H / 8; ++nb) {
+            if (env_nb && atoi(env_nb) != nb) continue;
+            const int br = (g.H + nb - 1) / nb;
+            if ((nb - 1) * br >= g.H) continue;               // last band would be empty
+            int halo = nb == 1 ? 1 << 20 : (TR - br) / 2;
+            if (br > TR || halo < 2) continue;
+            if (halo > 64) halo = 64;
+            const double wgs = (double)nb * g.B, rounds = ceil(wgs / 256.0);
+            // per launch: ~4us fixed + load/store; per sweep: rounds * TR row-sweeps
+            const double cost_per_sweep = rounds * TR * 0.0065, launch = 4.0 + rounds * TR * 0.02;
+            const double cost20 = ceil(20.0 / halo) * launch + 20 * cost_per_sweep;   // tuned at the reference's J=20..100
+            if (cost20 < best) { best = cost20; pl.rpw = rpw; pl.br = br; pl.nb = nb; pl.halo = halo; ok = true; }
+        }
+    }
+    return ok;
+}
+
+template <int VEC>
+static void launch_band(const Geom &g, const JacobiPlan &pl, const float *pin, float *pout, const float *div, int iters,
+                        hipStream_t st) {
+    dim3 grid(pl.nb, g.B), block(JB_NW * 64);
+    switch (pl.rpw) {
+        case 2: hipLaunchKernelGGL((k_jacobi_band<VEC, 2>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
+        case 3: hipLaunchKernelGGL((k_jacobi_band<VEC, 3>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
+        case 4: hipLaunchKernelGGL((k_jacobi_band<VEC, 4>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
+        case 6: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 6>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
+        case 8: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 8>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
+    }
+}
+
+hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, int iters, hipStream_t st) {
+    if (iters <= 0) return hipSuccess;
+    dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B), block(TX, TY);
+    JacobiPlan pl;
+    float *cur = p, *nxt = p2;
+    if (plan_jacobi(g, pl)) {
+        // an even number of nearly equal chunks (global ping-pong ends back in p); each chunk <= halo sweeps
+        int L = 2 * ((iters + 2 * pl.halo - 1) / (2 * pl.halo));
+        if (iters == 1) L = 1;
+        int done = 0;
+        for (int c = 0; c < L; ++c) {
+            const int n = (iters - done + (L - c) - 1) / (L - c);
+            switch (pl.vec) {
+                case 1: launch_band<1>(g, pl, cur, nxt, div, n, st); break;
+                case 2: launch_band<2>(g, pl, cur, nxt, div, n, st); break;
+                case 4: launch_band<4>(g, pl, cur, nxt, div, n, st); break;
+                case 8: launch_band<8>(g, pl, cur, nxt, div, n, st); break;
+            }
+            done += n;
+            float *t = cur; cur = nxt; nxt = t;
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            hipLaunchKernelGGL(k_jacobi_sweep, grid, block, 0, st, g, cur, nxt, div);
+            float *t = cur; cur = nxt; nxt = t;
+        }
     }
     if (cur != p) hipLaunchKernelGGL(k_copy_cells, grid, block, 0, st, g, cur, p);
     return hipGetLastError();
