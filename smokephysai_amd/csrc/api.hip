@@ -30,6 +30,7 @@ struct smk_sim {
 struct smk_encoder {
     EncoderDev e;
     float *blob = nullptr;
+    unsigned short *blob16 = nullptr;
     int device = 0;
 };
 
@@ -366,6 +367,15 @@ int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *st
     enc->e.t1 = p; p += 64;
     enc->e.s2 = p; p += 128;
     enc->e.t2 = p;
+    const size_t n16 = 2 * 64 * 64 + 36 * 2 * 128 * 16;
+    e = hipMalloc((void **)&enc->blob16, n16 * sizeof(unsigned short));
+    if (e != hipSuccess) {
+        smk_encoder_destroy(enc);
+        set_error(std::string("smk_encoder_create: ") + hipGetErrorString(e));
+        return SMK_ERR_HIP;
+    }
+    enc->e.w2q = enc->blob16;                       // 16-byte aligned rows first
+    enc->e.w1p = enc->blob16 + 36 * 2 * 128 * 16;
     rc = check_launch(launch_fold_weights(*w, enc->e, (hipStream_t)stream), "fold_weights");
     if (rc) { smk_encoder_destroy(enc); return rc; }
     *out = enc;
@@ -376,6 +386,7 @@ int smk_encoder_destroy(smk_encoder *enc) {
     if (!enc) return SMK_OK;
     (void)hipSetDevice(enc->device);
     if (enc->blob) (void)hipFree(enc->blob);
+    if (enc->blob16) (void)hipFree(enc->blob16);
     delete enc;
     return SMK_OK;
 }
@@ -403,8 +414,11 @@ int smk_encoder_forward(smk_encoder *enc, const float *frames, int64_t frame_str
     if (rc) return rc;
     if (dtype == SMK_F32)
         return check_launch(launch_encoder_f32(frames, frame_stride, B, H, W, enc->e, features, (hipStream_t)stream), "encoder_f32");
-    set_error("encoder dtype not built (only SMK_F32 in this version)");
-    return SMK_ERR_UNSUPPORTED;
+    if (dtype == SMK_BF16X3 || dtype == SMK_BF16)
+        return check_launch(launch_encoder_bf16(frames, frame_stride, B, H, W, enc->e, features, dtype == SMK_BF16X3,
+                                                (hipStream_t)stream), "encoder_bf16");
+    set_error("unknown encoder dtype");
+    return SMK_ERR_INVALID;
 }
 
 int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H, int32_t W,
