@@ -1,0 +1,171 @@
+"""Synthetic smoke dataset on MI355X -- drop-in for src/utils/data_loader.py:10-184.
+
+The reference generates `num_samples` sequences by looping a single-grid simulator in Python
+(data_loader.py:44-97).  Here the same samples come from the batched HIP stepper: the source lists are drawn from
+the global np.random stream in the reference's exact order (so a given seed gives the same sources), `sim_batch`
+grids are simulated per launch, and the chaos-statistics labels are computed on the device -- including the
+reference's quirk that the simulator history is never cleared between samples (data_loader.py:46 resets only the
+solver), so sample i's Lyapunov window reaches back into sample i-1's frames.
+"""
+import os
+import pickle
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from .. import _lib
+from ..physics.smoke_simulator import SmokeSimulator
+from .distributed import shard_range
+
+
+def draw_source_configs(num_samples: int, grid_size: Tuple[int, int]) -> List[Dict]:
+    """data_loader.py:49-58: per sample k=randint(1,4), then k x (x, y, intensity), from the global np.random."""
+    cfgs = []
+    for _ in range(num_samples):
+        k = np.random.randint(1, 4)
+        pos, inten = [], []
+        for _ in range(k):
+            x = np.random.randint(20, grid_size[1] - 20)
+            y = np.random.randint(20, grid_size[0] - 20)
+            intensity = np.random.uniform(0.5, 2.0)
+            pos.append((x, y))
+            inten.append(intensity)
+        cfgs.append({"positions": pos, "intensities": inten})
+    return cfgs
+
+
+def _frame_stats(frames: torch.Tensor):
+    """Per-frame box counts [n,5] and histogram entropy [n] of frames [n,H,W] (smoke_simulator.py:89-140), on device."""
+    n, h, w = frames.shape
+    mean = frames.mean(dim=(1, 2), keepdim=True)
+    binary = frames > mean
+    counts = []
+    for scale in (2, 4, 8, 16, 32):
+        bh, bw = h // scale, w // scale
+        boxes = binary[:, : bh * scale, : bw * scale].reshape(n, bh, scale, bw, scale)
+        counts.append(boxes.any(dim=4).any(dim=2).flatten(1).sum(dim=1))
+    counts = torch.stack(counts, dim=1)
+    flat = frames.flatten(1)
+    ok = (flat >= 0) & (flat <= 1)                       # torch.histogram(range=(0,1)) drops the rest; 1.0 -> last bin
+    idx = torch.clamp((flat * 256).floor().long(), 0, 255) + 256 * torch.arange(n, device=frames.device)[:, None]
+    hist = torch.bincount(idx[ok], minlength=256 * n).reshape(n, 256).float()
+    probs = hist / hist.sum(dim=1, keepdim=True)
+    entropy = -(probs * torch.log2(probs + 1e-8)).sum(dim=1)
+    return counts, entropy
+
+
+def chaos_labels(seq: torch.Tensor, prev_tail: Optional[torch.Tensor], start: int = 10) -> Tuple[dict, List[dict]]:
+    """Labels of one sample: average over t=start..T-1 of get_chaos_features() (data_loader.py:71-88).
+    seq [T,H,W]; prev_tail = the frames the simulator history held before this sample (up to 19 are used)."""
+    T = seq.shape[0]
+    ext = seq if prev_tail is None or prev_tail.shape[0] == 0 else torch.cat([prev_tail[-19:], seq])
+    off = ext.shape[0] - T
+    d = torch.linalg.vector_norm((ext[1:] - ext[:-1]).flatten(1), dim=1).double().cpu().numpy()
+    counts, entropy = _frame_stats(seq[start:])
+    counts, entropy = counts.cpu().numpy(), entropy.cpu().numpy()
+    log_scales = np.log([2, 4, 8, 16, 32])
+    feats = []
+    for t in range(start, T):
+        e = off + t                                        # index of frame t in ext; history length = e + 1
+        if e + 1 < 10:
+            continue                                       # smoke_simulator.py:49-50 -> {} (not appended)
+        lyap = 0.0
+        if e + 1 >= 20:                                    # smoke_simulator.py:69-70
+            win = d[e - 19:e]                              # 19 distances between the last 20 frames
+            lyap = max(0, float(np.mean(np.diff(np.log(win + 1e-8)))))
+        slope = np.polyfit(log_scales, np.log(counts[t - start] + 1), 1)[0]
+        feats.append({"lyapunov_exponent": lyap, "fractal_dimension": abs(float(slope)),
+                      "entropy": float(entropy[t - start])})
+    if feats:
+        avg = {k: np.mean([f[k] for f in feats]) for k in ("lyapunov_exponent", "fractal_dimension", "entropy")}
+    else:
+        avg = {"lyapunov_exponent": 0.0, "fractal_dimension": 1.0, "entropy": 0.0}
+    return avg, feats
+
+
+class SyntheticSmokeDataset(Dataset):
+    """Same constructor/items as the reference (data_loader.py:13-123).  Extra keyword-only knobs:
+    sim_batch (grids per launch), jacobi_iters, storage_device (where sequences are kept; default = device),
+    rank/world (generate and hold only this rank's contiguous block of the global sample list)."""
+
+    def __init__(self, num_samples: int = 1000, grid_size: Tuple[int, int] = (128, 128), sequence_length: int = 20,
+                 device: str = "cuda", cache_path: Optional[str] = None, *, sim_batch: int = 64, jacobi_iters: int = 20,
+                 storage_device: Optional[str] = None, rank: int = 0, world: int = 1):
+        self.num_samples = num_samples
+        self.grid_size = tuple(grid_size)
+        self.sequence_length = sequence_length
+        self.device = device
+        self.cache_path = cache_path
+        self.sim_batch = sim_batch
+        self.jacobi_iters = jacobi_iters
+        self.storage_device = storage_device if storage_device is not None else device
+        self.rank, self.world = rank, world
+        if self.cache_path and os.path.exists(self.cache_path):
+            with open(self.cache_path, "rb") as f:
+                self.data = pickle.load(f)
+            print(f"Loaded synthetic data from {self.cache_path}")
+        else:
+            self.data = self._generate_synthetic_data()
+            if self.cache_path:
+                os.makedirs(os.path.dirname(self.cache_path) or ".", exist_ok=True)
+                with open(self.cache_path, "wb") as f:
+                    pickle.dump([dict(d, sequence=d["sequence"].cpu()) for d in self.data], f)
+                print(f"Saved synthetic data to {self.cache_path}")
+
+    def _generate_synthetic_data(self) -> List[Dict]:
+        dev = _lib.require_cuda(self.device, "SyntheticSmokeDataset")
+        cfgs = draw_source_configs(self.num_samples, self.grid_size)       # every rank draws the full list
+        lo, hi = shard_range(self.num_samples, self.rank, self.world)
+        first = max(lo - 1, 0)                                              # one extra sample: its frames seed the history
+        data, prev_tail = [], None
+        T = self.sequence_length
+        for c0 in range(first, hi, self.sim_batch):
+            c1 = min(c0 + self.sim_batch, hi)
+            sim = SmokeSimulator(self.grid_size, device=dev, batch_size=c1 - c0, jacobi_iters=self.jacobi_iters)
+            srcs = [(i - c0, x, y, 8, inten) for i in range(c0, c1)
+                    for (x, y), inten in zip(cfgs[i]["positions"], cfgs[i]["intensities"])]
+            sim.ns_solver.add_smoke_sources(srcs)
+            seqs = sim.simulate_sequence(T, add_fractal=True)              # [chunk, T, H, W]
+            for i in range(c0, c1):
+                seq = seqs[i - c0]
+                if i >= lo:
+                    avg, _ = chaos_labels(seq, prev_tail)
+                    data.append({"sequence": seq.to(self.storage_device).clone(), "chaos_features": avg,
+                                 "source_config": cfgs[i]})
+                # the reference's history keeps the last 100 frames across samples (smoke_simulator.py:41-43)
+                prev_tail = seq if prev_tail is None else torch.cat([prev_tail, seq])[-100:]
+            del sim
+        return data
+
+    def __len__(self) -> int:
+        return len(self.data)
+
+    def __getitem__(self, idx: int) -> Dict:
+        sample = self.data[idx]
+        frame_idx = np.random.randint(5, self.sequence_length - 5)         # data_loader.py:108
+        return {"input": sample["sequence"][frame_idx].unsqueeze(0),
+                "target": sample["sequence"][frame_idx + 1].unsqueeze(0),
+                "chaos_features": torch.tensor([sample["chaos_features"]["lyapunov_exponent"],
+                                                sample["chaos_features"]["fractal_dimension"],
+                                                sample["chaos_features"]["entropy"]], dtype=torch.float32),
+                "sequence": sample["sequence"]}
+
+
+def create_data_loaders(batch_size: int = 16, num_train: int = 800, num_val: int = 200,
+                        grid_size: Tuple[int, int] = (128, 128), device: str = "cuda", cache_dir: Optional[str] = None,
+                        **dataset_kwargs) -> Tuple[DataLoader, DataLoader]:
+    """data_loader.py:126-184.  Sequences live on the device, so the loaders run in-process (num_workers=0): the
+    reference forks workers only after generation, and forking after HIP initialisation is not allowed here."""
+    rank, world = dataset_kwargs.get("rank", 0), dataset_kwargs.get("world", 1)
+    suffix = "" if world == 1 else f".rank{rank}of{world}"
+    train_cache = os.path.join(cache_dir, f"train_data{suffix}.pkl") if cache_dir else None
+    val_cache = os.path.join(cache_dir, f"val_data{suffix}.pkl") if cache_dir else None
+    train_dataset = SyntheticSmokeDataset(num_samples=num_train, grid_size=grid_size, device=device,
+                                          cache_path=train_cache, **dataset_kwargs)
+    val_dataset = SyntheticSmokeDataset(num_samples=num_val, grid_size=grid_size, device=device,
+                                        cache_path=val_cache, **dataset_kwargs)
+    train_loader = DataLoader(train_dataset, batch_size=batch_size, shuffle=True, num_workers=0)
+    val_loader = DataLoader(val_dataset, batch_size=batch_size, shuffle=False, num_workers=0)
+    return train_loader, val_loader

@@ -1,0 +1,59 @@
+"""One process per GPU over RCCL (torch.distributed backend "nccl" on ROCm); gloo on CPU for tests.
+
+The hot path needs no collective: grids and frames are independent, so ranks own disjoint contiguous blocks of
+grids/samples (shard_range).  The only exchange step is the training gradient all-reduce (DDP, bucketed and
+overlapped with backward), SURVEY.md 8(e).
+"""
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of n independent units owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_distributed(backend: str = None):
+    """Initialise from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*); no-op for one process.
+    Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank
+
+
+def wrap_ddp(model: torch.nn.Module, device, sync_bn: bool = False) -> torch.nn.Module:
+    """DistributedDataParallel around `model` when a process group exists (gradient all-reduce = mean over ranks)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    if sync_bn:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        return torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], bucket_cap_mb=64,
+                                                         gradient_as_bucket_view=True)
+    return torch.nn.parallel.DistributedDataParallel(model)
+
+
+def all_reduce_mean_scalars(values, device):
+    """Mean over ranks of a few logging scalars (one small all-reduce)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return (t / dist.get_world_size()).tolist()

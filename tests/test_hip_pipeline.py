@@ -1,0 +1,120 @@
+"""GPU tests of the callers either side of the hot path: batched dataset generation (data_loader.py), rank-sharded
+generation, and SmokePhysNet forward (HIP encoder + PyTorch-ROCm body) against the reference's captured outputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+from smokephysai_amd.models import SmokePhysNet                            # noqa: E402
+from smokephysai_amd.utils.data_loader import SyntheticSmokeDataset       # noqa: E402
+
+
+@pytest.mark.parametrize("N,nsamp", [(64, 2), (128, 1)])
+def test_dataset_matches_reference_frame_stream(golden, N, nsamp):
+    """np.random.seed(0): identical source lists, frame sequences within 1e-5 (bar 1e-4), labels within 1e-3."""
+    g = golden(f"dataset_seed0_{N}.npz")
+    np.random.seed(0)
+    ds = SyntheticSmokeDataset(num_samples=nsamp, grid_size=(N, N), device="cuda", sim_batch=2)
+    assert len(ds) == nsamp
+    for i, s in enumerate(ds.data):
+        np.testing.assert_array_equal(np.array(s["source_config"]["positions"], dtype=np.int64), g[f"s{i}_positions"])
+        np.testing.assert_array_equal(np.array(s["source_config"]["intensities"]), g[f"s{i}_intensities"])
+        seq = s["sequence"].cpu().numpy()
+        assert seq.shape == (20, N, N)
+        if N == 64:
+            assert rel_err(seq, g[f"s{i}_sequence"]) < 1e-5
+        else:
+            assert rel_err(seq[[0, 5, 10, 19]], g[f"s{i}_sequence_sel"]) < 1e-5
+        np.testing.assert_allclose(seq.astype(np.float64).sum(axis=(1, 2)), g[f"s{i}_frame_sums"], rtol=1e-5)
+        cf = s["chaos_features"]
+        got = [cf["lyapunov_exponent"], cf["fractal_dimension"], cf["entropy"]]
+        np.testing.assert_allclose(got, g[f"s{i}_chaos"], rtol=1e-3, atol=1e-6)
+    np.random.seed(123)
+    item = ds[0]
+    assert set(item) == {"input", "target", "chaos_features", "sequence"}
+    assert rel_err(item["input"].cpu().numpy(), g["item0_seed123_input"]) < 1e-5
+    assert rel_err(item["target"].cpu().numpy(), g["item0_seed123_target"]) < 1e-5
+    np.testing.assert_allclose(item["chaos_features"].numpy(), g["item0_seed123_chaos"], rtol=1e-3, atol=1e-6)
+
+
+def test_rank_sharded_generation_equals_single_process():
+    """2 'ranks' generating their blocks independently reproduce the single-process dataset bit for bit, labels
+    included (each rank re-simulates the one sample before its block to seed the shared-history quirk)."""
+    def gen(rank, world):
+        np.random.seed(42)
+        return SyntheticSmokeDataset(num_samples=5, grid_size=(64, 64), device="cuda", sim_batch=3, rank=rank,
+                                     world=world).data
+    full = gen(0, 1)
+    parts = gen(0, 2) + gen(1, 2)
+    assert len(parts) == len(full) == 5
+    for a, b in zip(full, parts):
+        assert torch.equal(a["sequence"], b["sequence"])
+        assert a["chaos_features"] == b["chaos_features"] and a["source_config"] == b["source_config"]
+
+
+def _load_small(g):
+    model = SmokePhysNet(input_dim=32, hidden_dim=64, num_layers=2, num_heads=4, output_channels=16)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w::")})
+    return model.cuda().eval()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16x3", 1e-4)])
+def test_small_model_forward_vs_reference(golden, dtype, tol):
+    """Full forward (HIP encoder -> transformer with the chaos term folded into Q -> heads) with the reference's own
+    chaos-noise draws injected: all four outputs within 1e-4 relative."""
+    g = golden("model_small.npz")
+    model = _load_small(g)
+    x = torch.from_numpy(g["frames"]).cuda()[:, None]
+    with torch.no_grad():
+        out = model(x, return_features=True, chaos_noise=torch.from_numpy(g["chaos_noise"]).cuda(), encoder_dtype=dtype)
+    for k in ("reconstructed", "physics_features", "latent_features", "intermediate_features"):
+        assert out[k].shape == g[k].shape
+        assert rel_err(out[k].cpu().numpy(), g[k]) < tol, k
+
+
+def test_eval_is_nondeterministic_like_reference_unless_noise_is_pinned(golden):
+    g = golden("model_small.npz")
+    model = _load_small(g)
+    x = torch.from_numpy(g["frames"]).cuda()[:, None]
+    noise = torch.from_numpy(g["chaos_noise"]).cuda()
+    with torch.no_grad():
+        a = model(x, chaos_noise=noise)["latent_features"]
+        b = model(x, chaos_noise=noise)["latent_features"]
+        c = model(x)["latent_features"]
+    assert torch.equal(a, b) and not torch.equal(a, c)       # chaos_attention.py:50-52 draws randn even in eval
+
+
+def test_full_model_forward_vs_reference(golden):
+    """Default 27.8 M-parameter configuration, torch.manual_seed(0) init (identical to the reference's), 128^2 frame."""
+    g = golden("model_full_checksums.npz")
+    torch.manual_seed(0)
+    model = SmokePhysNet().cuda().eval()
+    x = torch.from_numpy(g["frames"]).cuda()[:, None]
+    with torch.no_grad():
+        out = model(x, chaos_noise=torch.from_numpy(g["chaos_noise"]).cuda())
+    assert out["reconstructed"].shape == (1, 1, 128, 128)
+    assert rel_err(out["physics_features"].cpu().numpy(), g["physics_features"]) < 1e-4
+    assert rel_err(out["latent_features"].cpu().numpy(), g["latent_features"]) < 1e-4
+    assert rel_err(out["reconstructed"].cpu().numpy()[0, 0, ::8, ::8], g["recon_sel"]) < 1e-4
+
+
+def test_train_step_runs_and_updates(golden):
+    """One optimisation step of train.py's loop on the GPU (autograd encoder path): finite losses, weights move."""
+    import train
+    g = golden("train_batch.npz")
+    model = SmokePhysNet(input_dim=32, hidden_dim=64, num_layers=2, num_heads=4, output_channels=16)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w::")})
+    model = model.cuda().train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    batch = {"input": torch.from_numpy(g["inputs"]), "target": torch.from_numpy(g["targets"]),
+             "chaos_features": torch.from_numpy(g["chaos_targets"]), "sequence": torch.zeros(2, 20, 128, 128)}
+    w0 = model.feature_proj.weight.detach().clone()
+    total, recon, phys, chaos = train.batch_losses(model, model.physics_regularizer, batch, "cuda")
+    total.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    opt.step()
+    assert torch.isfinite(total) and not torch.equal(w0, model.feature_proj.weight)
+    assert abs(float(recon) - g["losses"][1]) / g["losses"][1] < 1e-2    # dropout active: loose

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""SmokePhysAI training on MI355X -- CLI and function surface of the reference's train.py (41-280):
+load_config / setup_experiment / train_epoch / validate_epoch / main, same loss decomposition
+(recon MSE + 0.1 chaos MSE + 0.05 physics), clip 1.0, AdamW + CosineAnnealingLR, best-val checkpoint schema.
+
+New: data-parallel training, one process per GPU (`python -m torch.distributed.run --nproc-per-node N train.py`):
+each rank simulates and holds its own block of the samples (no data exchange), gradients are averaged with a bucketed
+RCCL all-reduce overlapped with backward (DistributedDataParallel); rank 0 writes the checkpoint.
+TensorBoard logging is optional (the module is not required).
+"""
+import argparse
+import os
+from datetime import datetime
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+import yaml
+from torch.utils.data import DataLoader
+from tqdm import tqdm
+
+from smokephysai_amd.models.physics_regularizer import PhysicsRegularizer
+from smokephysai_amd.utils.data_loader import create_data_loaders
+from smokephysai_amd.utils.distributed import all_reduce_mean_scalars, init_distributed, wrap_ddp
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k): pass
+    def close(self): pass
+
+
+def load_config(config_path: str) -> dict:
+    with open(config_path, "r") as f:
+        return yaml.safe_load(f)
+
+
+def setup_experiment(config: dict, rank: int = 0, local_rank: int = 0):
+    """train.py:25-39 of the reference: experiment dir + writer + device."""
+    timestamp = datetime.now().strftime("%Y%m%d_%H%M%S")
+    exp_dir = f"experiments/smokephys_{timestamp}"
+    writer = _NullWriter()
+    if rank == 0:
+        os.makedirs(exp_dir, exist_ok=True)
+        with open(os.path.join(exp_dir, "config.yaml"), "w") as f:
+            yaml.dump(config, f)
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            writer = SummaryWriter(os.path.join(exp_dir, "logs"))
+        except Exception:
+            pass
+    device = torch.device("cuda", local_rank)
+    if not torch.cuda.is_available():
+        raise RuntimeError("train.py needs a ROCm GPU: smokephysai_amd has no CPU fallback for the simulator")
+    torch.cuda.set_device(device)
+    print(f"Using device: {device}")
+    return exp_dir, writer, device
+
+
+def batch_losses(model, physics_regularizer, batch, device, chaos_noise=None):
+    """Forward + the reference's loss decomposition (train.py:59-85). Returns (total, recon, physics, chaos)."""
+    inputs = batch["input"].to(device)
+    targets = batch["target"].to(device)
+    chaos_targets = batch["chaos_features"].to(device)
+    outputs = model(inputs) if chaos_noise is None else model(inputs, chaos_noise=chaos_noise)
+    recon_loss = F.mse_loss(outputs["reconstructed"], targets)
+    chaos_loss = F.mse_loss(outputs["physics_features"], chaos_targets)
+    physics_losses = physics_regularizer({"density": outputs["reconstructed"],
+                                          "density_sequence": batch["sequence"].to(device)}, {"density": targets})
+    physics_loss = physics_losses["total_physics_loss"]
+    total = recon_loss + 0.1 * chaos_loss + 0.05 * physics_loss
+    return total, recon_loss, physics_loss, chaos_loss
+
+
+def train_epoch(model: nn.Module, train_loader: DataLoader, optimizer: optim.Optimizer,
+                physics_regularizer: PhysicsRegularizer, device, epoch: int, writer) -> Dict[str, float]:
+    model.train()
+    sums = [0.0, 0.0, 0.0, 0.0]
+    pbar = tqdm(train_loader, desc=f"Training Epoch {epoch+1}", leave=True)
+    for batch_idx, batch in enumerate(pbar):
+        optimizer.zero_grad()
+        total, recon, phys, chaos = batch_losses(model, physics_regularizer, batch, device)
+        total.backward()                      # DDP: bucketed RCCL all-reduce (mean over ranks) overlaps this backward
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        optimizer.step()
+        vals = [total.item(), recon.item(), phys.item(), chaos.item()]
+        sums = [s + v for s, v in zip(sums, vals)]
+        if batch_idx % 50 == 0:
+            step = epoch * len(train_loader) + batch_idx
+            for name, v in zip(("Total", "Recon", "Physics", "Chaos"), vals):
+                writer.add_scalar(f"Train/Batch_{name}_Loss", v, step)
+        pbar.set_postfix({"loss": f"{vals[0]:.4f}", "recon": f"{vals[1]:.4f}", "phys": f"{vals[2]:.4f}"})
+    n = max(len(train_loader), 1)
+    avg = all_reduce_mean_scalars([s / n for s in sums], device)
+    return dict(zip(("total_loss", "recon_loss", "physics_loss", "chaos_loss"), avg))
+
+
+def validate_epoch(model: nn.Module, val_loader: DataLoader, physics_regularizer: PhysicsRegularizer,
+                   device) -> Dict[str, float]:
+    model.eval()
+    sums = [0.0, 0.0, 0.0, 0.0]
+    with torch.no_grad():
+        pbar = tqdm(val_loader, desc="Validation", leave=True)
+        for batch in pbar:
+            losses = batch_losses(model, physics_regularizer, batch, device)
+            vals = [v.item() if torch.is_tensor(v) else float(v) for v in losses]
+            sums = [s + v for s, v in zip(sums, vals)]
+            pbar.set_postfix({"loss": f"{vals[0]:.4f}", "recon": f"{vals[1]:.4f}"})
+    n = max(len(val_loader), 1)
+    avg = all_reduce_mean_scalars([s / n for s in sums], device)
+    return dict(zip(("total_loss", "recon_loss", "physics_loss", "chaos_loss"), avg))
+
+
+def main():
+    parser = argparse.ArgumentParser(description="SmokePhysAI Training")
+    parser.add_argument("--config", type=str, default="config/config.yaml", help="Path to config file")
+    parser.add_argument("--resume", type=str, default=None, help="Path to checkpoint to resume from")
+    args = parser.parse_args()
+    config = load_config(args.config)
+    hw = config.get("mi355x", {}) or {}
+    rank, world, local_rank = init_distributed()
+    exp_dir, writer, device = setup_experiment(config, rank, local_rank)
+
+    train_loader, val_loader = create_data_loaders(
+        batch_size=config["training"]["batch_size"], num_train=config["data"]["num_train"],
+        num_val=config["data"]["num_val"], grid_size=tuple(config["data"]["grid_size"]), device=device,
+        cache_dir=config["data"]["cache_dir"], sim_batch=hw.get("sim_batch", 64),
+        jacobi_iters=hw.get("jacobi_iters", 20), rank=rank, world=world)
+
+    from smokephysai_amd.models.smokephys_net import SmokePhysNet
+    model = SmokePhysNet(input_dim=config["model"]["input_dim"], hidden_dim=config["model"]["hidden_dim"],
+                         num_layers=config["model"]["num_layers"], num_heads=config["model"]["num_heads"],
+                         chaos_strength=config["model"]["chaos_strength"],
+                         encoder_dtype=hw.get("encoder_dtype", "f32")).to(device)
+    physics_regularizer = PhysicsRegularizer(conservation_weight=config["physics"]["conservation_weight"],
+                                             continuity_weight=config["physics"]["continuity_weight"],
+                                             energy_weight=config["physics"]["energy_weight"])
+    start_epoch = 0
+    ckpt = None
+    if args.resume:                       # the reference parses --resume but never reads it (train.py:186-187)
+        ckpt = torch.load(args.resume, map_location=device)
+        model.load_state_dict(ckpt["model_state_dict"])
+        start_epoch = int(ckpt.get("epoch", -1)) + 1
+    ddp_model = wrap_ddp(model, device, sync_bn=bool(hw.get("sync_bn", False)))
+    optimizer = optim.AdamW(ddp_model.parameters(), lr=config["training"]["learning_rate"],
+                            weight_decay=config["training"]["weight_decay"])
+    scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=config["training"]["num_epochs"])
+    if ckpt is not None:
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+
+    best_val_loss = float("inf")
+    for epoch in range(start_epoch, config["training"]["num_epochs"]):
+        print(f"\nEpoch {epoch + 1}/{config['training']['num_epochs']}")
+        train_metrics = train_epoch(ddp_model, train_loader, optimizer, physics_regularizer, device, epoch, writer)
+        val_metrics = validate_epoch(model, val_loader, physics_regularizer, device)
+        scheduler.step()
+        writer.add_scalar("Train/Epoch_Loss", train_metrics["total_loss"], epoch)
+        writer.add_scalar("Val/Epoch_Loss", val_metrics["total_loss"], epoch)
+        writer.add_scalar("Learning_Rate", optimizer.param_groups[0]["lr"], epoch)
+        if rank == 0:
+            print("\nEpoch Summary:")
+            print(f"Train Loss: {train_metrics['total_loss']:.4f}")
+            print(f"Val Loss: {val_metrics['total_loss']:.4f}")
+            print(f"Learning Rate: {optimizer.param_groups[0]['lr']:.6f}")
+        if val_metrics["total_loss"] < best_val_loss:
+            best_val_loss = val_metrics["total_loss"]
+            if rank == 0:                  # same schema as the reference (train.py:268-277)
+                torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
+                            "optimizer_state_dict": optimizer.state_dict(),
+                            "scheduler_state_dict": scheduler.state_dict(),
+                            "val_loss": val_metrics["total_loss"], "config": config},
+                           os.path.join(exp_dir, "best_model.pth"))
+    print("Training completed!")
+    writer.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
