@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64, help="grids per GPU")
     ap.add_argument("--jacobi", type=int, default=100)
-    ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--encoder-dtype", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
     args = ap.parse_args()
@@ -154,7 +154,8 @@ def main():
         out = {"metric": "simulated+encoded frames/sec at 256^2 grid, batch 64", "value": frames_total / elapsed,
                "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.encoder_dtype == "f32" else "bf16", "data": "synthetic",
+               "dtype": {"f32": "f32", "bf16x3": "f32 stencil + bf16x3 encoder (split-bf16 MFMA, fp32 accumulate)",
+                         "bf16": "f32 stencil + bf16 encoder"}[args.encoder_dtype], "data": "synthetic",
                "config": {"workload": f"configs[2]: {N}x{N} grid, batch {B} per GPU, Jacobi-{J} project, fractal frame emit, "
                                       f"CNN encoder {args.encoder_dtype} -> [B,128,32,32]",
                           "grid": N, "batch_per_gpu": B, "jacobi_iters": J, "encoder_dtype": args.encoder_dtype,
