@@ -118,7 +118,12 @@ def main():
         if ev: ev[0].record()
         sim.ns_solver.step_into(frame, 1, add_fractal=True, fractal_intensity=0.05)
         if ev: ev[1].record()
-        feats = None if args.no_encode else enc(frame, input_dim=128, dtype=args.encoder_dtype)
+        if args.no_encode:
+            feats = None
+        elif args.encoder_dtype == "f32":
+            feats = enc(frame, input_dim=128, dtype="f32")                        # [B,128,32,32]
+        else:
+            feats = enc.tokens(frame, input_dim=128, dtype=args.encoder_dtype)    # same features, token-major [B,1024,128]
         if ev: ev[2].record()
         return feats
 

@@ -143,6 +143,11 @@ int smk_encoder_destroy(smk_encoder *enc);
 int smk_encoder_forward(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H,
                         int32_t W, int32_t input_dim, float *features, int32_t dtype, void *stream);
 
+/* Same computation, features written token-major: [B][32*32 tokens][128 channels] fp32 -- the layout
+ * `encoded.flatten(2).transpose(1, 2)` (smokephys_net.py:95) hands to feature_proj; coalesced stores. bf16 dtypes only. */
+int smk_encoder_forward_tokens(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H,
+                               int32_t W, int32_t input_dim, float *tokens, int32_t dtype, void *stream);
+
 /* conv1+BN+ReLU activations only (smokephys_net.py:25-27), [B][64][H][W] fp32 -- parity hook. */
 int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H,
                       int32_t W, float *act, void *stream);

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "smk_encoder_destroy": [C.c_void_p],
     "smk_encoder_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                             C.c_void_p, C.c_int32, C.c_void_p],
+    "smk_encoder_forward_tokens": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_int32, C.c_void_p],
     "smk_encoder_conv1": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
 }
 EXPORTS = ["smk_abi_version", "smk_last_error"] + list(_SIGNATURES)

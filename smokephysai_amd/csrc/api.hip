@@ -415,10 +415,26 @@ int smk_encoder_forward(smk_encoder *enc, const float *frames, int64_t frame_str
     if (dtype == SMK_F32)
         return check_launch(launch_encoder_f32(frames, frame_stride, B, H, W, enc->e, features, (hipStream_t)stream), "encoder_f32");
     if (dtype == SMK_BF16X3 || dtype == SMK_BF16)
-        return check_launch(launch_encoder_bf16(frames, frame_stride, B, H, W, enc->e, features, dtype == SMK_BF16X3,
+        return check_launch(launch_encoder_bf16(frames, frame_stride, B, H, W, enc->e, features, dtype == SMK_BF16X3, false,
                                                 (hipStream_t)stream), "encoder_bf16");
     set_error("unknown encoder dtype");
     return SMK_ERR_INVALID;
+}
+
+int smk_encoder_forward_tokens(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H,
+                               int32_t W, int32_t input_dim, float *tokens, int32_t dtype, void *stream) {
+    SMK_REQUIRE(enc && frames && tokens, "null enc/frames/tokens");
+    SMK_REQUIRE(frame_stride >= (int64_t)H * W, "frame_stride >= H*W");
+    int rc = encoder_shape_ok(B, H, W, input_dim);
+    if (rc) return rc;
+    rc = set_device(enc->device);
+    if (rc) return rc;
+    if (dtype != SMK_BF16X3 && dtype != SMK_BF16) {
+        set_error("token-major output is built for the bf16 MFMA kernels (SMK_BF16X3, SMK_BF16)");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return check_launch(launch_encoder_bf16(frames, frame_stride, B, H, W, enc->e, tokens, dtype == SMK_BF16X3, true,
+                                            (hipStream_t)stream), "encoder_bf16_tokens");
 }
 
 int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H, int32_t W,

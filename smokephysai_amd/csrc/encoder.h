@@ -10,7 +10,7 @@ struct EncoderDev {
     float *w2t;   // [9][64][128]       conv2 weights, [tap][c][o]
     float *s2, *t2;   // [128]
     // split-bf16 copies for the bf16 MFMA kernels (value = hi + lo, each a bf16):
-    unsigned short *w1p;   // [2 hi/lo][64 ch][64 taps]   (taps >= 49 are zero)
+    unsigned short *w1p;   // [2 hi/lo][64 ch][64 k], k = 8*ki + kj (ki = 7 or kj = 7: zero)
     unsigned short *w2q;   // [36 k-steps = tap*4 + c/16][2 hi/lo][128 o][16 c]  (B fragments, 1 KiB per wave load)
 };
 
@@ -21,7 +21,8 @@ hipError_t launch_encoder_f32(const float *frames, int64_t fstride, int B, int H
                               float *features, hipStream_t st);
 
 // x3 = true: split-bf16 (hi*hi + hi*lo + lo*hi, ~fp32 accuracy); false: single-pass bf16.
+// tokens = true: features written token-major [B][32*32][128] (coalesced; the layout feature_proj consumes).
 hipError_t launch_encoder_bf16(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
-                               float *features, bool x3, hipStream_t st);
+                               float *features, bool x3, bool tokens, hipStream_t st);
 
 }  // namespace smk

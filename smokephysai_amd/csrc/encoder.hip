@@ -42,9 +42,9 @@ __global__ void k_fold_weights(smk_encoder_weights w, EncoderDev e) {
         e.w2t[t] = w.conv2_w[((size_t)o * 64 + c) * 9 + tap];
     }
     __bf16 *w1p = reinterpret_cast<__bf16 *>(e.w1p), *w2q = reinterpret_cast<__bf16 *>(e.w2q);
-    if (t < 64 * 64) {                                              // w1p [hi|lo][c][64 taps]
-        int c = t / 64, tap = t % 64;
-        float v = tap < 49 ? w.conv1_w[c * 49 + tap] : 0.f;
+    if (t < 64 * 64) {                                              // w1p [hi|lo][c][k = 8*ki + kj] (ki = 7, kj = 7: zero)
+        int c = t / 64, k = t % 64, ki = k >> 3, kj = k & 7;
+        float v = (ki < 7 && kj < 7) ? w.conv1_w[c * 49 + ki * 7 + kj] : 0.f;
         __bf16 hi = (__bf16)v;
         w1p[t] = hi;
         w1p[64 * 64 + t] = (__bf16)(v - (float)hi);
@@ -255,27 +255,30 @@ hipError_t launch_encoder_f32(const float *frames, int64_t fstride, int B, int H
 }
 
 // ---------------------------------------------------------------- fused encoder, bf16 MFMA (single-pass or split "x3")
-// Same 8x32 output tile as the fp32 kernel; both convolutions run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// Both convolutions on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; output tile 8 rows x 16 cols x 128 channels per
+// 256-thread workgroup (4 waves, wave = one 32-channel block).  LDS 54 KB (x3) / 28 KB: >= 2 workgroups per CU, so the
+// VALU/LDS-heavy conv1 phase of one tile overlaps the MFMA-bound conv2 loop of another.
 //   x3: every operand is split v = hi + lo (two bf16) and a product is hi*hi + hi*lo + lo*hi (lo*lo ~ 2^-18 dropped):
 //       fp32-class accuracy (features within 1e-4 of the fp32 reference) at 3 bf16 MFMAs per fp32 MFMA-equivalent.
-// conv1: D[ch][pix] = W1[ch][tap] * im2col(x)[tap][pix]  (M = 32 channels, N = 32 halo pixels, K = 49 padded to 64);
-//        its C/D layout gives each lane 4 consecutive channels of one pixel -> 8-byte packed stores into a1s[pix][ch].
-// conv2: D[pix][o] = a1[pix + tap shift][c] * W2[tap][c][o]   (M = 32 pixels of one row, N = 32 channels, K = 16 c per step)
-//        wave = (mh, nb): 4 tile rows x one 32-channel block -> 4 accumulators;
-//        A fragments = 16-byte reads of a1s (pixel pitch 144 B = 9*16: conflict-free for ds_read_b128);
-//        B fragments = the wave's own weights straight from L2 as fully coalesced 1 KiB loads into a 3-deep register
-//        ring (layout [k-step][hi|lo][o][16 c]) -- no LDS staging and NO barrier inside the K loop, so the 8 waves drift
-//        apart and LDS reads, L2 loads and MFMAs of different waves overlap.
-// epilogue: BN2 + ReLU + block-mean pool in registers (PS = 2, 4 complete per lane; PS = 8 through an 8 KiB LDS reduce).
+// conv1: D[ch][pix] = W1[ch][k] * X[k][pix], M = 32 channels, N = 32 halo pixels, K = 64 with k = 8*ki + kj (kj = 7 and
+//        ki = 7 carry zero weights): a lane's 8 k-values are 8 consecutive pixels of one row of the x tile, read with
+//        immediate-offset ds_read_b32 (no address arithmetic); C/D gives each lane 4 consecutive channels of a pixel ->
+//        8-byte packed stores into a1s[pix][ch].
+// conv2: D[pix][o] = a1[pix + tap][c] * W2[tap][c][o], M block = 2 rows x 16 cols of the tile, K = 16 c per step;
+//        A fragments = 16-byte reads of a1s (pixel pitch 144 B = 9*16); B fragments straight from L2 as coalesced
+//        1 KiB loads into a 3-deep register ring (layout [k-step][hi|lo][o][16 c]); no barrier inside the K loop.
+// epilogue: BN2 + ReLU + block-mean pool in registers (+ one wave shuffle for PS = 8); NCHW or token-major stores.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BX_XS_BYTES = ENC_XH * ENC_XW * 4;         // 2560
-constexpr int BX_A1_PITCH = 144;                         // bytes per halo pixel: 64 ch * 2 B + 16 pad
-constexpr int BX_A1_BYTES = ENC_ACS * BX_A1_PITCH;       // 48960
-constexpr int BX_PART_BYTES = 2 * 2 * 4 * 128 * 4;       // 8192: pool partials [mh][hi][q][o]
-constexpr int BX_ST_BYTES = 2 * 64 * 4;                  // 512: s1 | t1
-template <bool X3> constexpr int bx_lds_bytes() { return BX_XS_BYTES + (X3 ? 2 : 1) * BX_A1_BYTES + BX_PART_BYTES + BX_ST_BYTES; }
+constexpr int B3_TH = 8, B3_TW = 16;                     // output tile
+constexpr int B3_AW = B3_TW + 2, B3_APIX = (B3_TH + 2) * B3_AW;   // a1 halo tile: 10 x 18 = 180 pixels
+constexpr int B3_XH = B3_TH + 9, B3_XW = B3_TW + 9;      // x tile 16 x 24 (+1 zero row, +1 pad column) = 17 x 25
+constexpr int B3_XS_BYTES = ((B3_XH * B3_XW * 4 + 15) / 16) * 16;   // 1712
+constexpr int B3_A1_PITCH = 144;                         // bytes per halo pixel: 64 ch * 2 B + 16 pad
+constexpr int B3_A1_BYTES = B3_APIX * B3_A1_PITCH;       // 25920
+constexpr int B3_ST_BYTES = 2 * 64 * 4;                  // s1 | t1
+template <bool X3> constexpr int b3_lds_bytes() { return B3_XS_BYTES + (X3 ? 2 : 1) * B3_A1_BYTES + B3_ST_BYTES; }
 
 __device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
     hi = (__bf16)v;
@@ -296,26 +299,26 @@ __device__ __forceinline__ float bn_relu(float a, float s, float t) {
     return y > 0.f ? y : 0.f;
 }
 
-template <bool X3, int PS>
-__global__ __launch_bounds__(512) void k_encoder_bf16(const float *__restrict__ frames, int64_t fstride, int H, int W,
+template <bool X3, int PS, bool TOKENS>
+__global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ frames, int64_t fstride, int H, int W,
                                                       EncoderDev e, float *__restrict__ features) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *xs = reinterpret_cast<float *>(smem);
-    unsigned char *a1h = smem + BX_XS_BYTES, *a1l = a1h + BX_A1_BYTES;
-    float *part = reinterpret_cast<float *>(a1h + (X3 ? 2 : 1) * BX_A1_BYTES);
-    float *st1 = part + BX_PART_BYTES / 4;
+    unsigned char *a1h = smem + B3_XS_BYTES, *a1l = a1h + B3_A1_BYTES;
+    float *st1 = reinterpret_cast<float *>(a1h + (X3 ? 2 : 1) * B3_A1_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, r0 = blockIdx.y * ENC_TH, c0 = blockIdx.x * ENC_TW;
+    const int b = blockIdx.z, r0 = blockIdx.y * B3_TH, c0 = blockIdx.x * B3_TW;
     const float *x = frames + (size_t)b * fstride;
 
-    for (int k = tid; k < ENC_XH * ENC_XW; k += 512) {
-        int ii = r0 - 4 + k / ENC_XW, jj = c0 - 4 + k % ENC_XW;
-        xs[k] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? x[(size_t)ii * W + jj] : 0.f;
+    for (int k = tid; k < B3_XH * B3_XW; k += 256) {
+        const int row = k / B3_XW, col = k - row * B3_XW;
+        const int ii = r0 - 4 + row, jj = c0 - 4 + col;
+        xs[k] = (row < B3_XH - 1 && col < B3_XW - 1 && ii >= 0 && ii < H && jj >= 0 && jj < W) ? x[(size_t)ii * W + jj] : 0.f;
     }
     if (tid < 128) st1[tid] = tid < 64 ? e.s1[tid] : e.t1[tid - 64];
 
-    // conv1 weight fragments (A operand: lane = channel row r, k = 8*hi + j), kept in registers for both pixel rounds
+    // conv1 weight fragments (A operand: lane = channel row r, k = 16s + 8hi + j <-> tap (ki = 2s + hi, kj = j))
     const __bf16 *w1p = reinterpret_cast<const __bf16 *>(e.w1p);
     bf16x8 wh[2][4], wl[2][4];
 #pragma unroll
@@ -328,61 +331,56 @@ __global__ __launch_bounds__(512) void k_encoder_bf16(const float *__restrict__ 
         }
     __syncthreads();
 
-    // ---- conv1 on MFMA: 11 blocks of 32 halo pixels x 2 blocks of 32 channels
-    for (int pb = wave; pb < 11; pb += 8) {
+    // ---- conv1 on MFMA: 6 blocks of 32 halo pixels x 2 blocks of 32 channels = 12 tasks, 3 per wave
+#pragma unroll 1
+    for (int k3 = 0; k3 < 3; ++k3) {
+        const int task = wave + 4 * k3, cb = task / 6, pb = task - 6 * cb;      // wave-uniform
         const int pix = pb * 32 + r;
-        const bool valid = pix < ENC_ACS;
-        const int pc = valid ? pix : ENC_ACS - 1;
-        const int ar = pc / ENC_AW, ac = pc % ENC_AW;
+        const bool valid = pix < B3_APIX;
+        const int pc = valid ? pix : B3_APIX - 1;
+        const int ar = pc / B3_AW, ac = pc - ar * B3_AW;
         const int ii = r0 - 1 + ar, jj = c0 - 1 + ac;
         const bool inimg = valid && ii >= 0 && ii < H && jj >= 0 && jj < W;
-        bf16x8 xh[4], xl[4];
+        const float *xp = xs + (ar + hi) * B3_XW + ac;                          // row ar + 2s + hi, cols ac .. ac+7
+        f32x16 acc;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 xh, xl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int t = 16 * s + 8 * hi + j;
-                float xv = 0.f;
-                if (t < 49) {
-                    const int ki = (t * 37) >> 8, kj = t - 7 * ki;
-                    xv = xs[(ar + ki) * ENC_XW + ac + kj];
-                }
                 __bf16 vh, vl;
-                split_bf16(xv, vh, vl);
-                xh[s][j] = vh; xl[s][j] = vl;
+                split_bf16(xp[s * 2 * B3_XW + j], vh, vl);
+                xh[j] = vh; xl[j] = vl;
             }
+            const bf16x8 ah = cb ? wh[1][s] : wh[0][s];
+            const bf16x8 al = X3 ? (cb ? wl[1][s] : wl[0][s]) : ah;
+            mma3<X3>(acc, ah, al, xh, xl);
+        }
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            f32x16 acc;
+        for (int q = 0; q < 4; ++q) {
+            const int ch0 = cb * 32 + 8 * q + 4 * hi;
+            const float4 sc = *reinterpret_cast<const float4 *>(st1 + ch0);
+            const float4 sh = *reinterpret_cast<const float4 *>(st1 + 64 + ch0);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+            bf16x4 vh, vl;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma3<X3>(acc, wh[cb][s], wl[cb][s], xh[s], xl[s]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch0 = cb * 32 + 8 * q + 4 * hi;
-                const float4 sc = *reinterpret_cast<const float4 *>(st1 + ch0);
-                const float4 sh = *reinterpret_cast<const float4 *>(st1 + 64 + ch0);
-                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-                bf16x4 vh, vl;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float y = inimg ? bn_relu(acc[4 * q + i], scv[i], shv[i]) : 0.f;   // outside the image: conv2's zero pad
-                    __bf16 a, bb;
-                    split_bf16(y, a, bb);
-                    vh[i] = a; vl[i] = bb;
-                }
-                if (valid) {
-                    *reinterpret_cast<bf16x4 *>(a1h + pix * BX_A1_PITCH + ch0 * 2) = vh;
-                    if (X3) *reinterpret_cast<bf16x4 *>(a1l + pix * BX_A1_PITCH + ch0 * 2) = vl;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const float y = inimg ? bn_relu(acc[4 * q + i], scv[i], shv[i]) : 0.f;   // outside the image: conv2's zero pad
+                __bf16 a, bb;
+                split_bf16(y, a, bb);
+                vh[i] = a; vl[i] = bb;
+            }
+            if (valid) {
+                *reinterpret_cast<bf16x4 *>(a1h + pix * B3_A1_PITCH + ch0 * 2) = vh;
+                if (X3) *reinterpret_cast<bf16x4 *>(a1l + pix * B3_A1_PITCH + ch0 * 2) = vl;
             }
         }
     }
 
-    // ---- conv2: wave -> tile rows [4mh, 4mh+4) x channels [32nb, 32nb+32)
-    const int nb = wave & 3, mh = wave >> 2;
-    const int o = nb * 32 + r;
+    // ---- conv2: wave = channel block nb; 4 M blocks (rows 2mi, 2mi+1 x 16 cols)
+    const int o = wave * 32 + r;
     const float s2 = e.s2[o], t2 = e.t2[o];
     // w2q as 16-byte units: [k-step 36][hi|lo][o 128][2]; this lane's unit for k-step k: ((k*2+part)*128 + o)*2 + hi
     const uint4 *wq = reinterpret_cast<const uint4 *>(e.w2q) + (size_t)o * 2 + hi;
@@ -397,6 +395,7 @@ __global__ __launch_bounds__(512) void k_encoder_bf16(const float *__restrict__ 
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[mi][g] = 0.f;
+    const int lane_off = ((r >> 4) * B3_AW + (r & 15)) * B3_A1_PITCH + 8 * hi * 2;
     __syncthreads();                                      // a1s complete
 #pragma unroll 1
     for (int k0 = 0; k0 < 36; k0 += 3) {                  // ring depth 3: slot indices stay compile-time constants
@@ -408,11 +407,11 @@ __global__ __launch_bounds__(512) void k_encoder_bf16(const float *__restrict__ 
                 if (X3) bql[(u + 2) % 3] = wq[(size_t)((k + 2) * 2 + 1) * 256];
             }
             const int tap = k >> 2, ks = k & 3, ki = tap / 3, kj = tap - 3 * ki;
-            const int abase = ((4 * mh + ki) * ENC_AW + r + kj) * BX_A1_PITCH + (ks * 16 + 8 * hi) * 2;
+            const int abase = lane_off + (ki * B3_AW + kj) * B3_A1_PITCH + ks * 32;
             bf16x8 ah[4], al[4];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int off = abase + mi * ENC_AW * BX_A1_PITCH;
+                const int off = abase + mi * 2 * B3_AW * B3_A1_PITCH;
                 ah[mi] = *reinterpret_cast<const bf16x8 *>(a1h + off);
                 if (X3) al[mi] = *reinterpret_cast<const bf16x8 *>(a1l + off);
             }
@@ -423,76 +422,79 @@ __global__ __launch_bounds__(512) void k_encoder_bf16(const float *__restrict__ 
         }
     }
 
-    // ---- epilogue: BN2 + ReLU + (PS x PS) block mean.  acc[mi][g]: row 4mh+mi, col (g&3) + 8(g>>2) + 4hi, channel o
-    float *fo = features + ((size_t)b * 128 + o) * 1024;
+    // ---- epilogue.  acc[mi][g]: pixel p = (g&3) + 8(g>>2) + 4hi of M block mi -> tile row 2mi + (p>>4), col p & 15
+    //      i.e. q = g>>2: row 2mi + (q>>1), cols 8(q&1) + 4hi + (g&3)
+    auto out_index = [&](int pi, int pj) -> size_t {
+        return TOKENS ? ((size_t)b * 1024 + pi * 32 + pj) * 128 + o : ((size_t)b * 128 + o) * 1024 + pi * 32 + pj;
+    };
     if (PS == 2) {
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int qc = 0; qc < 2; ++qc)
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg) {
                     float sum = 0.f;
 #pragma unroll
-                    for (int mi = 2 * rg; mi < 2 * rg + 2; ++mi)
+                    for (int qr = 0; qr < 2; ++qr)
 #pragma unroll
-                        for (int i = 2 * cg; i < 2 * cg + 2; ++i) sum += bn_relu(acc[mi][4 * q + i], s2, t2);
-                    const int pi = (r0 + 4 * mh + 2 * rg) / 2, pj = (c0 + 8 * q + 4 * hi + 2 * cg) / 2;
-                    fo[pi * 32 + pj] = sum * 0.25f;
+                        for (int i = 2 * cg; i < 2 * cg + 2; ++i) sum += bn_relu(acc[mi][4 * (2 * qr + qc) + i], s2, t2);
+                    features[out_index((r0 + 2 * mi) / 2, (c0 + 8 * qc + 4 * hi + 2 * cg) / 2)] = sum * 0.25f;
                 }
-    } else {
-        float ps[4];
+    } else if (PS == 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int mp = 0; mp < 2; ++mp)
+#pragma unroll
+            for (int qc = 0; qc < 2; ++qc) {
+                float sum = 0.f;
+#pragma unroll
+                for (int mi = 2 * mp; mi < 2 * mp + 2; ++mi)
+#pragma unroll
+                    for (int qr = 0; qr < 2; ++qr)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += bn_relu(acc[mi][4 * (2 * qr + qc) + i], s2, t2);
+                features[out_index((r0 + 4 * mp) / 4, (c0 + 8 * qc + 4 * hi) / 4)] = sum * (1.0f / 16);
+            }
+    } else {   // PS == 8: two cells (qc); each is split over the two lane halves (hi)
+        float cell[2];
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) {
             float sum = 0.f;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sum += bn_relu(acc[mi][4 * q + i], s2, t2);
-            ps[q] = sum;
-        }
-        if (PS == 4) {
+                for (int qr = 0; qr < 2; ++qr)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fo[((r0 + 4 * mh) / 4) * 32 + (c0 + 8 * q + 4 * hi) / 4] = ps[q] * (1.0f / 16);
-        } else {   // PS == 8: cell = 2 row halves (mh) x 2 column halves (hi)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) part[((mh * 2 + hi) * 4 + q) * 128 + o] = ps[q];
-            __syncthreads();
-            const int oo = tid & 127, q = tid >> 7;
-            float sum = part[((0 * 2 + 0) * 4 + q) * 128 + oo] + part[((0 * 2 + 1) * 4 + q) * 128 + oo];
-            sum += part[((1 * 2 + 0) * 4 + q) * 128 + oo];
-            sum += part[((1 * 2 + 1) * 4 + q) * 128 + oo];
-            features[((size_t)b * 128 + oo) * 1024 + (r0 / 8) * 32 + c0 / 8 + q] = sum * (1.0f / 64);
+                    for (int i = 0; i < 4; ++i) sum += bn_relu(acc[mi][4 * (2 * qr + qc) + i], s2, t2);
+            cell[qc] = sum;
         }
+        const float other0 = __shfl_xor(cell[0], 32), other1 = __shfl_xor(cell[1], 32);
+        const float total = hi == 0 ? cell[0] + other0 : cell[1] + other1;   // a+b == b+a: both halves agree bitwise
+        features[out_index(r0 / 8, c0 / 8 + hi)] = total * (1.0f / 64);
     }
 }
 
-template <bool X3>
+template <bool X3, bool TOKENS>
 static hipError_t launch_bf16_t(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
                                 float *features, hipStream_t st) {
     const int PS = H / 32;
-    dim3 grid(W / ENC_TW, H / ENC_TH, B), block(512);
-    constexpr size_t lds_bytes = bx_lds_bytes<X3>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-    }
+    dim3 grid(W / B3_TW, H / B3_TH, B), block(256);
+    constexpr size_t lds_bytes = b3_lds_bytes<X3>();
     switch (PS) {
-        case 2: hipLaunchKernelGGL((k_encoder_bf16<X3, 2>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
-        case 4: hipLaunchKernelGGL((k_encoder_bf16<X3, 4>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
-        case 8: hipLaunchKernelGGL((k_encoder_bf16<X3, 8>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
+        case 2: hipLaunchKernelGGL((k_encoder_bf16<X3, 2, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
+        case 4: hipLaunchKernelGGL((k_encoder_bf16<X3, 4, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
+        case 8: hipLaunchKernelGGL((k_encoder_bf16<X3, 8, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_encoder_bf16(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
-                               float *features, bool x3, hipStream_t st) {
-    return x3 ? launch_bf16_t<true>(frames, fstride, B, H, W, e, features, st)
-              : launch_bf16_t<false>(frames, fstride, B, H, W, e, features, st);
+                               float *features, bool x3, bool tokens, hipStream_t st) {
+    if (x3) return tokens ? launch_bf16_t<true, true>(frames, fstride, B, H, W, e, features, st)
+                          : launch_bf16_t<true, false>(frames, fstride, B, H, W, e, features, st);
+    return tokens ? launch_bf16_t<false, true>(frames, fstride, B, H, W, e, features, st)
+                  : launch_bf16_t<false, false>(frames, fstride, B, H, W, e, features, st);
 }
 
 }  // namespace smk

@@ -65,6 +65,15 @@ class HipEncoder:
                                                out.data_ptr(), _lib.DTYPES[dtype], _lib.stream_ptr(self._dev)))
         return out
 
+    def tokens(self, x: torch.Tensor, input_dim: int = 128, dtype: str = "bf16x3") -> torch.Tensor:
+        """Same features, token-major [B, 1024, 128] (= encoded.flatten(2).transpose(1, 2), smokephys_net.py:95)."""
+        x = self._frames(x)
+        B, H, W = x.shape
+        out = torch.empty(B, 1024, 128, device=self._dev)
+        _lib.check(self._L.smk_encoder_forward_tokens(self._handle, x.data_ptr(), x.stride(0), B, H, W, int(input_dim),
+                                                      out.data_ptr(), _lib.DTYPES[dtype], _lib.stream_ptr(self._dev)))
+        return out
+
     def conv1_activations(self, x: torch.Tensor) -> torch.Tensor:
         x = self._frames(x)
         B, H, W = x.shape

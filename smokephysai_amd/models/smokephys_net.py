@@ -86,9 +86,13 @@ class SmokePhysNet(nn.Module):
         """x: [B,1,H,W].  chaos_noise (optional): [num_layers,3,B,1] standard-normal draws replacing the reference's
         in-forward torch.randn (chaos_attention.py:50-52) so results can be pinned."""
         B = x.shape[0]
-        encoded = self.encode_frames(x, encoder_dtype)
         pool_size = 32
-        flattened = encoded.flatten(2).transpose(1, 2)
+        dt = encoder_dtype or self.encoder_dtype
+        if not (self.training and torch.is_grad_enabled()) and dt in ("bf16x3", "bf16"):
+            # the bf16 MFMA kernels write the token-major layout feature_proj consumes (smokephys_net.py:95) directly
+            flattened = self.hip_encoder().tokens(x, input_dim=self.input_dim, dtype=dt)
+        else:
+            flattened = self.encode_frames(x, encoder_dtype).flatten(2).transpose(1, 2)
         features = self.feature_proj(flattened)
         features = features + self._pos_embed(pool_size)
         for li, layer in enumerate(self.chaos_layers):

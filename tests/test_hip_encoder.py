@@ -51,6 +51,17 @@ def test_features_bf16_single_pass(golden, enc, N):
     assert rel_err(feats, g["features"]) < 2e-2
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("N", [64, 128, 256])
+def test_token_major_output_is_the_same_data(golden, enc, dtype, N):
+    """smk_encoder_forward_tokens writes [B,1024,128] = features.flatten(2).transpose(1,2) (smokephys_net.py:95), bitwise."""
+    x = torch.from_numpy(golden(f"encoder_io_{N}.npz")["frames"]).cuda()
+    nchw = enc(x, input_dim=128, dtype=dtype)
+    tok = enc.tokens(x, input_dim=128, dtype=dtype)
+    assert tok.shape == (x.shape[0], 1024, 128)
+    assert torch.equal(tok, nchw.flatten(2).transpose(1, 2))
+
+
 def test_conv1_activations(golden, enc):
     g = golden("encoder_io_64.npz")
     act = enc.conv1_activations(torch.from_numpy(g["frames"][:1]).cuda()).cpu().numpy()
