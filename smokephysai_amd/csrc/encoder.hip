@@ -13,6 +13,8 @@
 //   fp32 path: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain).
 #include "encoder.h"
 
+#include <stdlib.h>
+
 namespace smk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -275,10 +277,11 @@ constexpr int B3_TH = 8, B3_TW = 16;                     // output tile
 constexpr int B3_AW = B3_TW + 2, B3_APIX = (B3_TH + 2) * B3_AW;   // a1 halo tile: 10 x 18 = 180 pixels
 constexpr int B3_XH = B3_TH + 9, B3_XW = B3_TW + 9;      // x tile 16 x 24 (+1 zero row, +1 pad column) = 17 x 25
 constexpr int B3_XS_BYTES = ((B3_XH * B3_XW * 4 + 15) / 16) * 16;   // 1712
-constexpr int B3_A1_PITCH = 144;                         // bytes per halo pixel: 64 ch * 2 B + 16 pad
-constexpr int B3_A1_BYTES = B3_APIX * B3_A1_PITCH;       // 25920
-constexpr int B3_ST_BYTES = 2 * 64 * 4;                  // s1 | t1
-template <bool X3> constexpr int b3_lds_bytes() { return B3_XS_BYTES + (X3 ? 2 : 1) * B3_A1_BYTES + B3_ST_BYTES; }
+constexpr int B3_A1_PITCH = 144;                         // bytes per halo pixel: 64 ch * 2 B + 16 pad (9 x 16 B: odd)
+constexpr int B3_A1_ROW = B3_AW * B3_A1_PITCH + 32;      // 2624 B per halo row: 4 rows = 656 x 16 B = 0 mod 16 units, so
+                                                         // an M block of rows (m, m+4) x 16 cols reads conflict-free
+constexpr int B3_A1_BYTES = (B3_TH + 2) * B3_A1_ROW;     // 26240
+template <bool X3> constexpr int b3_lds_bytes() { return B3_XS_BYTES + (X3 ? 2 : 1) * B3_A1_BYTES; }   // 54,192 (x3): 3 per CU
 
 __device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
     hi = (__bf16)v;
@@ -299,178 +302,232 @@ __device__ __forceinline__ float bn_relu(float a, float s, float t) {
     return y > 0.f ? y : 0.f;
 }
 
+constexpr int B3_W1_PITCH = 144;                         // conv1 weights in LDS: [hi|lo][64 ch][64 k] bf16, row pitch 9 x 16 B
+constexpr int B3_W1_BYTES = 64 * B3_W1_PITCH;            // 9216 per part
+template <bool X3> constexpr int b3_lds_total() { return b3_lds_bytes<X3>() + (X3 ? 2 : 1) * B3_W1_BYTES; }   // 72,624 (x3)
+
+// Persistent: each workgroup walks tiles t = blockIdx.x, +gridDim.x, ... .  Per-workgroup costs (conv1 weights -> LDS,
+// BN2 scale/shift, B-ring fill) are paid once; the next tile's x halo is prefetched into registers under the K loop and
+// the B-fragment ring simply keeps running across tiles (the weights do not depend on the tile).
 template <bool X3, int PS, bool TOKENS>
 __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ frames, int64_t fstride, int H, int W,
-                                                      EncoderDev e, float *__restrict__ features) {
+                                                      EncoderDev e, float *__restrict__ features, int lg_tiles_x,
+                                                      int lg_tiles_per_frame, int ntiles, int stagger) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *xs = reinterpret_cast<float *>(smem);
     unsigned char *a1h = smem + B3_XS_BYTES, *a1l = a1h + B3_A1_BYTES;
-    float *st1 = reinterpret_cast<float *>(a1h + (X3 ? 2 : 1) * B3_A1_BYTES);
+    unsigned char *w1s = a1h + (X3 ? 2 : 1) * B3_A1_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, r0 = blockIdx.y * B3_TH, c0 = blockIdx.x * B3_TW;
-    const float *x = frames + (size_t)b * fstride;
 
-    for (int k = tid; k < B3_XH * B3_XW; k += 256) {
-        const int row = k / B3_XW, col = k - row * B3_XW;
-        const int ii = r0 - 4 + row, jj = c0 - 4 + col;
-        xs[k] = (row < B3_XH - 1 && col < B3_XW - 1 && ii >= 0 && ii < H && jj >= 0 && jj < W) ? x[(size_t)ii * W + jj] : 0.f;
-    }
-    if (tid < 128) st1[tid] = tid < 64 ? e.s1[tid] : e.t1[tid - 64];
-
-    // conv1 weight fragments (A operand: lane = channel row r, k = 16s + 8hi + j <-> tap (ki = 2s + hi, kj = j))
-    const __bf16 *w1p = reinterpret_cast<const __bf16 *>(e.w1p);
-    bf16x8 wh[2][4], wl[2][4];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(w1p + (cb * 32 + r) * 64 + 16 * s + 8 * hi);
-            wh[cb][s] = wp[0];
-            if (X3) wl[cb][s] = wp[64 * 64 / 8];
-        }
-    __syncthreads();
-
-    // ---- conv1 on MFMA: 6 blocks of 32 halo pixels x 2 blocks of 32 channels = 12 tasks, 3 per wave
-#pragma unroll 1
-    for (int k3 = 0; k3 < 3; ++k3) {
-        const int task = wave + 4 * k3, cb = task / 6, pb = task - 6 * cb;      // wave-uniform
-        const int pix = pb * 32 + r;
-        const bool valid = pix < B3_APIX;
-        const int pc = valid ? pix : B3_APIX - 1;
-        const int ar = pc / B3_AW, ac = pc - ar * B3_AW;
-        const int ii = r0 - 1 + ar, jj = c0 - 1 + ac;
-        const bool inimg = valid && ii >= 0 && ii < H && jj >= 0 && jj < W;
-        const float *xp = xs + (ar + hi) * B3_XW + ac;                          // row ar + 2s + hi, cols ac .. ac+7
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 xh, xl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                __bf16 vh, vl;
-                split_bf16(xp[s * 2 * B3_XW + j], vh, vl);
-                xh[j] = vh; xl[j] = vl;
-            }
-            const bf16x8 ah = cb ? wh[1][s] : wh[0][s];
-            const bf16x8 al = X3 ? (cb ? wl[1][s] : wl[0][s]) : ah;
-            mma3<X3>(acc, ah, al, xh, xl);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ch0 = cb * 32 + 8 * q + 4 * hi;
-            const float4 sc = *reinterpret_cast<const float4 *>(st1 + ch0);
-            const float4 sh = *reinterpret_cast<const float4 *>(st1 + 64 + ch0);
-            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-            bf16x4 vh, vl;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float y = inimg ? bn_relu(acc[4 * q + i], scv[i], shv[i]) : 0.f;   // outside the image: conv2's zero pad
-                __bf16 a, bb;
-                split_bf16(y, a, bb);
-                vh[i] = a; vl[i] = bb;
-            }
-            if (valid) {
-                *reinterpret_cast<bf16x4 *>(a1h + pix * B3_A1_PITCH + ch0 * 2) = vh;
-                if (X3) *reinterpret_cast<bf16x4 *>(a1l + pix * B3_A1_PITCH + ch0 * 2) = vl;
-            }
+    // ---- once per workgroup
+    {   // conv1 weights [part][ch][64 k] -> LDS with a 144-byte row pitch (16-byte chunks: 8 per row)
+        constexpr int NCH = (X3 ? 2 : 1) * 64 * 8;
+        const uint4 *src = reinterpret_cast<const uint4 *>(e.w1p);
+        for (int c = tid; c < NCH; c += 256) {
+            const int row = c >> 3, u = c & 7;                 // row = part*64 + ch
+            *reinterpret_cast<uint4 *>(w1s + row * B3_W1_PITCH + u * 16) = src[c];
         }
     }
-
-    // ---- conv2: wave = channel block nb; 4 M blocks (rows 2mi, 2mi+1 x 16 cols)
     const int o = wave * 32 + r;
     const float s2 = e.s2[o], t2 = e.t2[o];
     // w2q as 16-byte units: [k-step 36][hi|lo][o 128][2]; this lane's unit for k-step k: ((k*2+part)*128 + o)*2 + hi
     const uint4 *wq = reinterpret_cast<const uint4 *>(e.w2q) + (size_t)o * 2 + hi;
-    uint4 bqh[3], bql[3];
+    constexpr int RING = 6;                               // B fragments in flight: RING-1 k-steps ahead (L2 latency under load)
+    uint4 bqh[RING], bql[RING];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < RING - 1; ++k) {
         bqh[k] = wq[(size_t)(k * 2) * 256];
         if (X3) bql[k] = wq[(size_t)(k * 2 + 1) * 256];
     }
-    f32x16 acc[4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc[mi][g] = 0.f;
-    const int lane_off = ((r >> 4) * B3_AW + (r & 15)) * B3_A1_PITCH + 8 * hi * 2;
-    __syncthreads();                                      // a1s complete
-#pragma unroll 1
-    for (int k0 = 0; k0 < 36; k0 += 3) {                  // ring depth 3: slot indices stay compile-time constants
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int k = k0 + u;
-            if (k + 2 < 36) {
-                bqh[(u + 2) % 3] = wq[(size_t)((k + 2) * 2) * 256];
-                if (X3) bql[(u + 2) % 3] = wq[(size_t)((k + 2) * 2 + 1) * 256];
-            }
-            const int tap = k >> 2, ks = k & 3, ki = tap / 3, kj = tap - 3 * ki;
-            const int abase = lane_off + (ki * B3_AW + kj) * B3_A1_PITCH + ks * 32;
-            bf16x8 ah[4], al[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int off = abase + mi * 2 * B3_AW * B3_A1_PITCH;
-                ah[mi] = *reinterpret_cast<const bf16x8 *>(a1h + off);
-                if (X3) al[mi] = *reinterpret_cast<const bf16x8 *>(a1l + off);
-            }
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, bqh[u]);
-            const bf16x8 bl = X3 ? __builtin_bit_cast(bf16x8, bql[u]) : bh;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) mma3<X3>(acc[mi], ah[mi], al[mi], bh, bl);
-        }
-    }
+    const int lane_off = (r >> 4) * 4 * B3_A1_ROW + (r & 15) * B3_A1_PITCH + 8 * hi * 2;
 
-    // ---- epilogue.  acc[mi][g]: pixel p = (g&3) + 8(g>>2) + 4hi of M block mi -> tile row 2mi + (p>>4), col p & 15
-    //      i.e. q = g>>2: row 2mi + (q>>1), cols 8(q&1) + 4hi + (g&3)
-    auto out_index = [&](int pi, int pj) -> size_t {
-        return TOKENS ? ((size_t)b * 1024 + pi * 32 + pj) * 128 + o : ((size_t)b * 128 + o) * 1024 + pi * 32 + pj;
+    // x halo element k of a tile (2 per thread): value or 0 outside the image / in the pad row and column
+    auto x_fetch = [&](int t, int k) -> float {
+        if (k >= B3_XH * B3_XW) return 0.f;
+        const int bb = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);     // tile counts are 2^n
+        const int rr0 = (rem >> lg_tiles_x) * B3_TH, cc0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
+        const int row = k / B3_XW, col = k - row * B3_XW;
+        const int ii = rr0 - 4 + row, jj = cc0 - 4 + col;
+        const bool ok = row < B3_XH - 1 && col < B3_XW - 1 && ii >= 0 && ii < H && jj >= 0 && jj < W;
+        return ok ? frames[(size_t)bb * fstride + (size_t)ii * W + jj] : 0.f;
     };
-    if (PS == 2) {
+    int t = blockIdx.x;
+    // Workgroups that share a CU run the same program with the same period; started together they stay in lockstep
+    // (both in the VALU-heavy conv1 phase, then both in the MFMA loop).  Delay every other dispatch round by about
+    // half a tile so that one workgroup's conv1 overlaps the other's K loop (speed only, never correctness).
+    if (stagger > 0 && ((blockIdx.x / 256) & 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    if (t < ntiles) {
+        xs[tid] = x_fetch(t, tid);
+        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = x_fetch(t, tid + 256);
+    }
+    __syncthreads();
+
+    for (; t < ntiles; t += gridDim.x) {
+        const int b = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);
+        const int r0 = (rem >> lg_tiles_x) * B3_TH, c0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
+
+        // ---- conv1 on MFMA: 6 blocks of 32 halo pixels x 2 blocks of 32 channels = 12 tasks, 3 per wave
+#pragma unroll 1
+        for (int k3 = 0; k3 < 3; ++k3) {
+            const int task = wave + 4 * k3, cb = task / 6, pb = task - 6 * cb;      // wave-uniform
+            const int pix = pb * 32 + r;
+            const bool valid = pix < B3_APIX;
+            const int pc = valid ? pix : B3_APIX - 1;
+            const int ar = pc / B3_AW, ac = pc - ar * B3_AW;
+            const int ii = r0 - 1 + ar, jj = c0 - 1 + ac;
+            const bool inimg = valid && ii >= 0 && ii < H && jj >= 0 && jj < W;
+            const float *xp = xs + (ar + hi) * B3_XW + ac;                          // row ar + 2s + hi, cols ac .. ac+7
+            const unsigned char *wrow = w1s + (cb * 32 + r) * B3_W1_PITCH + 8 * hi * 2;
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 xh, xl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 vh, vl;
+                    split_bf16(xp[s * 2 * B3_XW + j], vh, vl);
+                    xh[j] = vh; xl[j] = vl;
+                }
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(wrow + s * 32);
+                const bf16x8 al = X3 ? *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + s * 32) : ah;
+                mma3<X3>(acc, ah, al, xh, xl);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch0 = cb * 32 + 8 * q + 4 * hi;
+                const float4 sc = *reinterpret_cast<const float4 *>(e.s1 + ch0);         // L1-resident, 16-byte loads
+                const float4 sh = *reinterpret_cast<const float4 *>(e.t1 + ch0);
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float y = inimg ? bn_relu(acc[4 * q + i], scv[i], shv[i]) : 0.f;   // outside the image: conv2's zero pad
+                    __bf16 a, bb;
+                    split_bf16(y, a, bb);
+                    vh[i] = a; vl[i] = bb;
+                }
+                if (valid) {
+                    const int aoff = ar * B3_A1_ROW + ac * B3_A1_PITCH + ch0 * 2;
+                    *reinterpret_cast<bf16x4 *>(a1h + aoff) = vh;
+                    if (X3) *reinterpret_cast<bf16x4 *>(a1l + aoff) = vl;
+                }
+            }
+        }
+        __syncthreads();                                      // a1s complete; xs is free again
+
+        // next tile's x halo -> registers (lands under the K loop)
+        const int tn = t + gridDim.x;
+        float xr0 = 0.f, xr1 = 0.f;
+        if (tn < ntiles) {
+            xr0 = x_fetch(tn, tid);
+            xr1 = x_fetch(tn, tid + 256);
+        }
+
+        // ---- conv2: wave = channel block; 4 M blocks (rows mi and mi+4, 16 cols each)
+        f32x16 acc[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int qc = 0; qc < 2; ++qc)
+            for (int g = 0; g < 16; ++g) acc[mi][g] = 0.f;
+        auto load_a = [&](int k, bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
+            const int tap = k >> 2, ks = k & 3, ki = tap / 3, kj = tap - 3 * ki;
+            const int abase = lane_off + ki * B3_A1_ROW + kj * B3_A1_PITCH + ks * 32;
 #pragma unroll
-                for (int cg = 0; cg < 2; ++cg) {
+            for (int mi = 0; mi < 4; ++mi) {
+                ah[mi] = *reinterpret_cast<const bf16x8 *>(a1h + abase + mi * B3_A1_ROW);
+                if (X3) al[mi] = *reinterpret_cast<const bf16x8 *>(a1l + abase + mi * B3_A1_ROW);
+            }
+        };
+        bf16x8 ahA[4], alA[4], ahB[4], alB[4];
+        load_a(0, ahA, alA);
+#pragma unroll 1
+        for (int k0 = 0; k0 < 36; k0 += 6) {                  // unrolled by 6 = RING: ring / buffer indices are constants
+                                                              // (a full unroll needs 352 registers: 1 wave/SIMD, slower)
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int k = k0 + u;
+                {   // refill the slot consumed one step ago with k-step k + RING - 1 (wraps into the next tile's k-steps)
+                    int kn = k + RING - 1;
+                    kn = kn >= 36 ? kn - 36 : kn;
+                    bqh[(u + RING - 1) % RING] = wq[(size_t)(kn * 2) * 256];
+                    if (X3) bql[(u + RING - 1) % RING] = wq[(size_t)(kn * 2 + 1) * 256];
+                }
+                if (k + 1 < 36) {
+                    if (u & 1) load_a(k + 1, ahA, alA); else load_a(k + 1, ahB, alB);
+                }
+                // keep the loads of step k+1 / k+RING-1 ahead of step k's MFMAs: hipcc otherwise sinks every ds_read to
+                // just before its consumer (LDS latency exposed per MFMA pair) and drains the ring with vmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bqh[u % RING]);
+                const bf16x8 bl = X3 ? __builtin_bit_cast(bf16x8, bql[u % RING]) : bh;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    if (u & 1) mma3<X3>(acc[mi], ahB[mi], alB[mi], bh, bl); else mma3<X3>(acc[mi], ahA[mi], alA[mi], bh, bl);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue.  acc[mi][g]: pixel p = (g&3) + 8(g>>2) + 4hi of M block mi -> tile row mi + 4(p>>4), col p & 15
+        //      i.e. q = g>>2 = 2qr + qc: row mi + 4qr, cols 8qc + 4hi + (g&3)
+        auto out_index = [&](int pi, int pj) -> size_t {
+            return TOKENS ? ((size_t)b * 1024 + pi * 32 + pj) * 128 + o : ((size_t)b * 128 + o) * 1024 + pi * 32 + pj;
+        };
+        if (PS == 2) {          // cell rows (mi, mi+1) for even mi, cell cols = column pairs
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp)
+#pragma unroll
+                for (int qr = 0; qr < 2; ++qr)
+#pragma unroll
+                    for (int qc = 0; qc < 2; ++qc)
+#pragma unroll
+                        for (int cg = 0; cg < 2; ++cg) {
+                            float sum = 0.f;
+#pragma unroll
+                            for (int mi = 2 * mp; mi < 2 * mp + 2; ++mi)
+#pragma unroll
+                                for (int i = 2 * cg; i < 2 * cg + 2; ++i) sum += bn_relu(acc[mi][4 * (2 * qr + qc) + i], s2, t2);
+                            features[out_index((r0 + 2 * mp + 4 * qr) / 2, (c0 + 8 * qc + 4 * hi + 2 * cg) / 2)] = sum * 0.25f;
+                        }
+        } else if (PS == 4) {   // cell row = qr (rows 4qr .. 4qr+3 = all mi), cell col = 2qc + hi
+#pragma unroll
+            for (int qr = 0; qr < 2; ++qr)
+#pragma unroll
+                for (int qc = 0; qc < 2; ++qc) {
                     float sum = 0.f;
 #pragma unroll
-                    for (int qr = 0; qr < 2; ++qr)
+                    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                        for (int i = 2 * cg; i < 2 * cg + 2; ++i) sum += bn_relu(acc[mi][4 * (2 * qr + qc) + i], s2, t2);
-                    features[out_index((r0 + 2 * mi) / 2, (c0 + 8 * qc + 4 * hi + 2 * cg) / 2)] = sum * 0.25f;
+                        for (int i = 0; i < 4; ++i) sum += bn_relu(acc[mi][4 * (2 * qr + qc) + i], s2, t2);
+                    features[out_index((r0 + 4 * qr) / 4, (c0 + 8 * qc + 4 * hi) / 4)] = sum * (1.0f / 16);
                 }
-    } else if (PS == 4) {
-#pragma unroll
-        for (int mp = 0; mp < 2; ++mp)
+        } else {   // PS == 8: two cells (qc); each is split over the two lane halves (hi)
+            float cell[2];
 #pragma unroll
             for (int qc = 0; qc < 2; ++qc) {
                 float sum = 0.f;
 #pragma unroll
-                for (int mi = 2 * mp; mi < 2 * mp + 2; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int qr = 0; qr < 2; ++qr)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) sum += bn_relu(acc[mi][4 * (2 * qr + qc) + i], s2, t2);
-                features[out_index((r0 + 4 * mp) / 4, (c0 + 8 * qc + 4 * hi) / 4)] = sum * (1.0f / 16);
+                cell[qc] = sum;
             }
-    } else {   // PS == 8: two cells (qc); each is split over the two lane halves (hi)
-        float cell[2];
-#pragma unroll
-        for (int qc = 0; qc < 2; ++qc) {
-            float sum = 0.f;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int qr = 0; qr < 2; ++qr)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sum += bn_relu(acc[mi][4 * (2 * qr + qc) + i], s2, t2);
-            cell[qc] = sum;
+            const float other0 = __shfl_xor(cell[0], 32), other1 = __shfl_xor(cell[1], 32);
+            const float total = hi == 0 ? cell[0] + other0 : cell[1] + other1;   // a+b == b+a: both halves agree bitwise
+            features[out_index(r0 / 8, c0 / 8 + hi)] = total * (1.0f / 64);
         }
-        const float other0 = __shfl_xor(cell[0], 32), other1 = __shfl_xor(cell[1], 32);
-        const float total = hi == 0 ? cell[0] + other0 : cell[1] + other1;   // a+b == b+a: both halves agree bitwise
-        features[out_index(r0 / 8, c0 / 8 + hi)] = total * (1.0f / 64);
+
+        // next tile's x halo -> LDS (xs has been free since the barrier above); one barrier then covers both
+        // "every wave is done reading a1" and "xs is visible"
+        xs[tid] = xr0;
+        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = xr1;
+        __syncthreads();
     }
 }
 
@@ -478,12 +535,36 @@ template <bool X3, bool TOKENS>
 static hipError_t launch_bf16_t(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
                                 float *features, hipStream_t st) {
     const int PS = H / 32;
-    dim3 grid(W / B3_TW, H / B3_TH, B), block(256);
-    constexpr size_t lds_bytes = b3_lds_bytes<X3>();
+    const int tiles_x = W / B3_TW, tiles_per_frame = tiles_x * (H / B3_TH), ntiles = tiles_per_frame * B;
+    int lg_tx = 0, lg_tpf = 0;
+    while ((1 << lg_tx) < tiles_x) ++lg_tx;
+    while ((1 << lg_tpf) < tiles_per_frame) ++lg_tpf;
+    if ((1 << lg_tx) != tiles_x || (1 << lg_tpf) != tiles_per_frame) return hipErrorInvalidValue;   // H = W in {64,128,256}
+    static int stagger = -1;
+    if (stagger < 0) { const char *sv = getenv("SMK_ENC_STAGGER"); stagger = sv ? atoi(sv) : 1; }
+    constexpr size_t lds_bytes = b3_lds_total<X3>();
+    static int wgs_per_cu = 0, num_cu = 0;
+    if (!wgs_per_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        num_cu = prop.multiProcessorCount;
+        int n = 0;
+        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 8, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 4, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 2, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_encoder_bf16<X3, 8, TOKENS>, 256, lds_bytes) != hipSuccess || n < 1) n = 2;
+        const char *ov = getenv("SMK_ENC_WGS_PER_CU");
+        if (ov && atoi(ov) > 0) n = atoi(ov);
+        wgs_per_cu = n;
+    }
+    int nwg = num_cu * wgs_per_cu;
+    if (nwg > ntiles) nwg = ntiles;
+    dim3 grid(nwg), block(256);
     switch (PS) {
-        case 2: hipLaunchKernelGGL((k_encoder_bf16<X3, 2, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
-        case 4: hipLaunchKernelGGL((k_encoder_bf16<X3, 4, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
-        case 8: hipLaunchKernelGGL((k_encoder_bf16<X3, 8, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
+        case 2: hipLaunchKernelGGL((k_encoder_bf16<X3, 2, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles, stagger); break;
+        case 4: hipLaunchKernelGGL((k_encoder_bf16<X3, 4, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles, stagger); break;
+        case 8: hipLaunchKernelGGL((k_encoder_bf16<X3, 8, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles, stagger); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
