@@ -219,44 +219,63 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
             dv[k][c] = div[base + (size_t)k * g.pc + c];
         }
     const bool first_col = lane == 0, last_col = lane == 63;
-    for (int it = 0; it < iters; ++it) {
-        const int par = it & 1;
+    // ring rows (grid row 0 / H-1) exist only in the first wave of the first band and the last wave of the last band
+    const int ring_k = __builtin_amdgcn_readfirstlane(row0 == 0 ? 0 : (row0 + RPW == g.H ? RPW - 1 : -1));   // wave-uniform
+    // one sweep src -> dst (register ping-pong: no row copies); par selects the LDS edge buffer
+    auto sweep = [&](const float (&src)[RPW][VEC], float (&dst)[RPW][VEC], int par) {
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            edge[par][wave][0][j0 + c] = pv[0][c];
-            edge[par][wave][1][j0 + c] = pv[RPW - 1][c];
+            edge[par][wave][0][j0 + c] = src[0][c];
+            edge[par][wave][1][j0 + c] = src[RPW - 1][c];
         }
         __syncthreads();
-        float up[VEC], below[VEC];
+        const float *eu = &edge[par][wave > 0 ? wave - 1 : 0][1][j0];            // top wave: value unused (ring or halo row)
+        const float *ed = &edge[par][wave < JB_NW - 1 ? wave + 1 : JB_NW - 1][0][j0];
+        float above[VEC], below[VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            up[c] = wave > 0 ? edge[par][wave - 1][1][j0 + c] : 0.f;
-            below[c] = wave < JB_NW - 1 ? edge[par][wave + 1][0][j0 + c] : 0.f;
+            above[c] = eu[c];
+            below[c] = ed[c];
         }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
-            float cur[VEC];
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) cur[c] = pv[k][c];
-            const float lin = wave_shr1(cur[VEC - 1]), rin = wave_shl1(cur[0]);
-            const int gi = row0 + k;
-            const bool ring_row = gi == 0 || gi == g.H - 1;
+            const float lin = wave_shr1(src[k][VEC - 1]), rin = wave_shl1(src[k][0]);
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
-                const float dn = k < RPW - 1 ? pv[k + 1][c] : below[c];
-                const float l = c > 0 ? cur[c - 1] : lin;
-                const float r = c < VEC - 1 ? cur[c + 1] : rin;
-                float s = up[c] + dn;
+                const float up = k > 0 ? src[k - 1][c] : above[c];
+                const float dn = k < RPW - 1 ? src[k + 1][c] : below[c];
+                const float l = c > 0 ? src[k][c - 1] : lin;
+                const float r = c < VEC - 1 ? src[k][c + 1] : rin;
+                float s = up + dn;
                 s = s + l;
                 s = s + r;
                 s = s - dv[k][c];
-                float nv = 0.25f * s;
-                if (ring_row || (c == 0 && first_col) || (c == VEC - 1 && last_col)) nv = 0.f;
-                pv[k][c] = nv;
+                dst[k][c] = 0.25f * s;
             }
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) up[c] = cur[c];
+            dst[k][0] = first_col ? 0.f : dst[k][0];          // column ring: only the two edge cells need a select
+            dst[k][VEC - 1] = last_col ? 0.f : dst[k][VEC - 1];
         }
+        if (ring_k == 0) {                                    // row ring: scalar branches, taken by 2 waves of a grid
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) dst[0][c] = 0.f;
+        }
+        if (ring_k == RPW - 1) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) dst[RPW - 1][c] = 0.f;
+        }
+    };
+    float pw[RPW][VEC];
+    int it = 0;
+    for (; it + 2 <= iters; it += 2) {
+        sweep(pv, pw, 0);
+        sweep(pw, pv, 1);
+    }
+    if (it < iters) {
+        sweep(pv, pw, 0);
+#pragma unroll
+        for (int k = 0; k < RPW; ++k)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) pv[k][c] = pw[k][c];
     }
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
@@ -293,10 +312,11 @@ static bool plan_jacobi(const Geom &g, JacobiPlan &pl) {
             if (br > TR || halo < 2) continue;
             if (halo > 64) halo = 64;
             const double wgs = (double)nb * g.B, rounds = ceil(wgs / 256.0);
-            // per launch: ~4us fixed + load/store; per sweep: rounds * TR row-sweeps
-            const double cost_per_sweep = rounds * TR * 0.0065, launch = 4.0 + rounds * TR * 0.02;
-            const double cost20 = ceil(20.0 / halo) * launch + 20 * cost_per_sweep;   // tuned at the reference's J=20..100
-            if (cost20 < best) { best = cost20; pl.rpw = rpw; pl.br = br; pl.nb = nb; pl.halo = halo; ok = true; }
+            // measured on MI355X (256^2 x 64, profiles/r01): ~6 us fixed per launch, ~1.33 us per sweep at 96 rows per
+            // workgroup (barrier + LDS round trip bound, roughly linear in the rows a CU owns)
+            const double cost_per_sweep = rounds * TR * (1.33 / 96.0), launch = 6.0;
+            const double cost = 2 * ceil(50.0 / halo) * launch + 100 * cost_per_sweep;   // evaluated at J = 100
+            if (cost < best) { best = cost; pl.rpw = rpw; pl.br = br; pl.nb = nb; pl.halo = halo; ok = true; }
         }
     }
     return ok;
