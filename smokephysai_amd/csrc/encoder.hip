@@ -331,14 +331,23 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
     }
     const int o = wave * 32 + r;
     const float s2 = e.s2[o], t2 = e.t2[o];
-    // w2q as 16-byte units: [k-step 36][hi|lo][o 128][2]; this lane's unit for k-step k: ((k*2+part)*128 + o)*2 + hi
-    const uint4 *wq = reinterpret_cast<const uint4 *>(e.w2q) + (size_t)o * 2 + hi;
+    // w2q: [k-step 36][hi|lo][o 128][16 c] bf16 = 4 KiB per (k-step, part); this lane reads 16 bytes at a constant
+    // per-lane offset from a wave-uniform (scalar) base: no per-load VGPR address arithmetic
+    // (buffer_load with the descriptor in SGPRs: voffset = lane bytes, soffset = fragment bytes).
+    const int lane_b = (o * 2 + hi) * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(e.w2q), 0, 36 * 2 * 4096, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto load_b = [&](int kn, int part) -> uint4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (kn * 2 + part) * 4096, 0);
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    };
     constexpr int RING = 6;                               // B fragments in flight: RING-1 k-steps ahead (L2 latency under load)
     uint4 bqh[RING], bql[RING];
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k) {
-        bqh[k] = wq[(size_t)(k * 2) * 256];
-        if (X3) bql[k] = wq[(size_t)(k * 2 + 1) * 256];
+        bqh[k] = load_b(k, 0);
+        if (X3) bql[k] = load_b(k, 1);
     }
     const int lane_off = (r >> 4) * 4 * B3_A1_ROW + (r & 15) * B3_A1_PITCH + 8 * hi * 2;
 
@@ -453,20 +462,28 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
                 {   // refill the slot consumed one step ago with k-step k + RING - 1 (wraps into the next tile's k-steps)
                     int kn = k + RING - 1;
                     kn = kn >= 36 ? kn - 36 : kn;
-                    bqh[(u + RING - 1) % RING] = wq[(size_t)(kn * 2) * 256];
-                    if (X3) bql[(u + RING - 1) % RING] = wq[(size_t)(kn * 2 + 1) * 256];
+                    kn = __builtin_amdgcn_readfirstlane(kn);
+                    bqh[(u + RING - 1) % RING] = load_b(kn, 0);
+                    if (X3) bql[(u + RING - 1) % RING] = load_b(kn, 1);
                 }
                 if (k + 1 < 36) {
                     if (u & 1) load_a(k + 1, ahA, alA); else load_a(k + 1, ahB, alB);
                 }
-                // keep the loads of step k+1 / k+RING-1 ahead of step k's MFMAs: hipcc otherwise sinks every ds_read to
-                // just before its consumer (LDS latency exposed per MFMA pair) and drains the ring with vmcnt(0)
-                __builtin_amdgcn_sched_barrier(0);
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, bqh[u % RING]);
                 const bf16x8 bl = X3 ? __builtin_bit_cast(bf16x8, bql[u % RING]) : bh;
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     if (u & 1) mma3<X3>(acc[mi], ahB[mi], alB[mi], bh, bl); else mma3<X3>(acc[mi], ahA[mi], alA[mi], bh, bl);
+                }
+                // Schedule of one k-step: the loads of step k+1 (LDS) and k+RING-1 (L2) are issued INSIDE the gaps of step
+                // k's MFMAs, one per MFMA (hipcc otherwise either sinks each ds_read to just before its consumer or, with
+                // the blocks pinned, issues all loads while the matrix pipe idles).
+                constexpr int NMF = X3 ? 12 : 4, NDS = X3 ? 8 : 4, NVM = X3 ? 2 : 1;
+#pragma unroll
+                for (int i = 0; i < NMF; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                    if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 DS read
+                    else if (i < NDS + NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
