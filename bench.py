@@ -78,6 +78,30 @@ def cpu_baseline(N, J, weights, budget_frames):
             "host_cores_available": os.cpu_count()}
 
 
+def inference_ms(dev, N, frames, encoder_dtype):
+    """Metric M2 (BASELINE.json): SmokePhysNet.forward wall time per frame, eval mode, full 27.8 M-parameter network
+    (HIP encoder + PyTorch-ROCm transformer/heads, fp32), device-synchronised, at the reference's batch sizes
+    (benchmark.py uses 4, inference.py uses 1) and at the simulation batch."""
+    from smokephysai_amd.models import SmokePhysNet
+    torch.manual_seed(0)
+    model = SmokePhysNet(encoder_dtype=encoder_dtype).to(dev).eval()
+    res = {}
+    with torch.no_grad():
+        for bs in (1, 4, frames.shape[0]):
+            x = frames[:bs, None]
+            for _ in range(2):
+                model(x)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                model(x)
+            torch.cuda.synchronize(dev)
+            res[f"batch{bs}"] = (time.perf_counter() - t0) / reps / bs * 1e3
+    res["note"] = f"{N}x{N} frames; reference README: 610.92 ms/frame (hardware unstated)"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +113,7 @@ def main():
     ap.add_argument("--encoder-dtype", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the per-frame inference-ms measurement (metric M2)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +209,8 @@ def main():
             for key, kname in (("roofline_stencil", "stencil"), ("roofline_encoder", "encoder")):
                 if key in out and kname in tr:
                     out[key]["traffic"] = tr[kname]
+        if world == 1 and not args.no_encode and not args.no_inference:
+            out["inference_ms_per_frame"] = inference_ms(dev, N, frame, args.encoder_dtype)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
         print(json.dumps(out), flush=True)
