@@ -304,7 +304,8 @@ __device__ __forceinline__ float bn_relu(float a, float s, float t) {
 
 constexpr int B3_W1_PITCH = 144;                         // conv1 weights in LDS: [hi|lo][64 ch][64 k] bf16, row pitch 9 x 16 B
 constexpr int B3_W1_BYTES = 64 * B3_W1_PITCH;            // 9216 per part
-template <bool X3> constexpr int b3_lds_total() { return b3_lds_bytes<X3>() + (X3 ? 2 : 1) * B3_W1_BYTES; }   // 72,624 (x3)
+constexpr int B3_ST_BYTES = 2 * 64 * 4;                  // BN1 scale | shift
+template <bool X3> constexpr int b3_lds_total() { return b3_lds_bytes<X3>() + (X3 ? 2 : 1) * B3_W1_BYTES + B3_ST_BYTES; }   // 73,136 (x3)
 
 // Persistent: each workgroup walks tiles t = blockIdx.x, +gridDim.x, ... .  Per-workgroup costs (conv1 weights -> LDS,
 // BN2 scale/shift, B-ring fill) are paid once; the next tile's x halo is prefetched into registers under the K loop and
@@ -317,10 +318,12 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
     float *xs = reinterpret_cast<float *>(smem);
     unsigned char *a1h = smem + B3_XS_BYTES, *a1l = a1h + B3_A1_BYTES;
     unsigned char *w1s = a1h + (X3 ? 2 : 1) * B3_A1_BYTES;
+    float *st1 = reinterpret_cast<float *>(w1s + (X3 ? 2 : 1) * B3_W1_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- once per workgroup
+    if (tid < 128) st1[tid] = tid < 64 ? e.s1[tid] : e.t1[tid - 64];
     {   // conv1 weights [part][ch][64 k] -> LDS with a 144-byte row pitch (16-byte chunks: 8 per row)
         constexpr int NCH = (X3 ? 2 : 1) * 64 * 8;
         const uint4 *src = reinterpret_cast<const uint4 *>(e.w1p);
@@ -342,7 +345,8 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (kn * 2 + part) * 4096, 0);
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
-    constexpr int RING = 6;                               // B fragments in flight: RING-1 k-steps ahead (L2 latency under load)
+    constexpr int RING = X3 ? 4 : 6;                      // B fragments in flight: RING-1 k-steps ahead (L2 latency under load);
+                                                          // the ring stays live through conv1, so x3 (2 regs sets) keeps it shorter
     uint4 bqh[RING], bql[RING];
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k) {
@@ -377,39 +381,33 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
         const int b = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);
         const int r0 = (rem >> lg_tiles_x) * B3_TH, c0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
 
-        // ---- conv1 on MFMA: 6 blocks of 32 halo pixels x 2 blocks of 32 channels = 12 tasks, 3 per wave
-#pragma unroll 1
-        for (int k3 = 0; k3 < 3; ++k3) {
-            const int task = wave + 4 * k3, cb = task / 6, pb = task - 6 * cb;      // wave-uniform
+        // ---- conv1 on MFMA: 6 blocks of 32 halo pixels x 2 blocks of 32 channels.  Wave w takes pixel block w for BOTH
+        //      channel blocks (x fragments built once, two independent accumulator chains) and one half of a shared
+        //      block (pixel block 4 + w/2, channel block w&1): 3 (block, channel-block) units per wave.
+        auto x_frags = [&](int pb, bf16x8 (&xh)[4], bf16x8 (&xl)[4], int &aoff, bool &valid, bool &inimg) {
             const int pix = pb * 32 + r;
-            const bool valid = pix < B3_APIX;
+            valid = pix < B3_APIX;
             const int pc = valid ? pix : B3_APIX - 1;
             const int ar = pc / B3_AW, ac = pc - ar * B3_AW;
             const int ii = r0 - 1 + ar, jj = c0 - 1 + ac;
-            const bool inimg = valid && ii >= 0 && ii < H && jj >= 0 && jj < W;
+            inimg = valid && ii >= 0 && ii < H && jj >= 0 && jj < W;
+            aoff = ar * B3_A1_ROW + ac * B3_A1_PITCH;
             const float *xp = xs + (ar + hi) * B3_XW + ac;                          // row ar + 2s + hi, cols ac .. ac+7
-            const unsigned char *wrow = w1s + (cb * 32 + r) * B3_W1_PITCH + 8 * hi * 2;
-            f32x16 acc;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 xh, xl;
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     __bf16 vh, vl;
                     split_bf16(xp[s * 2 * B3_XW + j], vh, vl);
-                    xh[j] = vh; xl[j] = vl;
+                    xh[s][j] = vh; xl[s][j] = vl;
                 }
-                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(wrow + s * 32);
-                const bf16x8 al = X3 ? *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + s * 32) : ah;
-                mma3<X3>(acc, ah, al, xh, xl);
-            }
+        };
+        auto conv1_store = [&](const f32x16 &acc, int cb, int aoff, bool valid, bool inimg) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ch0 = cb * 32 + 8 * q + 4 * hi;
-                const float4 sc = *reinterpret_cast<const float4 *>(e.s1 + ch0);         // L1-resident, 16-byte loads
-                const float4 sh = *reinterpret_cast<const float4 *>(e.t1 + ch0);
+                const float4 sc = *reinterpret_cast<const float4 *>(st1 + ch0);
+                const float4 sh = *reinterpret_cast<const float4 *>(st1 + 64 + ch0);
                 const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
                 bf16x4 vh, vl;
 #pragma unroll
@@ -420,11 +418,47 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
                     vh[i] = a; vl[i] = bb;
                 }
                 if (valid) {
-                    const int aoff = ar * B3_A1_ROW + ac * B3_A1_PITCH + ch0 * 2;
-                    *reinterpret_cast<bf16x4 *>(a1h + aoff) = vh;
-                    if (X3) *reinterpret_cast<bf16x4 *>(a1l + aoff) = vl;
+                    *reinterpret_cast<bf16x4 *>(a1h + aoff + ch0 * 2) = vh;
+                    if (X3) *reinterpret_cast<bf16x4 *>(a1l + aoff + ch0 * 2) = vl;
                 }
             }
+        };
+        {
+            bf16x8 xh[4], xl[4];
+            int aoff; bool valid, inimg;
+            x_frags(wave, xh, xl, aoff, valid, inimg);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { acc0[g] = 0.f; acc1[g] = 0.f; }
+            const unsigned char *wrow = w1s + r * B3_W1_PITCH + 8 * hi * 2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(wrow + s * 32);
+                const bf16x8 a1hh = *reinterpret_cast<const bf16x8 *>(wrow + 32 * B3_W1_PITCH + s * 32);
+                const bf16x8 a0l = X3 ? *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + s * 32) : a0h;
+                const bf16x8 a1l_ = X3 ? *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + 32 * B3_W1_PITCH + s * 32) : a1hh;
+                mma3<X3>(acc0, a0h, a0l, xh[s], xl[s]);
+                mma3<X3>(acc1, a1hh, a1l_, xh[s], xl[s]);
+            }
+            conv1_store(acc0, 0, aoff, valid, inimg);
+            conv1_store(acc1, 1, aoff, valid, inimg);
+        }
+        {
+            bf16x8 xh[4], xl[4];
+            int aoff; bool valid, inimg;
+            const int cb = wave & 1;
+            x_frags(4 + (wave >> 1), xh, xl, aoff, valid, inimg);
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            const unsigned char *wrow = w1s + (cb * 32 + r) * B3_W1_PITCH + 8 * hi * 2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(wrow + s * 32);
+                const bf16x8 al = X3 ? *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + s * 32) : ah;
+                mma3<X3>(acc, ah, al, xh[s], xl[s]);
+            }
+            conv1_store(acc, cb, aoff, valid, inimg);
         }
         __syncthreads();                                      // a1s complete; xs is free again
 
@@ -453,11 +487,11 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
         };
         bf16x8 ahA[4], alA[4], ahB[4], alB[4];
         load_a(0, ahA, alA);
+        constexpr int UNR = RING == 6 ? 6 : 12;               // multiple of RING and of 2: ring / buffer indices are constants
 #pragma unroll 1
-        for (int k0 = 0; k0 < 36; k0 += 6) {                  // unrolled by 6 = RING: ring / buffer indices are constants
-                                                              // (a full unroll needs 352 registers: 1 wave/SIMD, slower)
+        for (int k0 = 0; k0 < 36; k0 += UNR) {                // (a full unroll needs 352 registers: 1 wave/SIMD, slower)
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const int k = k0 + u;
                 {   // refill the slot consumed one step ago with k-step k + RING - 1 (wraps into the next tile's k-steps)
                     int kn = k + RING - 1;
