@@ -121,6 +121,15 @@ int smk_advect(const float *field, float *out, int32_t which, const float *u, co
  * writes [N][N] fp32 each (any pointer may be NULL): perlin, mandelbrot (counts/100), 0.7*perlin+0.3*mandelbrot. */
 int smk_fractal_constants(int32_t N, float *perlin, float *mandel, float *field, void *stream);
 
+/* SmokeSimulator.get_chaos_features' reductions (smoke_simulator.py:47-140) for n frames [H][W] (dense rows, frame
+ * stride `frame_stride` floats): means [n] fp32 (frame.mean()), box_counts [n][5] int32 (scales 2,4,8,16,32 of
+ * frame > mean), hist [n][256] int32 (torch.histogram(bins=256, range=(0,1)) counts). Needs (H/2)*(W/2) <= 65536. */
+int smk_chaos_stats(const float *frames, int64_t frame_stride, int32_t n, int32_t H, int32_t W, float *means,
+                    int32_t *box_counts, int32_t *hist, void *stream);
+/* ||frame[i+1] - frame[i]||_2 for i < n-1 (smoke_simulator.py:73-79) -> norms [n-1] fp32 (fp64 accumulation). */
+int smk_frame_diff_norms(const float *frames, int64_t frame_stride, int32_t n, int32_t H, int32_t W, float *norms,
+                         void *stream);
+
 /* ------------------------------------------------------------------ CNN encoder */
 typedef enum smk_dtype { SMK_F32 = 0, SMK_BF16X3 = 1, SMK_BF16 = 2 } smk_dtype;
 

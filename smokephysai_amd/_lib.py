@@ -47,6 +47,9 @@ _SIGNATURES = {
     "smk_advect": [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                    C.c_int32, C.c_int32, C.c_double, C.c_void_p],
     "smk_fractal_constants": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "smk_chaos_stats": [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                        C.c_void_p],
+    "smk_frame_diff_norms": [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
     "smk_encoder_create": [C.POINTER(SmkEncoderWeights), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
     "smk_encoder_destroy": [C.c_void_p],
     "smk_encoder_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

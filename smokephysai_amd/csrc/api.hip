@@ -3,6 +3,7 @@
 #include <mutex>
 #include <vector>
 
+#include "chaos.h"
 #include "encoder.h"
 #include "stencil.h"
 
@@ -342,6 +343,24 @@ int smk_fractal_constants(int32_t N, float *perlin, float *mandel, float *field,
     (void)hipFree(tmp);
     if (rc) return rc;
     return check_launch(e, "fractal_constants copy");
+}
+
+int smk_chaos_stats(const float *frames, int64_t frame_stride, int32_t n, int32_t H, int32_t W, float *means,
+                    int32_t *box_counts, int32_t *hist, void *stream) {
+    SMK_REQUIRE(frames && means && box_counts && hist, "null pointer");
+    SMK_REQUIRE(n >= 1 && H >= 2 && W >= 2 && frame_stride >= (int64_t)H * W, "n>=1, H,W>=2, frame_stride >= H*W");
+    if ((int64_t)(H / 2) * (W / 2) > 65536) {
+        set_error("chaos_stats: frames larger than 512x512 are not built");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return check_launch(launch_chaos_stats(frames, frame_stride, n, H, W, means, box_counts, hist, (hipStream_t)stream),
+                        "chaos_stats");
+}
+
+int smk_frame_diff_norms(const float *frames, int64_t frame_stride, int32_t n, int32_t H, int32_t W, float *norms,
+                         void *stream) {
+    SMK_REQUIRE(frames && norms && n >= 2 && H >= 1 && W >= 1 && frame_stride >= (int64_t)H * W, "bad arguments");
+    return check_launch(launch_diff_norms(frames, frame_stride, n - 1, H * W, norms, (hipStream_t)stream), "diff_norms");
 }
 
 // ------------------------------------------------------------------ encoder

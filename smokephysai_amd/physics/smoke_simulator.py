@@ -2,7 +2,8 @@
 
 simulate_step = one fused stencil step of the batched solver; the fractal perturbation is applied to the emitted
 frame only (the solver keeps the unperturbed density, smoke_simulator.py:36-39) inside the density-advect kernel.
-The chaos statistics (smoke_simulator.py:47-140) are computed on the device with torch reductions.
+The chaos statistics (smoke_simulator.py:47-140) use the HIP reductions of csrc/chaos.hip (mean, box counts, histogram,
+frame-difference norms); only the scalar formulas on their results run on the host, as in the reference.
 """
 from typing import Optional
 
@@ -10,6 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from .fractal_generator import FractalGenerator
 from .navier_stokes import NavierStokesSimulator
 
@@ -75,44 +77,63 @@ class SmokeSimulator(nn.Module):
         return histogram_entropy(self.history[-1])
 
 
-# ---- statistics on device tensors (single grid [.., H, W]) -------------------------------------------------
-def lyapunov_from_frames(states: torch.Tensor) -> float:
-    """smoke_simulator.py:67-87: mean of diff(log(|s[i+1]-s[i]|_2 + 1e-8)) over 20 frames, clamped at 0."""
-    d = torch.linalg.vector_norm((states[1:] - states[:-1]).flatten(1), dim=1)       # fp32 norms, as torch.norm
-    distances = d.double().cpu().numpy()
-    if len(distances) > 1:
-        return max(0, float(np.mean(np.diff(np.log(distances + 1e-8)))))
+# ---- chaos statistics: HIP reductions (csrc/chaos.hip) + the reference's tiny host-side formulas ---------------
+def chaos_stats(frames: torch.Tensor):
+    """means [n] fp32, box counts [n,5] int32 (scales 2..32 of frame > mean), histogram [n,256] int32 of n frames
+    [n,H,W] on the device (smoke_simulator.py:89-140's reductions, one launch)."""
+    dev = _lib.require_cuda(frames.device, "chaos_stats")
+    f = frames.to(torch.float32)
+    if f.dim() == 2:
+        f = f[None]
+    if f.stride(2) != 1 or f.stride(1) != f.shape[2]:
+        f = f.contiguous()
+    n, h, w = f.shape
+    means = torch.empty(n, device=dev)
+    box = torch.empty(n, 5, dtype=torch.int32, device=dev)
+    hist = torch.empty(n, 256, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().smk_chaos_stats(f.data_ptr(), f.stride(0), n, h, w, means.data_ptr(), box.data_ptr(),
+                                           hist.data_ptr(), _lib.stream_ptr(dev)))
+    return means, box, hist
+
+
+def frame_diff_norms(frames: torch.Tensor) -> torch.Tensor:
+    """||frames[i+1] - frames[i]||_2 for consecutive frames [n,H,W] -> [n-1] fp32 (smoke_simulator.py:73-79)."""
+    dev = _lib.require_cuda(frames.device, "frame_diff_norms")
+    f = frames.to(torch.float32).contiguous()
+    n, h, w = f.shape
+    out = torch.empty(n - 1, device=dev)
+    _lib.check(_lib.load().smk_frame_diff_norms(f.data_ptr(), f.stride(0), n, h, w, out.data_ptr(), _lib.stream_ptr(dev)))
+    return out
+
+
+def lyapunov_from_norms(distances) -> float:
+    """smoke_simulator.py:81-87: mean(diff(log(d + 1e-8))) clamped at 0 (host, float64 like the reference)."""
+    d = np.asarray(distances, dtype=np.float64)
+    if len(d) > 1:
+        return max(0, float(np.mean(np.diff(np.log(d + 1e-8)))))
     return 0.0
 
 
-def box_counts(frame: torch.Tensor) -> torch.Tensor:
-    """smoke_simulator.py:96-115: number of scale x scale boxes holding any cell above the frame mean."""
-    binary = frame > frame.mean()
-    h, w = binary.shape
-    counts = []
-    for scale in (2, 4, 8, 16, 32):
-        bh, bw = h // scale, w // scale
-        boxes = binary[: bh * scale, : bw * scale].reshape(bh, scale, bw, scale)
-        counts.append(boxes.any(dim=3).any(dim=1).sum())
-    return torch.stack(counts)
-
-
-def fractal_dimension(frame: torch.Tensor) -> float:
-    counts = box_counts(frame).cpu().numpy()
-    slope = np.polyfit(np.log([2, 4, 8, 16, 32]), np.log(counts + 1), 1)[0]
+def fractal_dimension_from_counts(counts) -> float:
+    """smoke_simulator.py:116-122: |slope| of log(count+1) vs log(scale)."""
+    slope = np.polyfit(np.log([2, 4, 8, 16, 32]), np.log(np.asarray(counts, dtype=np.float64) + 1), 1)[0]
     return abs(float(slope))
 
 
-def hist256(frame: torch.Tensor) -> torch.Tensor:
-    """torch.histogram(bins=256, range=(0,1)) semantics (smoke_simulator.py:134-135): values outside [0,1] are
-    dropped and exactly 1.0 falls in the last bin; bin = floor(x*256) (exact: power-of-two scale)."""
-    x = frame.flatten()
-    x = x[(x >= 0) & (x <= 1)]
-    idx = torch.clamp((x * 256).floor().long(), max=255)
-    return torch.bincount(idx, minlength=256)
+def entropy_from_hist(hist) -> float:
+    """smoke_simulator.py:136-140: -sum(p * log2(p + 1e-8)), p = counts / total, fp32 like the reference."""
+    h = np.asarray(hist).astype(np.float32)
+    probs = h / h.sum(dtype=np.float32)
+    return float(-np.sum(probs * np.log2(probs + np.float32(1e-8)), dtype=np.float32))
+
+
+def lyapunov_from_frames(states: torch.Tensor) -> float:
+    return lyapunov_from_norms(frame_diff_norms(states).cpu().numpy())
+
+
+def fractal_dimension(frame: torch.Tensor) -> float:
+    return fractal_dimension_from_counts(chaos_stats(frame)[1][0].cpu().numpy())
 
 
 def histogram_entropy(frame: torch.Tensor) -> float:
-    hist = hist256(frame).float()
-    probs = hist / hist.sum()
-    return float(-torch.sum(probs * torch.log2(probs + 1e-8)))
+    return entropy_from_hist(chaos_stats(frame)[2][0].cpu().numpy())

@@ -3,7 +3,7 @@
 The reference generates `num_samples` sequences by looping a single-grid simulator in Python
 (data_loader.py:44-97).  Here the same samples come from the batched HIP stepper: the source lists are drawn from
 the global np.random stream in the reference's exact order (so a given seed gives the same sources), `sim_batch`
-grids are simulated per launch, and the chaos-statistics labels are computed on the device -- including the
+grids are simulated per launch, and the chaos-statistics labels come from the HIP reductions -- including the
 reference's quirk that the simulator history is never cleared between samples (data_loader.py:46 resets only the
 solver), so sample i's Lyapunov window reaches back into sample i-1's frames.
 """
@@ -16,7 +16,8 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 from .. import _lib
-from ..physics.smoke_simulator import SmokeSimulator
+from ..physics.smoke_simulator import (SmokeSimulator, chaos_stats, entropy_from_hist, fractal_dimension_from_counts,
+                                       frame_diff_norms, lyapunov_from_norms)
 from .distributed import shard_range
 
 
@@ -36,53 +37,38 @@ def draw_source_configs(num_samples: int, grid_size: Tuple[int, int]) -> List[Di
     return cfgs
 
 
-def _frame_stats(frames: torch.Tensor):
-    """Per-frame box counts [n,5] and histogram entropy [n] of frames [n,H,W] (smoke_simulator.py:89-140), on device."""
-    n, h, w = frames.shape
-    mean = frames.mean(dim=(1, 2), keepdim=True)
-    binary = frames > mean
-    counts = []
-    for scale in (2, 4, 8, 16, 32):
-        bh, bw = h // scale, w // scale
-        boxes = binary[:, : bh * scale, : bw * scale].reshape(n, bh, scale, bw, scale)
-        counts.append(boxes.any(dim=4).any(dim=2).flatten(1).sum(dim=1))
-    counts = torch.stack(counts, dim=1)
-    flat = frames.flatten(1)
-    ok = (flat >= 0) & (flat <= 1)                       # torch.histogram(range=(0,1)) drops the rest; 1.0 -> last bin
-    idx = torch.clamp((flat * 256).floor().long(), 0, 255) + 256 * torch.arange(n, device=frames.device)[:, None]
-    hist = torch.bincount(idx[ok], minlength=256 * n).reshape(n, 256).float()
-    probs = hist / hist.sum(dim=1, keepdim=True)
-    entropy = -(probs * torch.log2(probs + 1e-8)).sum(dim=1)
-    return counts, entropy
-
-
-def chaos_labels(seq: torch.Tensor, prev_tail: Optional[torch.Tensor], start: int = 10) -> Tuple[dict, List[dict]]:
-    """Labels of one sample: average over t=start..T-1 of get_chaos_features() (data_loader.py:71-88).
-    seq [T,H,W]; prev_tail = the frames the simulator history held before this sample (up to 19 are used)."""
-    T = seq.shape[0]
-    ext = seq if prev_tail is None or prev_tail.shape[0] == 0 else torch.cat([prev_tail[-19:], seq])
-    off = ext.shape[0] - T
-    d = torch.linalg.vector_norm((ext[1:] - ext[:-1]).flatten(1), dim=1).double().cpu().numpy()
-    counts, entropy = _frame_stats(seq[start:])
-    counts, entropy = counts.cpu().numpy(), entropy.cpu().numpy()
-    log_scales = np.log([2, 4, 8, 16, 32])
+def labels_from_stats(diff_norms, box_counts, hists, T: int, off: int, start: int = 10) -> Tuple[dict, List[dict]]:
+    """Host part of the labels (data_loader.py:71-88 + smoke_simulator.py:47-140's scalar formulas).
+    diff_norms: distances between consecutive frames of the extended history (off frames of the previous sample, then
+    this sample's T frames); box_counts / hists: per frame t = start..T-1."""
+    d = np.asarray(diff_norms, dtype=np.float64)
     feats = []
     for t in range(start, T):
-        e = off + t                                        # index of frame t in ext; history length = e + 1
+        e = off + t                                        # index of frame t in the history; history length = e + 1
         if e + 1 < 10:
             continue                                       # smoke_simulator.py:49-50 -> {} (not appended)
         lyap = 0.0
         if e + 1 >= 20:                                    # smoke_simulator.py:69-70
-            win = d[e - 19:e]                              # 19 distances between the last 20 frames
-            lyap = max(0, float(np.mean(np.diff(np.log(win + 1e-8)))))
-        slope = np.polyfit(log_scales, np.log(counts[t - start] + 1), 1)[0]
-        feats.append({"lyapunov_exponent": lyap, "fractal_dimension": abs(float(slope)),
-                      "entropy": float(entropy[t - start])})
+            lyap = lyapunov_from_norms(d[e - 19:e])        # 19 distances between the last 20 frames
+        feats.append({"lyapunov_exponent": lyap,
+                      "fractal_dimension": fractal_dimension_from_counts(box_counts[t - start]),
+                      "entropy": entropy_from_hist(hists[t - start])})
     if feats:
         avg = {k: np.mean([f[k] for f in feats]) for k in ("lyapunov_exponent", "fractal_dimension", "entropy")}
     else:
         avg = {"lyapunov_exponent": 0.0, "fractal_dimension": 1.0, "entropy": 0.0}
     return avg, feats
+
+
+def chaos_labels(seq: torch.Tensor, prev_tail: Optional[torch.Tensor], start: int = 10) -> Tuple[dict, List[dict]]:
+    """Labels of one sample: average over t=start..T-1 of get_chaos_features() (data_loader.py:71-88).
+    seq [T,H,W] on the device; prev_tail = the frames the simulator history held before this sample (19 are used)."""
+    T = seq.shape[0]
+    ext = seq if prev_tail is None or prev_tail.shape[0] == 0 else torch.cat([prev_tail[-19:], seq])
+    off = ext.shape[0] - T
+    d = frame_diff_norms(ext).cpu().numpy()
+    _, box, hist = chaos_stats(seq[start:])
+    return labels_from_stats(d, box.cpu().numpy(), hist.cpu().numpy(), T, off, start)
 
 
 class SyntheticSmokeDataset(Dataset):

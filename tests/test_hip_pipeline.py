@@ -40,6 +40,32 @@ def test_dataset_matches_reference_frame_stream(golden, N, nsamp):
     np.testing.assert_allclose(item["chaos_features"].numpy(), g["item0_seed123_chaos"], rtol=1e-3, atol=1e-6)
 
 
+def test_chaos_stat_kernels_exact_vs_reference_and_oracle(golden):
+    """HIP chaos-statistics reductions: box counts and histogram counts are integer work -> exact against the
+    reference's captured values and against the CPU oracle on random frames; norms / means within fp32 rounding."""
+    import oracle
+    from smokephysai_amd.physics.smoke_simulator import chaos_stats, frame_diff_norms
+    g = golden("chaos_stats_64.npz")
+    frames = torch.from_numpy(g["frames"]).cuda()
+    means, box, hist = chaos_stats(frames[-1])
+    np.testing.assert_array_equal(box[0].cpu().numpy(), g["box_counts"])
+    np.testing.assert_array_equal(hist[0].cpu().numpy(), g["hist_counts"])
+    assert abs(float(means[0]) - float(g["mean"])) < 1e-7
+    np.testing.assert_allclose(frame_diff_norms(frames[-20:]).cpu().numpy(), g["lyap_dists"], rtol=2e-6)
+    rng = np.random.RandomState(5)
+    for N in (64, 256):
+        fr = (rng.rand(3, N, N) ** 3 * 1.6 - 0.1).astype(np.float32)         # values below 0, above 1, and exactly 1.0
+        fr[0, 0, :5] = [1.0, 0.0, -0.0, 1.0000001, 0.99999994]
+        means, box, hist = chaos_stats(torch.from_numpy(fr).cuda())
+        o = oracle.OracleSmokeSimulator((N, N))
+        for i in range(3):
+            cnt = np.empty(5, np.int64)
+            oracle.lib().so_box_counts(fr[i], N, N, float(means[i]), cnt)    # same mean -> exact comparison
+            np.testing.assert_array_equal(box[i].cpu().numpy(), cnt)
+            np.testing.assert_array_equal(hist[i].cpu().numpy(), o.hist_counts(fr[i]))
+            assert abs(float(means[i]) - fr[i].astype(np.float64).mean()) < 1e-6
+
+
 def test_rank_sharded_generation_equals_single_process():
     """2 'ranks' generating their blocks independently reproduce the single-process dataset bit for bit, labels
     included (each rank re-simulates the one sample before its block to seed the shared-history quirk)."""

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from smokephysai_amd.models import PhysicsRegularizer, SmokePhysNet
-from smokephysai_amd.utils.data_loader import chaos_labels, draw_source_configs
+from smokephysai_amd.utils.data_loader import draw_source_configs
 from smokephysai_amd.utils.distributed import shard_range
 
 
@@ -34,28 +34,41 @@ def test_source_draw_order_matches_reference(golden, N, nsamp):
 
 
 def test_chaos_labels_with_shared_history_quirk(golden):
-    """Labels from the reference's own frames: sample 1's Lyapunov window reaches into sample 0 (history never cleared)."""
+    """Host label logic on the reference's own frames (stats from the CPU oracle): sample 1's Lyapunov window reaches
+    into sample 0 because the reference never clears the history (data_loader.py:46 resets only the solver)."""
+    import oracle
+    from smokephysai_amd.utils.data_loader import labels_from_stats
     g = golden("dataset_seed0_64.npz")
-    s0, s1 = torch.from_numpy(g["s0_sequence"]), torch.from_numpy(g["s1_sequence"])
-    avg0, f0 = chaos_labels(s0, None)
-    avg1, f1 = chaos_labels(s1, s0)
+    s0, s1 = g["s0_sequence"], g["s1_sequence"]
+
+    def stats(seq, prev):
+        ext = seq if prev is None else np.concatenate([prev[-19:], seq])
+        d = np.array([np.float32(np.sqrt(np.sum((ext[i + 1].astype(np.float64) - ext[i]) ** 2))) for i in range(len(ext) - 1)])
+        o = oracle.OracleSmokeSimulator((64, 64))
+        box = np.stack([o.box_counts(f) for f in seq[10:]])
+        hist = np.stack([o.hist_counts(f) for f in seq[10:]])
+        return d, box, hist, len(ext) - len(seq)
+
+    d, box, hist, off = stats(s0, None)
+    avg0, f0 = labels_from_stats(d, box, hist, 20, off)
+    d, box, hist, off = stats(s1, s0)
+    avg1, f1 = labels_from_stats(d, box, hist, 20, off)
     for avg, ref in ((avg0, g["s0_chaos"]), (avg1, g["s1_chaos"])):
         got = [avg["lyapunov_exponent"], avg["fractal_dimension"], avg["entropy"]]
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7)
     assert len(f0) == 10 and sum(f["lyapunov_exponent"] == 0.0 for f in f0) >= 9     # only t=19 has 20 frames
-    # without the quirk sample 1 would look like sample 0 (zeros until t=19): the averages must differ
-    avg1_noquirk, _ = chaos_labels(s1, None)
+    d, box, hist, off = stats(s1, None)
+    avg1_noquirk, _ = labels_from_stats(d, box, hist, 20, off)
     assert avg1_noquirk["lyapunov_exponent"] != avg1["lyapunov_exponent"] or avg1["lyapunov_exponent"] == 0.0
 
 
-def test_chaos_stats_vs_reference(golden):
-    from smokephysai_amd.physics.smoke_simulator import box_counts, hist256, histogram_entropy, lyapunov_from_frames
+def test_chaos_scalar_formulas_vs_reference(golden):
+    from smokephysai_amd.physics.smoke_simulator import (entropy_from_hist, fractal_dimension_from_counts,
+                                                         lyapunov_from_norms)
     g = golden("chaos_stats_64.npz")
-    frames = torch.from_numpy(g["frames"])
-    np.testing.assert_array_equal(box_counts(frames[-1]).numpy(), g["box_counts"])
-    np.testing.assert_array_equal(hist256(frames[-1]).numpy(), g["hist_counts"])
-    assert abs(lyapunov_from_frames(frames[-20:]) - g["feats"][0]) < 1e-6
-    assert abs(histogram_entropy(frames[-1]) - g["feats"][2]) < 1e-5
+    assert abs(lyapunov_from_norms(g["lyap_dists"]) - g["feats"][0]) < 1e-9
+    assert abs(fractal_dimension_from_counts(g["box_counts"]) - g["feats"][1]) < 1e-9
+    assert abs(entropy_from_hist(g["hist_counts"]) - g["feats"][2]) < 1e-5
 
 
 def _small_model(g):
