@@ -49,6 +49,8 @@ def lib():
         L.so_box_counts.argtypes = [f32p, C.c_int, C.c_int, C.c_float, i64p]
         L.so_hist256.argtypes = [f32p, C.c_size_t, i64p]
         L.so_encoder_frame.argtypes = [f32p, C.c_int, C.c_int, C.c_int] + [f32p] * 12 + [C.c_void_p, f32p]
+        L.so_encoder_frame_fast.argtypes = [f32p, C.c_int, C.c_int, C.c_int] + [f32p] * 12 + [f32p]
+        L.so_encoder_frame_fast.restype = None
         for fn in ("so_linspace so_add_source so_diffuse so_buoyancy so_divergence so_jacobi so_grad_subtract "
                    "so_project so_bilinear so_advect so_step so_perlin so_mandelbrot_counts so_fractal_field "
                    "so_apply_fractal so_box_counts so_hist256 so_encoder_frame").split():
@@ -233,6 +235,19 @@ def encoder_features(frames, weights, input_dim=128, want_conv1=False):
         lib().so_encoder_frame(frames[b], H, W, input_dim, *ws,
                                c1[b].ctypes.data if want_conv1 else None, out[b])
     return (out, c1) if want_conv1 else out
+
+
+def encoder_features_fast(frames, weights, input_dim=128):
+    """Timing-grade variant of encoder_features (fp32 accumulation, vectorised rows, OpenMP): bench.py's CPU baseline."""
+    frames = _c(frames)
+    B, H, W = frames.shape
+    keys = ["conv1_w", "conv1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
+            "conv2_w", "conv2_b", "bn2_w", "bn2_b", "bn2_mean", "bn2_var"]
+    ws = [_c(weights[k]) for k in keys]
+    out = np.empty((B, 128, 32, 32), np.float32)
+    for b in range(B):
+        lib().so_encoder_frame_fast(frames[b], H, W, input_dim, *ws, out[b])
+    return out
 
 
 def draw_sources(grid_size, rng=np.random):

@@ -210,3 +210,5 @@ def test_encoder_features(golden, N):
     else:
         feats = oracle.encoder_features(frames[-1:], w)         # the dense frame
         assert rel_err(feats, g["features"][-1:]) < 1e-5
+        fast = oracle.encoder_features_fast(frames[-1:], w)     # the timing-grade port bench.py uses as CPU baseline
+        assert rel_err(fast, g["features"][-1:]) < 1e-5
