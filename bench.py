@@ -127,13 +127,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; SMK_BENCH_BACKEND=gloo lets a 1-GPU box rehearse the N>1 control path (ranks share cuda:0)
+    backend = os.environ.get("SMK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from smokephysai_amd.models.encoder import HipEncoder
     from smokephysai_amd.physics import SmokeSimulator
@@ -172,7 +178,7 @@ def main():
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(frame).all() and (feats is None or torch.isfinite(feats).all())
