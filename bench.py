@@ -84,6 +84,20 @@ def cpu_baseline(N, J, weights, budget_frames):
             "reference_on_8_cores_in_build_container": "6.45 frames/s (BASELINE.md: actual reference code, torch CPU/oneDNN)"}
 
 
+def hbm_copy_gbs(dev):
+    """Measured device-copy bandwidth (read + write bytes / time) of a 1 GiB fp32 tensor: the practical HBM ceiling
+    beside the 8 TB/s spec peak used for roofline.frac (MI355X_MICROARCH.md quotes ~6.3 TB/s for a float4 copy)."""
+    a = torch.empty(256 * 1024 * 1024, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        b.copy_(a)
+    torch.cuda.synchronize(dev)
+    return 2 * a.numel() * 4 * 10 / (time.perf_counter() - t0) / 1e9
+
+
 def inference_ms(dev, N, frames, encoder_dtype):
     """Metric M2 (BASELINE.json): SmokePhysNet.forward wall time per frame, eval mode, full 27.8 M-parameter network
     (HIP encoder + PyTorch-ROCm transformer/heads, fp32), device-synchronised, at the reference's batch sizes
@@ -221,6 +235,8 @@ def main():
             for key, kname in (("roofline_stencil", "stencil"), ("roofline_encoder", "encoder")):
                 if key in out and kname in tr:
                     out[key]["traffic"] = tr[kname]
+        if world == 1:
+            out["hbm_copy_measured_GBs"] = hbm_copy_gbs(dev)
         if world == 1 and not args.no_encode and not args.no_inference:
             out["inference_ms_per_frame"] = inference_ms(dev, N, frame, args.encoder_dtype)
         if world == 1 and args.cpu_frames > 0:

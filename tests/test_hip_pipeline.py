@@ -144,3 +144,15 @@ def test_train_step_runs_and_updates(golden):
     opt.step()
     assert torch.isfinite(total) and not torch.equal(w0, model.feature_proj.weight)
     assert abs(float(recon) - g["losses"][1]) / g["losses"][1] < 1e-2    # dropout active: loose
+
+
+def test_train_losses_at_256_pool_the_target():
+    """BASELINE config 4 trains on 256^2 grids; the head emits 128^2 (the reference's loss raises there): the target is
+    block-averaged to the head's resolution."""
+    import train
+    model = SmokePhysNet(input_dim=32, hidden_dim=64, num_layers=1, num_heads=4, output_channels=16).cuda().train()
+    x = torch.rand(2, 1, 256, 256, device="cuda")
+    batch = {"input": x, "target": x.clone(), "chaos_features": torch.zeros(2, 3), "sequence": torch.zeros(2, 20, 8, 8)}
+    total, recon, phys, chaos = train.batch_losses(model, model.physics_regularizer, batch, "cuda")
+    assert torch.isfinite(total)
+    total.backward()

@@ -64,6 +64,11 @@ def batch_losses(model, physics_regularizer, batch, device, chaos_noise=None):
     targets = batch["target"].to(device)
     chaos_targets = batch["chaos_features"].to(device)
     outputs = model(inputs) if chaos_noise is None else model(inputs, chaos_noise=chaos_noise)
+    if targets.shape[-2:] != outputs["reconstructed"].shape[-2:]:
+        # The reconstruction head always emits 128x128 (smokephys_net.py:57-66,117-118), so the reference's own
+        # F.mse_loss raises for any other grid size.  For BASELINE config 4 (256^2 grids) the target is block-averaged
+        # to the head's resolution (2x2 mean at 256^2); at 128^2 this branch is never taken.
+        targets = F.adaptive_avg_pool2d(targets, outputs["reconstructed"].shape[-2:])
     recon_loss = F.mse_loss(outputs["reconstructed"], targets)
     chaos_loss = F.mse_loss(outputs["physics_features"], chaos_targets)
     physics_losses = physics_regularizer({"density": outputs["reconstructed"],
