@@ -57,11 +57,7 @@ int run_stage(smk_sim *sim, int stage, float *frames, int64_t fsb, const float *
         case SMK_STAGE_BUOY_DIFFUSE:   // s -> t (u2, v2, d2)
             return check_launch(launch_buoy_diffuse(g, s, t, st), "buoy_diffuse");
         case SMK_STAGE_PROJECT: {      // on t.u, t.v with s.p
-            int rc = check_launch(launch_divergence(g, t.u, t.v, sim->div, g.pc, g.sc, st), "divergence");
-            if (rc) return rc;
-            rc = check_launch(launch_jacobi(g, s.p, t.p, sim->div, sim->jacobi_iters, st), "jacobi");
-            if (rc) return rc;
-            return check_launch(launch_grad_subtract(g, t.u, t.v, s.p, st), "grad_subtract");
+            return check_launch(launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st), "project");
         }
         case SMK_STAGE_ADVECT_U:       // u <- adv(u2; u2, v2)
             return check_launch(launch_advect(g, 0, t.u, s.u, t.u, t.v, nullptr, 0, nullptr, 0.f, nullptr, nullptr, st),

@@ -196,9 +196,15 @@ __device__ __forceinline__ float wave_shl1(float x) {   // lane i <- lane i+1 (l
 
 constexpr int JB_NW = 16;
 
-template <int VEC, int RPW>
+// MODE bit 0 (FIRST launch of a projection): the divergence of (u, v) is computed here for all tile rows (navier_stokes.py:136,
+//   same expression tree as k_divergence) and stored for the owned rows so that later launches can read it;
+// MODE bit 1 (LAST launch): after the final sweep the gradient subtraction (navier_stokes.py:148-149, as k_grad_subtract)
+//   is applied to the owned rows of u and v from the p held in registers (needs iters <= halo - 1: the row above the
+//   owned range must still be exact).
+template <int VEC, int RPW, int MODE>
 __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float *__restrict__ p_in,
-                                                            float *__restrict__ p_out, const float *__restrict__ div,
+                                                            float *__restrict__ p_out, float *__restrict__ div,
+                                                            float *__restrict__ u, float *__restrict__ v,
                                                             int iters, int BR) {
     constexpr int TR = JB_NW * RPW, ROWF = 64 * VEC;
     __shared__ float edge[2][JB_NW][2][ROWF];
@@ -214,10 +220,33 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
 #pragma unroll
     for (int k = 0; k < RPW; ++k)
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            pv[k][c] = p_in[base + (size_t)k * g.pc + c];
-            dv[k][c] = div[base + (size_t)k * g.pc + c];
+        for (int c = 0; c < VEC; ++c) pv[k][c] = p_in[base + (size_t)k * g.pc + c];
+    if (MODE & 1) {
+        const float *ub = u + b * g.su + (size_t)row0 * g.pc + j0, *vb = v + b * g.sv + (size_t)row0 * g.pv + j0;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            float vr[VEC + 1];
+#pragma unroll
+            for (int c = 0; c <= VEC; ++c) vr[c] = vb[(size_t)k * g.pv + c];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                float a = ub[(size_t)(k + 1) * g.pc + c] - ub[(size_t)k * g.pc + c];
+                a = a + vr[c + 1];
+                a = a - vr[c];
+                dv[k][c] = __fdiv_rn(a, g.dt);
+            }
+            const int gi = row0 + k;
+            if (gi >= own0 && gi < own1) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) div[base + (size_t)k * g.pc + c] = dv[k][c];
+            }
         }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) dv[k][c] = div[base + (size_t)k * g.pc + c];
+    }
     const bool first_col = lane == 0, last_col = lane == 63;
     // ring rows (grid row 0 / H-1) exist only in the first wave of the first band and the last wave of the last band
     const int ring_k = __builtin_amdgcn_readfirstlane(row0 == 0 ? 0 : (row0 + RPW == g.H ? RPW - 1 : -1));   // wave-uniform
@@ -285,6 +314,39 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
             for (int c = 0; c < VEC; ++c) p_out[base + (size_t)k * g.pc + c] = pv[k][c];
         }
     }
+    if (MODE & 2) {
+        // u[i,:] -= dt*(p[i,:] - p[i-1,:]) for 1 <= i <= H-1;  v[:,j] -= dt*(p[:,j] - p[:,j-1]) for 1 <= j <= W-1
+        __syncthreads();                                      // all reads of the last sweep's edges are done
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) edge[0][wave][1][j0 + c] = pv[RPW - 1][c];
+        __syncthreads();
+        float above[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) above[c] = edge[0][wave > 0 ? wave - 1 : 0][1][j0 + c];
+        float *ub = u + b * g.su + (size_t)row0 * g.pc + j0, *vb = v + b * g.sv + (size_t)row0 * g.pv + j0;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int gi = row0 + k;
+            const float lin = wave_shr1(pv[k][VEC - 1]);
+            if (gi >= own0 && gi < own1) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    if (gi >= 1) {                            // gi == row0 == 0 only in the first wave of band 0: skipped
+                        const float pu = k > 0 ? pv[k - 1][c] : above[c];
+                        const float gr = pv[k][c] - pu;
+                        float *cell = ub + (size_t)k * g.pc + c;
+                        *cell = *cell - g.dt * gr;
+                    }
+                    if (!(c == 0 && first_col)) {             // j >= 1 (j <= W-1 always holds here)
+                        const float pl = c > 0 ? pv[k][c - 1] : lin;
+                        const float gr = pv[k][c] - pl;
+                        float *cell = vb + (size_t)k * g.pv + c;
+                        *cell = *cell - g.dt * gr;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // Band plan for the register-resident kernel; false -> use the generic per-sweep kernel.
@@ -322,19 +384,31 @@ static bool plan_jacobi(const Geom &g, JacobiPlan &pl) {
     return ok;
 }
 
-template <int VEC>
-static void launch_band(const Geom &g, const JacobiPlan &pl, const float *pin, float *pout, const float *div, int iters,
-                        hipStream_t st) {
+template <int VEC, int MODE>
+static void launch_band(const Geom &g, const JacobiPlan &pl, const float *pin, float *pout, float *div, float *u, float *v,
+                        int iters, hipStream_t st) {
     dim3 grid(pl.nb, g.B), block(JB_NW * 64);
     switch (pl.rpw) {
-        case 2: hipLaunchKernelGGL((k_jacobi_band<VEC, 2>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
-        case 3: hipLaunchKernelGGL((k_jacobi_band<VEC, 3>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
-        case 4: hipLaunchKernelGGL((k_jacobi_band<VEC, 4>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
-        case 6: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 6>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
-        case 8: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 8>), grid, block, 0, st, g, pin, pout, div, iters, pl.br); break;
+        case 2: hipLaunchKernelGGL((k_jacobi_band<VEC, 2, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
+        case 3: hipLaunchKernelGGL((k_jacobi_band<VEC, 3, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
+        case 4: hipLaunchKernelGGL((k_jacobi_band<VEC, 4, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
+        case 6: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 6, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
+        case 8: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 8, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
     }
 }
 
+template <int MODE>
+static void launch_band_vec(const Geom &g, const JacobiPlan &pl, const float *pin, float *pout, float *div, float *u, float *v,
+                            int iters, hipStream_t st) {
+    switch (pl.vec) {
+        case 1: launch_band<1, MODE>(g, pl, pin, pout, div, u, v, iters, st); break;
+        case 2: launch_band<2, MODE>(g, pl, pin, pout, div, u, v, iters, st); break;
+        case 4: launch_band<4, MODE>(g, pl, pin, pout, div, u, v, iters, st); break;
+        case 8: launch_band<8, MODE>(g, pl, pin, pout, div, u, v, iters, st); break;
+    }
+}
+
+// `iters` Jacobi sweeps on a given divergence field (result in p; p2 scratch).
 hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, int iters, hipStream_t st) {
     if (iters <= 0) return hipSuccess;
     dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B), block(TX, TY);
@@ -347,12 +421,7 @@ hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, i
         int done = 0;
         for (int c = 0; c < L; ++c) {
             const int n = (iters - done + (L - c) - 1) / (L - c);
-            switch (pl.vec) {
-                case 1: launch_band<1>(g, pl, cur, nxt, div, n, st); break;
-                case 2: launch_band<2>(g, pl, cur, nxt, div, n, st); break;
-                case 4: launch_band<4>(g, pl, cur, nxt, div, n, st); break;
-                case 8: launch_band<8>(g, pl, cur, nxt, div, n, st); break;
-            }
+            launch_band_vec<0>(g, pl, cur, nxt, const_cast<float *>(div), nullptr, nullptr, n, st);
             done += n;
             float *t = cur; cur = nxt; nxt = t;
         }
@@ -364,6 +433,33 @@ hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, i
     }
     if (cur != p) hipLaunchKernelGGL(k_copy_cells, grid, block, 0, st, g, cur, p);
     return hipGetLastError();
+}
+
+// pressure_projection (navier_stokes.py:133-149) on (u, v, p): divergence, `iters` Jacobi sweeps, gradient subtraction.
+// With a band plan the divergence is computed inside the first Jacobi launch and the gradient subtraction inside the last.
+hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st) {
+    JacobiPlan pl;
+    const char *nf = getenv("SMK_PROJECT_UNFUSED");
+    if (iters < 2 || !plan_jacobi(g, pl) || pl.halo < 3 || (nf && nf[0] == '1')) {
+        hipError_t e = launch_divergence(g, u, v, div, g.pc, g.sc, st);
+        if (e != hipSuccess) return e;
+        e = launch_jacobi(g, p, p2, div, iters, st);
+        if (e != hipSuccess) return e;
+        return launch_grad_subtract(g, u, v, p, st);
+    }
+    const int cap = pl.halo - 1;                              // the fused gradient needs the row above the owned range exact
+    const int L = 2 * ((iters + 2 * cap - 1) / (2 * cap));
+    float *cur = p, *nxt = p2;
+    int done = 0;
+    for (int c = 0; c < L; ++c) {
+        const int n = (iters - done + (L - c) - 1) / (L - c);
+        if (c == 0) launch_band_vec<1>(g, pl, cur, nxt, div, u, v, n, st);
+        else if (c == L - 1) launch_band_vec<2>(g, pl, cur, nxt, div, u, v, n, st);
+        else launch_band_vec<0>(g, pl, cur, nxt, div, u, v, n, st);
+        done += n;
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    return hipGetLastError();                                 // L is even: the result is back in p
 }
 
 // u[1:-1,:] -= dt*(p[1:]-p[:-1]);  v[:,1:-1] -= dt*(p[:,1:]-p[:,:-1])   (:148-149)
