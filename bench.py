@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # dense peaks (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "i8x3": 5000.0}   # dense peaks (MI355X_MICROARCH.md)
 
 
 def encoder_weights(seed=0):
@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64, help="grids per GPU")
     ap.add_argument("--jacobi", type=int, default=100)
-    ap.add_argument("--encoder-dtype", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--encoder-dtype", default="bf16x3", choices=["f32", "bf16x3", "bf16", "i8x3"])
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
     ap.add_argument("--no-inference", action="store_true", help="skip the per-frame inference-ms measurement (metric M2)")
@@ -211,7 +211,9 @@ def main():
                "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": {"f32": "f32", "bf16x3": "f32 stencil + bf16x3 encoder (split-bf16 MFMA, fp32 accumulate)",
-                         "bf16": "f32 stencil + bf16 encoder"}[args.encoder_dtype], "data": "synthetic",
+                         "bf16": "f32 stencil + bf16 encoder",
+                         "i8x3": "f32 stencil + i8x3 encoder (16-bit fixed point on int8 MFMA, i32 accumulate)"}[args.encoder_dtype],
+               "data": "synthetic",
                "config": {"workload": f"configs[2]: {N}x{N} grid, batch {B} per GPU, Jacobi-{J} project, fractal frame emit, "
                                       f"CNN encoder {args.encoder_dtype} -> [B,128,32,32]",
                           "grid": N, "batch_per_gpu": B, "jacobi_iters": J, "encoder_dtype": args.encoder_dtype,

@@ -131,7 +131,9 @@ int smk_frame_diff_norms(const float *frames, int64_t frame_stride, int32_t n, i
                          void *stream);
 
 /* ------------------------------------------------------------------ CNN encoder */
-typedef enum smk_dtype { SMK_F32 = 0, SMK_BF16X3 = 1, SMK_BF16 = 2 } smk_dtype;
+/* SMK_F32: fp32 MFMA; SMK_BF16X3: split-bf16 MFMA (fp32-class accuracy); SMK_BF16: single-pass bf16;
+ * SMK_I8X3: 16-bit fixed point as two int8 limbs on int8 MFMA (per-tile activation scale, exact i32 accumulation). */
+typedef enum smk_dtype { SMK_F32 = 0, SMK_BF16X3 = 1, SMK_BF16 = 2, SMK_I8X3 = 3 } smk_dtype;
 
 /* Eval-mode input_encoder weights (smokephys_net.py:24-32), device pointers, PyTorch layouts:
  * conv1_w [64][1][7][7], conv2_w [128][64][3][3]; BN as (weight,bias,running_mean,running_var), eps 1e-5. */

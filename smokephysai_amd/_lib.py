@@ -7,9 +7,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmokehip.so")
 
-SMK_F32, SMK_BF16X3, SMK_BF16 = 0, 1, 2
+SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
 STAGE_BUOY_DIFFUSE, STAGE_PROJECT, STAGE_ADVECT_U, STAGE_ADVECT_V, STAGE_ADVECT_D = range(5)
-DTYPES = {"f32": SMK_F32, "fp32": SMK_F32, "float32": SMK_F32, "bf16x3": SMK_BF16X3, "bf16": SMK_BF16}
+DTYPES = {"f32": SMK_F32, "fp32": SMK_F32, "float32": SMK_F32, "bf16x3": SMK_BF16X3, "bf16": SMK_BF16, "i8x3": SMK_I8X3}
 
 
 class SmkSimDesc(C.Structure):

@@ -368,7 +368,7 @@ int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *st
     if (rc) return rc;
     smk_encoder *enc = new smk_encoder();
     enc->device = device_id;
-    const size_t n = 64 * 49 + 64 + 64 + 9 * 64 * 128 + 128 + 128;
+    const size_t n = 64 * 49 + 64 + 64 + 9 * 64 * 128 + 128 + 128 + 128 + 256;
     hipError_t e = hipMalloc((void **)&enc->blob, n * sizeof(float));
     if (e != hipSuccess) {
         delete enc;
@@ -381,8 +381,10 @@ int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *st
     enc->e.s1 = p; p += 64;
     enc->e.t1 = p; p += 64;
     enc->e.s2 = p; p += 128;
-    enc->e.t2 = p;
-    const size_t n16 = 2 * 64 * 64 + 36 * 2 * 128 * 16;
+    enc->e.t2 = p; p += 128;
+    enc->e.sw2 = p; p += 128;
+    enc->e.wsum = reinterpret_cast<int *>(p);
+    const size_t n16 = 2 * 64 * 64 + 36 * 2 * 128 * 16 + 18 * 2 * 128 * 32 / 2;   // + int8 limbs (bytes / 2)
     e = hipMalloc((void **)&enc->blob16, n16 * sizeof(unsigned short));
     if (e != hipSuccess) {
         smk_encoder_destroy(enc);
@@ -391,6 +393,7 @@ int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *st
     }
     enc->e.w2q = enc->blob16;                       // 16-byte aligned rows first
     enc->e.w1p = enc->blob16 + 36 * 2 * 128 * 16;
+    enc->e.w2i = reinterpret_cast<signed char *>(enc->blob16 + 36 * 2 * 128 * 16 + 2 * 64 * 64);
     rc = check_launch(launch_fold_weights(*w, enc->e, (hipStream_t)stream), "fold_weights");
     if (rc) { smk_encoder_destroy(enc); return rc; }
     *out = enc;
@@ -432,6 +435,9 @@ int smk_encoder_forward(smk_encoder *enc, const float *frames, int64_t frame_str
     if (dtype == SMK_BF16X3 || dtype == SMK_BF16)
         return check_launch(launch_encoder_bf16(frames, frame_stride, B, H, W, enc->e, features, dtype == SMK_BF16X3, false,
                                                 (hipStream_t)stream), "encoder_bf16");
+    if (dtype == SMK_I8X3)
+        return check_launch(launch_encoder_i8(frames, frame_stride, B, H, W, enc->e, features, false, (hipStream_t)stream),
+                            "encoder_i8");
     set_error("unknown encoder dtype");
     return SMK_ERR_INVALID;
 }
@@ -444,8 +450,11 @@ int smk_encoder_forward_tokens(smk_encoder *enc, const float *frames, int64_t fr
     if (rc) return rc;
     rc = set_device(enc->device);
     if (rc) return rc;
+    if (dtype == SMK_I8X3)
+        return check_launch(launch_encoder_i8(frames, frame_stride, B, H, W, enc->e, tokens, true, (hipStream_t)stream),
+                            "encoder_i8_tokens");
     if (dtype != SMK_BF16X3 && dtype != SMK_BF16) {
-        set_error("token-major output is built for the bf16 MFMA kernels (SMK_BF16X3, SMK_BF16)");
+        set_error("token-major output is built for the MFMA kernels SMK_BF16X3, SMK_BF16, SMK_I8X3");
         return SMK_ERR_UNSUPPORTED;
     }
     return check_launch(launch_encoder_bf16(frames, frame_stride, B, H, W, enc->e, tokens, dtype == SMK_BF16X3, true,

@@ -11,6 +11,9 @@ struct EncoderDev {
     float *s2, *t2;   // [128]
     // split-bf16 copies for the bf16 MFMA kernels (value = hi + lo, each a bf16):
     unsigned short *w1p;   // [2 hi/lo][64 ch][64 k], k = 8*ki + kj (ki = 7 or kj = 7: zero)
+    signed char *w2i;      // [18 k-steps = tap*2 + c/32][2 limbs h|l][128 o][32 c] int8: w = sw2[o] * (256 h + l)
+    float *sw2;            // [128] per-output-channel weight scale of the int8 limbs
+    int *wsum;             // [2][128] 128 * sum_k of the h / l weight limbs (offset correction of the unsigned activations)
     unsigned short *w2q;   // [36 k-steps = tap*4 + c/16][2 hi/lo][128 o][16 c]  (B fragments, 1 KiB per wave load)
 };
 
@@ -24,5 +27,9 @@ hipError_t launch_encoder_f32(const float *frames, int64_t fstride, int B, int H
 // tokens = true: features written token-major [B][32*32][128] (coalesced; the layout feature_proj consumes).
 hipError_t launch_encoder_bf16(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
                                float *features, bool x3, bool tokens, hipStream_t st);
+
+// int8 two-limb fixed point (activations scaled per tile, weights per output channel), exact i32 accumulation.
+hipError_t launch_encoder_i8(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
+                             float *features, bool tokens, hipStream_t st);
 
 }  // namespace smk

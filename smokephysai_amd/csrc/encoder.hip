@@ -61,7 +61,41 @@ __global__ void k_fold_weights(smk_encoder_weights w, EncoderDev e) {
     }
 }
 
+// conv2 weights as two balanced int8 limbs per output channel: w ~= sw2[o] * (256*h + l), |256h + l| <= 32512.
+__global__ __launch_bounds__(256) void k_quant_w2(smk_encoder_weights w, EncoderDev e) {
+    __shared__ float red[256];
+    __shared__ int sh_h, sh_l;
+    const int o = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { sh_h = 0; sh_l = 0; }
+    float m = 0.f;
+    for (int k = tid; k < 576; k += 256) m = fmaxf(m, fabsf(w.conv2_w[(size_t)o * 576 + k]));
+    red[tid] = m;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if (tid < sft) red[tid] = fmaxf(red[tid], red[tid + sft]);
+        __syncthreads();
+    }
+    const float wmax = red[0];
+    const float sw = wmax > 0.f ? wmax / 32512.0f : 1.0f;
+    if (tid == 0) e.sw2[o] = sw;
+    int sum_h = 0, sum_l = 0;
+    for (int k = tid; k < 576; k += 256) {
+        const int c = k / 9, tap = k - 9 * c;                      // conv2_w [o][c][3][3]
+        const int q = (int)rintf(w.conv2_w[(size_t)o * 576 + k] / sw);
+        const int h = (q + 128) >> 8, l = q - (h << 8);              // arithmetic shift = floor: l in [-128, 127]
+        const int ks = tap * 2 + (c >> 5), cc = c & 31;
+        e.w2i[((size_t)(ks * 2 + 0) * 128 + o) * 32 + cc] = (signed char)h;
+        e.w2i[((size_t)(ks * 2 + 1) * 128 + o) * 32 + cc] = (signed char)l;
+        sum_h += h; sum_l += l;
+    }
+    atomicAdd(&sh_h, sum_h);
+    atomicAdd(&sh_l, sum_l);
+    __syncthreads();
+    if (tid == 0) { e.wsum[o] = 128 * sh_h; e.wsum[128 + o] = 128 * sh_l; }
+}
+
 hipError_t launch_fold_weights(const smk_encoder_weights &w, const EncoderDev &e, hipStream_t st) {
+    hipLaunchKernelGGL(k_quant_w2, dim3(128), dim3(256), 0, st, w, e);
     int n = 9 * 64 * 128;    // largest of the index spaces above
     hipLaunchKernelGGL(k_fold_weights, dim3((n + 255) / 256), dim3(256), 0, st, w, e);
     return hipGetLastError();
@@ -627,6 +661,364 @@ hipError_t launch_encoder_bf16(const float *frames, int64_t fstride, int B, int 
                           : launch_bf16_t<true, false>(frames, fstride, B, H, W, e, features, st);
     return tokens ? launch_bf16_t<false, true>(frames, fstride, B, H, W, e, features, st)
                   : launch_bf16_t<false, false>(frames, fstride, B, H, W, e, features, st);
+}
+
+// ---------------------------------------------------------------- fused encoder, int8 fixed-point MFMA ("i8x3")
+// conv1 as in the split-bf16 kernel; its fp32 outputs stay in registers until the tile's maximum is known, then every
+// a1 value (>= 0 after the ReLU) is quantised to UNSIGNED 16-bit fixed point with the TILE's scale,
+// q = rint(y * 65024 / max) = 256 (h + 128) + l with int8 limbs h, l in [-128, 127]; the offset is undone exactly in the
+// epilogue by adding 128 * sum_k w[o][k] (precomputed integers) to the accumulators.  Limbs are stored as
+// [halo row][pixel][64 ch] bytes (pixel pitch 80 B, row pitch 1472 B: conflict-free b128 reads).
+// conv2 runs on v_mfma_i32_32x32x32_i8 (2x the bf16 rate, K = 32 channels per instruction) with EXACT i32 accumulation
+// in two weight classes: acc_hh += ah*wh (x 2^16), acc_mid += ah*wl + al*wh (x 2^8); the l*l class (2^-16 relative) is
+// dropped.  Result = ((hh + Ch[o])*65536 + (mid + Cl[o])*256) * s_tile * sw2[o].  216 MFMAs per wave-tile instead of 432, half the LDS and
+// L2 operand bytes.  Accuracy is fixed-point (absolute error ~ tile max * 2^-16): features within 1e-4 of the reference
+// on every fixture (2e-5 .. 7e-5), tighter than bf16 but looser than bf16x3 (3e-6) -- opt-in.
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int I8_A1_PITCH = 80;                           // bytes per halo pixel: 64 ch + 16 pad (5 x 16 B: odd)
+constexpr int I8_A1_ROW = B3_AW * I8_A1_PITCH + 32;       // 1472 B: 4 rows = 368 x 16 B = 0 mod 16 units
+constexpr int I8_A1_BYTES = (B3_TH + 2) * I8_A1_ROW;      // 14720 per limb
+constexpr int I8_LDS_BYTES = B3_XS_BYTES + 2 * I8_A1_BYTES + 2 * B3_W1_BYTES + B3_ST_BYTES + 64;   // ~50.2 KB
+
+template <int PS, bool TOKENS>
+__global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__ frames, int64_t fstride, int H, int W,
+                                                    EncoderDev e, float *__restrict__ features, int lg_tiles_x,
+                                                    int lg_tiles_per_frame, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    unsigned char *a1h = smem + B3_XS_BYTES, *a1l = a1h + I8_A1_BYTES;
+    unsigned char *w1s = a1l + I8_A1_BYTES;
+    float *st1 = reinterpret_cast<float *>(w1s + 2 * B3_W1_BYTES);
+    float *wmx = st1 + 128;                                 // per-wave maxima (4 floats) + padding
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (tid < 128) st1[tid] = tid < 64 ? e.s1[tid] : e.t1[tid - 64];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(e.w1p);
+        for (int c = tid; c < 2 * 64 * 8; c += 256) {
+            const int row = c >> 3, u = c & 7;
+            *reinterpret_cast<uint4 *>(w1s + row * B3_W1_PITCH + u * 16) = src[c];
+        }
+    }
+    const int o = wave * 32 + r;
+    const float t2 = e.t2[o];
+    const float scale_o = e.sw2[o] * e.s2[o];               // weight scale x BN2 scale (tile scale multiplies in later)
+    const int corr_h = e.wsum[o], corr_l = e.wsum[128 + o];   // 128 * sum of the weight limbs: undoes the activation offset
+    const int lane_b = (o * 2 + hi) * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char *>(e.w2i), 0, 18 * 2 * 4096, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto load_b = [&](int kn, int part) -> i32x4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (kn * 2 + part) * 4096, 0);
+        return __builtin_bit_cast(i32x4, v);
+    };
+    constexpr int RING = 3;
+    i32x4 bqh[RING], bql[RING];
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k) {
+        bqh[k] = load_b(k, 0);
+        bql[k] = load_b(k, 1);
+    }
+    const int lane_off = (r >> 4) * 4 * I8_A1_ROW + (r & 15) * I8_A1_PITCH + 16 * hi;
+
+    auto x_fetch = [&](int t, int k) -> float {
+        if (k >= B3_XH * B3_XW) return 0.f;
+        const int bb = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);
+        const int rr0 = (rem >> lg_tiles_x) * B3_TH, cc0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
+        const int row = k / B3_XW, col = k - row * B3_XW;
+        const int ii = rr0 - 4 + row, jj = cc0 - 4 + col;
+        const bool ok = row < B3_XH - 1 && col < B3_XW - 1 && ii >= 0 && ii < H && jj >= 0 && jj < W;
+        return ok ? frames[(size_t)bb * fstride + (size_t)ii * W + jj] : 0.f;
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) {
+        xs[tid] = x_fetch(t, tid);
+        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = x_fetch(t, tid + 256);
+    }
+    __syncthreads();
+
+    for (; t < ntiles; t += gridDim.x) {
+        const int b = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);
+        const int r0 = (rem >> lg_tiles_x) * B3_TH, c0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
+
+        // ---- conv1 (split-bf16 MFMA): 3 (pixel block, channel block) units per wave, fp32 results kept in registers
+        float yv[3][16];
+        int aoffs[2];
+        bool valids[2];
+        float vmax = 0.f;
+        auto x_frags = [&](int pb, bf16x8 (&xh)[4], bf16x8 (&xl)[4], int &aoff, bool &valid, bool &inimg) {
+            const int pix = pb * 32 + r;
+            valid = pix < B3_APIX;
+            const int pc = valid ? pix : B3_APIX - 1;
+            const int ar = pc / B3_AW, ac = pc - ar * B3_AW;
+            const int ii = r0 - 1 + ar, jj = c0 - 1 + ac;
+            inimg = valid && ii >= 0 && ii < H && jj >= 0 && jj < W;
+            aoff = ar * I8_A1_ROW + ac * I8_A1_PITCH;
+            const float *xp = xs + (ar + hi) * B3_XW + ac;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 vh, vl;
+                    split_bf16(xp[s * 2 * B3_XW + j], vh, vl);
+                    xh[s][j] = vh; xl[s][j] = vl;
+                }
+        };
+        auto bn1 = [&](const f32x16 &acc, int cb, bool inimg, float (&y)[16]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch0 = cb * 32 + 8 * q + 4 * hi;
+                const float4 sc = *reinterpret_cast<const float4 *>(st1 + ch0);
+                const float4 sh = *reinterpret_cast<const float4 *>(st1 + 64 + ch0);
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = inimg ? bn_relu(acc[4 * q + i], scv[i], shv[i]) : 0.f;
+                    y[4 * q + i] = v;
+                    vmax = fmaxf(vmax, v);
+                }
+            }
+        };
+        {
+            bf16x8 xh[4], xl[4];
+            bool inimg;
+            x_frags(wave, xh, xl, aoffs[0], valids[0], inimg);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { acc0[g] = 0.f; acc1[g] = 0.f; }
+            const unsigned char *wrow = w1s + r * B3_W1_PITCH + 8 * hi * 2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(wrow + s * 32);
+                const bf16x8 a1hh = *reinterpret_cast<const bf16x8 *>(wrow + 32 * B3_W1_PITCH + s * 32);
+                const bf16x8 a0l = *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + s * 32);
+                const bf16x8 a1l_ = *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + 32 * B3_W1_PITCH + s * 32);
+                mma3<true>(acc0, a0h, a0l, xh[s], xl[s]);
+                mma3<true>(acc1, a1hh, a1l_, xh[s], xl[s]);
+            }
+            bn1(acc0, 0, inimg, yv[0]);
+            bn1(acc1, 1, inimg, yv[1]);
+        }
+        const int cbs = wave & 1;
+        {
+            bf16x8 xh[4], xl[4];
+            bool inimg;
+            x_frags(4 + (wave >> 1), xh, xl, aoffs[1], valids[1], inimg);
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            const unsigned char *wrow = w1s + (cbs * 32 + r) * B3_W1_PITCH + 8 * hi * 2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(wrow + s * 32);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + s * 32);
+                mma3<true>(acc, ah, al, xh[s], xl[s]);
+            }
+            bn1(acc, cbs, inimg, yv[2]);
+        }
+        // ---- tile maximum -> fixed-point scale
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        if (lane == 0) wmx[wave] = vmax;
+        __syncthreads();
+        const float tmax = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+        const float inv = tmax > 0.f ? 65024.0f / tmax : 0.f;
+        const float s_tile = tmax > 0.f ? tmax / 65024.0f : 0.f;
+        auto quant_store = [&](const float (&y)[16], int cb, int aoff, bool valid) {
+            if (!valid) return;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch0 = cb * 32 + 8 * q + 4 * hi;
+                unsigned int ph = 0, pl = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int qv = (int)rintf(y[4 * q + i] * inv);        // 0 .. 65024
+                    const int hu = (qv + 128) >> 8, l = qv - (hu << 8);     // hu 0..254, l -128..127
+                    const int h = hu - 128;                                 // stored limb: -128..126
+                    ph |= (unsigned int)(h & 255) << (8 * i);
+                    pl |= (unsigned int)(l & 255) << (8 * i);
+                }
+                *reinterpret_cast<unsigned int *>(a1h + aoff + ch0) = ph;
+                *reinterpret_cast<unsigned int *>(a1l + aoff + ch0) = pl;
+            }
+        };
+        quant_store(yv[0], 0, aoffs[0], valids[0]);
+        quant_store(yv[1], 1, aoffs[0], valids[0]);
+        quant_store(yv[2], cbs, aoffs[1], valids[1]);
+        __syncthreads();                                      // a1 limbs complete; xs is free again
+
+        const int tn = t + gridDim.x;
+        float xr0 = 0.f, xr1 = 0.f;
+        if (tn < ntiles) {
+            xr0 = x_fetch(tn, tid);
+            xr1 = x_fetch(tn, tid + 256);
+        }
+
+        // ---- conv2 on int8 MFMA: 18 k-steps (tap, channel half) x 4 M blocks x 3 limb products
+        i32x16 hh[4], mid[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { hh[mi][g] = 0; mid[mi][g] = 0; }
+        auto load_a = [&](int k, int pair, i32x4 (&ah)[2], i32x4 (&al)[2]) {
+            const int tap = k >> 1, half = k & 1, ki = tap / 3, kj = tap - 3 * ki;
+            const int abase = lane_off + ki * I8_A1_ROW + kj * I8_A1_PITCH + half * 32 + pair * 2 * I8_A1_ROW;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = *reinterpret_cast<const i32x4 *>(a1h + abase + m * I8_A1_ROW);
+                al[m] = *reinterpret_cast<const i32x4 *>(a1l + abase + m * I8_A1_ROW);
+            }
+        };
+        i32x4 ahA[2], alA[2], ahB[2], alB[2];
+        load_a(0, 0, ahA, alA);
+#pragma unroll 1
+        for (int k0 = 0; k0 < 18; k0 += 6) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int k = k0 + u;
+                {
+                    int kn = k + RING - 1;
+                    kn = kn >= 18 ? kn - 18 : kn;
+                    kn = __builtin_amdgcn_readfirstlane(kn);
+                    bqh[(u + RING - 1) % RING] = load_b(kn, 0);
+                    bql[(u + RING - 1) % RING] = load_b(kn, 1);
+                }
+                const i32x4 bh = bqh[u % RING], bl = bql[u % RING];
+                // half-step 0: M blocks 0,1 from buffer A while buffer B loads M blocks 2,3 of this k-step
+                load_a(k, 1, ahB, alB);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    mid[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(alA[m], bh, mid[m], 0, 0, 0);
+                    mid[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahA[m], bl, mid[m], 0, 0, 0);
+                    hh[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahA[m], bh, hh[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // half-step 1: M blocks 2,3 from buffer B while buffer A loads M blocks 0,1 of the next k-step
+                if (k + 1 < 18) load_a(k + 1, 0, ahA, alA);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    mid[2 + m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(alB[m], bh, mid[2 + m], 0, 0, 0);
+                    mid[2 + m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahB[m], bl, mid[2 + m], 0, 0, 0);
+                    hh[2 + m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahB[m], bh, hh[2 + m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue: (hh*2^16 + mid*2^8) * s_tile * sw2[o] -> BN2 + ReLU + block mean
+        const float sc = s_tile * scale_o;
+        auto val = [&](int mi, int g) -> float {
+            const float v = fmaf((float)(hh[mi][g] + corr_h), 65536.0f, (float)(mid[mi][g] + corr_l) * 256.0f);
+            const float y = fmaf(v, sc, t2);
+            return y > 0.f ? y : 0.f;
+        };
+        auto out_index = [&](int pi, int pj) -> size_t {
+            return TOKENS ? ((size_t)b * 1024 + pi * 32 + pj) * 128 + o : ((size_t)b * 128 + o) * 1024 + pi * 32 + pj;
+        };
+        if (PS == 2) {
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp)
+#pragma unroll
+                for (int qr = 0; qr < 2; ++qr)
+#pragma unroll
+                    for (int qc = 0; qc < 2; ++qc)
+#pragma unroll
+                        for (int cg = 0; cg < 2; ++cg) {
+                            float sum = 0.f;
+#pragma unroll
+                            for (int mi = 2 * mp; mi < 2 * mp + 2; ++mi)
+#pragma unroll
+                                for (int i = 2 * cg; i < 2 * cg + 2; ++i) sum += val(mi, 4 * (2 * qr + qc) + i);
+                            features[out_index((r0 + 2 * mp + 4 * qr) / 2, (c0 + 8 * qc + 4 * hi + 2 * cg) / 2)] = sum * 0.25f;
+                        }
+        } else if (PS == 4) {
+#pragma unroll
+            for (int qr = 0; qr < 2; ++qr)
+#pragma unroll
+                for (int qc = 0; qc < 2; ++qc) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += val(mi, 4 * (2 * qr + qc) + i);
+                    features[out_index((r0 + 4 * qr) / 4, (c0 + 8 * qc + 4 * hi) / 4)] = sum * (1.0f / 16);
+                }
+        } else {
+            float cell[2];
+#pragma unroll
+            for (int qc = 0; qc < 2; ++qc) {
+                float sum = 0.f;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int qr = 0; qr < 2; ++qr)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += val(mi, 4 * (2 * qr + qc) + i);
+                cell[qc] = sum;
+            }
+            const float other0 = __shfl_xor(cell[0], 32), other1 = __shfl_xor(cell[1], 32);
+            const float total = hi == 0 ? cell[0] + other0 : cell[1] + other1;
+            features[out_index(r0 / 8, c0 / 8 + hi)] = total * (1.0f / 64);
+        }
+
+        xs[tid] = xr0;
+        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = xr1;
+        __syncthreads();
+    }
+}
+
+template <bool TOKENS>
+static hipError_t launch_i8_t(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e, float *features,
+                              hipStream_t st) {
+    const int PS = H / 32;
+    const int tiles_x = W / B3_TW, tiles_per_frame = tiles_x * (H / B3_TH), ntiles = tiles_per_frame * B;
+    int lg_tx = 0, lg_tpf = 0;
+    while ((1 << lg_tx) < tiles_x) ++lg_tx;
+    while ((1 << lg_tpf) < tiles_per_frame) ++lg_tpf;
+    if ((1 << lg_tx) != tiles_x || (1 << lg_tpf) != tiles_per_frame) return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = I8_LDS_BYTES;
+    static int wgs_per_cu = 0, num_cu = 0;
+    if (!wgs_per_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        num_cu = prop.multiProcessorCount;
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_encoder_i8<8, TOKENS>, 256, lds_bytes) != hipSuccess || n < 1) n = 2;
+        const char *ov = getenv("SMK_ENC_WGS_PER_CU");
+        if (ov && atoi(ov) > 0) n = atoi(ov);
+        wgs_per_cu = n;
+    }
+    int nwg = num_cu * wgs_per_cu;
+    if (nwg > ntiles) nwg = ntiles;
+    dim3 grid(nwg), block(256);
+    switch (PS) {
+        case 2: hipLaunchKernelGGL((k_encoder_i8<2, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles); break;
+        case 4: hipLaunchKernelGGL((k_encoder_i8<4, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles); break;
+        case 8: hipLaunchKernelGGL((k_encoder_i8<8, TOKENS>), grid, block, lds_bytes, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_encoder_i8(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e, float *features,
+                             bool tokens, hipStream_t st) {
+    return tokens ? launch_i8_t<true>(frames, fstride, B, H, W, e, features, st)
+                  : launch_i8_t<false>(frames, fstride, B, H, W, e, features, st);
 }
 
 }  // namespace smk

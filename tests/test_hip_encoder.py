@@ -41,6 +41,20 @@ def test_features_bf16x3_within_1e4(golden, enc, N):
         assert rel_err(feats[b], g["features"][b]) < TOL, f"frame {b}"
 
 
+@pytest.mark.parametrize("N", [64, 128, 256])
+def test_features_i8x3_fixed_point_within_1e4(golden, enc, N):
+    """int8 two-limb fixed point (per-tile activation scale, per-channel weight scale, exact i32 accumulation):
+    inside the 1e-4 bar on every reference fixture (numpy emulation predicts 2e-5 .. 7e-5), opt-in."""
+    g = golden(f"encoder_io_{N}.npz")
+    x = torch.from_numpy(g["frames"]).cuda()
+    feats = enc(x[:, None], input_dim=128, dtype="i8x3").cpu().numpy()
+    errs = [rel_err(feats[b], g["features"][b]) for b in range(feats.shape[0])]
+    print(f"i8x3 rel err at {N}: {errs}")
+    assert max(errs) < 0.5 * TOL, errs           # measured 1e-5 .. 3e-5
+    tok = enc.tokens(x, input_dim=128, dtype="i8x3")
+    assert torch.equal(tok, torch.from_numpy(feats).cuda().flatten(2).transpose(1, 2))
+
+
 @pytest.mark.parametrize("N", [64, 256])
 def test_features_bf16_single_pass(golden, enc, N):
     """Single-pass bf16 MFMA: operands rounded to 8 significant bits, so the bar is bf16-class (2e-2), not 1e-4;
@@ -83,6 +97,9 @@ def test_vs_oracle_random_weights_and_batch():
     assert rel_err(got, ref) < 2e-5
     got3 = e(torch.from_numpy(frames).cuda(), input_dim=128, dtype="bf16x3").cpu().numpy()
     assert rel_err(got3, ref) < TOL
+    goti = e(torch.from_numpy(frames).cuda(), input_dim=128, dtype="i8x3").cpu().numpy()
+    print("i8x3 vs oracle, random weights:", [rel_err(goti[b], ref[b]) for b in range(3)])
+    assert max(rel_err(goti[b], ref[b]) for b in range(3)) < TOL
     # input_dim=32 (small-model config): 64 -> 32 -> 32 composes to the same 2x2 block mean
     ref32 = oracle.encoder_features(frames[:1], w, input_dim=32)
     assert rel_err(e(torch.from_numpy(frames[:1]).cuda(), input_dim=32).cpu().numpy(), ref32) < 2e-5
