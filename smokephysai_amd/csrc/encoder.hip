@@ -740,7 +740,9 @@ __global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__
     }
     __syncthreads();
 
+    // [stamp:begin]
     for (; t < ntiles; t += gridDim.x) {
+        // [stamp:T0]
         const int b = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);
         const int r0 = (rem >> lg_tiles_x) * B3_TH, c0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
 
@@ -767,7 +769,9 @@ __global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__
                     xh[s][j] = vh; xl[s][j] = vl;
                 }
         };
+        bool inimgs[2];
         auto bn1 = [&](const f32x16 &acc, int cb, bool inimg, float (&y)[16]) {
+            float umax = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ch0 = cb * 32 + 8 * q + 4 * hi;
@@ -776,16 +780,18 @@ __global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__
                 const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v = inimg ? bn_relu(acc[4 * q + i], scv[i], shv[i]) : 0.f;
+                    const float v = bn_relu(acc[4 * q + i], scv[i], shv[i]);
                     y[4 * q + i] = v;
-                    vmax = fmaxf(vmax, v);
+                    umax = fmaxf(umax, v);
                 }
             }
+            vmax = fmaxf(vmax, inimg ? umax : 0.f);           // pixels outside the image are conv2's zero padding
         };
         {
             bf16x8 xh[4], xl[4];
             bool inimg;
             x_frags(wave, xh, xl, aoffs[0], valids[0], inimg);
+            inimgs[0] = inimg;
             f32x16 acc0, acc1;
 #pragma unroll
             for (int g = 0; g < 16; ++g) { acc0[g] = 0.f; acc1[g] = 0.f; }
@@ -807,6 +813,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__
             bf16x8 xh[4], xl[4];
             bool inimg;
             x_frags(4 + (wave >> 1), xh, xl, aoffs[1], valids[1], inimg);
+            inimgs[1] = inimg;
             f32x16 acc;
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[g] = 0.f;
@@ -819,36 +826,42 @@ __global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__
             }
             bn1(acc, cbs, inimg, yv[2]);
         }
+        // [stamp:T1]
         // ---- tile maximum -> fixed-point scale
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
         if (lane == 0) wmx[wave] = vmax;
         __syncthreads();
+        // [stamp:T2]
         const float tmax = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
-        const float inv = tmax > 0.f ? 65024.0f / tmax : 0.f;
+        // q' = rint(y * 65024 / max) + 128 as packed u16 (v_cvt_pknorm_u16_f32: round(x * 65535) of x in [0,1]);
+        // q' = 256 hu + lo, stored limbs h = hu - 128 and l = lo - 128 are the bytes XOR 0x80 (v_perm_b32 gathers them)
+        const float invn = tmax > 0.f ? 65024.0f / (tmax * 65535.0f) : 0.f;
         const float s_tile = tmax > 0.f ? tmax / 65024.0f : 0.f;
-        auto quant_store = [&](const float (&y)[16], int cb, int aoff, bool valid) {
+        constexpr float OFFN = 128.0f / 65535.0f;
+        auto quant_store = [&](const float (&y)[16], int cb, int aoff, bool valid, bool inimg) {
             if (!valid) return;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ch0 = cb * 32 + 8 * q + 4 * hi;
-                unsigned int ph = 0, pl = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int qv = (int)rintf(y[4 * q + i] * inv);        // 0 .. 65024
-                    const int hu = (qv + 128) >> 8, l = qv - (hu << 8);     // hu 0..254, l -128..127
-                    const int h = hu - 128;                                 // stored limb: -128..126
-                    ph |= (unsigned int)(h & 255) << (8 * i);
-                    pl |= (unsigned int)(l & 255) << (8 * i);
-                }
+                const unsigned int d0 = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(
+                    fmaf(y[4 * q + 0], invn, OFFN), fmaf(y[4 * q + 1], invn, OFFN)));
+                const unsigned int d1 = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(
+                    fmaf(y[4 * q + 2], invn, OFFN), fmaf(y[4 * q + 3], invn, OFFN)));
+                unsigned int ph = __builtin_amdgcn_perm(d1, d0, 0x07050301) ^ 0x80808080u;   // high bytes of the 4 u16
+                unsigned int pl = __builtin_amdgcn_perm(d1, d0, 0x06040200) ^ 0x80808080u;   // low bytes
+                ph = inimg ? ph : 0x80808080u;                                               // q = 0 (zero padding)
+                pl = inimg ? pl : 0u;
                 *reinterpret_cast<unsigned int *>(a1h + aoff + ch0) = ph;
                 *reinterpret_cast<unsigned int *>(a1l + aoff + ch0) = pl;
             }
         };
-        quant_store(yv[0], 0, aoffs[0], valids[0]);
-        quant_store(yv[1], 1, aoffs[0], valids[0]);
-        quant_store(yv[2], cbs, aoffs[1], valids[1]);
+        quant_store(yv[0], 0, aoffs[0], valids[0], inimgs[0]);
+        quant_store(yv[1], 1, aoffs[0], valids[0], inimgs[0]);
+        quant_store(yv[2], cbs, aoffs[1], valids[1], inimgs[1]);
+        // [stamp:T3]
         __syncthreads();                                      // a1 limbs complete; xs is free again
+        // [stamp:T4]
 
         const int tn = t + gridDim.x;
         float xr0 = 0.f, xr1 = 0.f;
@@ -862,7 +875,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { hh[mi][g] = 0; mid[mi][g] = 0; }
+            for (int g = 0; g < 16; ++g) { hh[mi][g] = corr_h; mid[mi][g] = corr_l; }   // offset correction pre-added
         auto load_a = [&](int k, int pair, i32x4 (&ah)[2], i32x4 (&al)[2]) {
             const int tap = k >> 1, half = k & 1, ki = tap / 3, kj = tap - 3 * ki;
             const int abase = lane_off + ki * I8_A1_ROW + kj * I8_A1_PITCH + half * 32 + pair * 2 * I8_A1_ROW;
@@ -919,10 +932,11 @@ __global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__
             }
         }
 
+        // [stamp:T5]
         // ---- epilogue: (hh*2^16 + mid*2^8) * s_tile * sw2[o] -> BN2 + ReLU + block mean
-        const float sc = s_tile * scale_o;
+        const float sc = s_tile * scale_o * 256.0f;
         auto val = [&](int mi, int g) -> float {
-            const float v = fmaf((float)(hh[mi][g] + corr_h), 65536.0f, (float)(mid[mi][g] + corr_l) * 256.0f);
+            const float v = fmaf((float)hh[mi][g], 256.0f, (float)mid[mi][g]);        // (hh*2^16 + mid*2^8) / 2^8
             const float y = fmaf(v, sc, t2);
             return y > 0.f ? y : 0.f;
         };
@@ -977,8 +991,12 @@ __global__ __launch_bounds__(256, 2) void k_encoder_i8(const float *__restrict__
 
         xs[tid] = xr0;
         if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = xr1;
+        // [stamp:T6]
         __syncthreads();
+        // [stamp:T7]
+        // [stamp:accumulate]
     }
+    // [stamp:end]
 }
 
 template <bool TOKENS>

@@ -87,7 +87,7 @@ def _load_small(g):
     return model.cuda().eval()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("i8x3", 1e-4)])
 def test_small_model_forward_vs_reference(golden, dtype, tol):
     """Full forward (HIP encoder -> transformer with the chaos term folded into Q -> heads) with the reference's own
     chaos-noise draws injected: all four outputs within 1e-4 relative."""
