@@ -5,12 +5,15 @@
 // scale/shift; for H a multiple of 32 and input_dim a multiple/divisor of H the two adaptive pools compose to an
 // (H/32)^2 block mean.
 //
-// Tiling (one workgroup = 512 threads = 8 waves, one wave per output row of the tile):
-//   output tile 8 rows x 32 cols x 128 channels;  a1 (conv1 activations) for the 10 x 34 halo tile x 64 channels is
-//   computed on the fly into LDS (never touches HBM); conv2 is an implicit GEMM  D[pixel][o] = sum_k A[pixel][k] B[k][o]
-//   with k = (tap, channel): A fragments are shifted reads of the LDS a1 tile (no im2col), B = conv2 weights re-laid out
-//   [tap][c][o] and streamed tap by tap through a double-buffered LDS stage.
-//   fp32 path: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain).
+// Nothing but the frame is read from HBM and nothing but the pooled features is written: the conv1 activations of a
+// tile (+1 halo) live only in LDS, conv2 is an implicit GEMM  D[pixel][o] = sum_k A[pixel][k] B[k][o]  with
+// k = (tap, channel) whose A fragments are shifted reads of that LDS tile (no im2col), BN2 + ReLU + the block-mean pool
+// run in the epilogue.  Three kernels, one per arithmetic:
+//   k_encoder_f32   tile 8x32, 512 threads; conv1 on VALU, conv2 on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain),
+//                   weights [tap][c][o] double-buffered through LDS.
+//   k_encoder_bf16  persistent, tile 8x16, 256 threads; both convs on v_mfma_f32_32x32x16_bf16; X3 = split-bf16
+//                   (hi*hi + hi*lo + lo*hi: fp32-class accuracy), weights as register fragments straight from L2.
+//   k_encoder_i8    same structure; conv2 on v_mfma_i32_32x32x32_i8 with 16-bit fixed-point operands as two int8 limbs.
 #include "encoder.h"
 
 #include <stdlib.h>
