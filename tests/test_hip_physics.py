@@ -177,3 +177,44 @@ def test_full_size_properties():
     np.testing.assert_array_equal(ns.density[5].cpu().numpy(), o.ns_solver.density)
     np.testing.assert_array_equal(ns.p[5].cpu().numpy(), o.ns_solver.p)
     np.testing.assert_array_equal(ns.u[5].cpu().numpy(), o.ns_solver.u)
+
+
+def test_abi_error_paths_return_status_and_message():
+    """Bad arguments come back as negative smk_status + smk_last_error text (no crash, no silent fallback)."""
+    import ctypes as C
+    L = _lib.load()
+    ns = NavierStokesSimulator((32, 32), batch_size=2)
+    st = _lib.stream_ptr(ns._dev)
+    # unknown stage
+    assert L.smk_sim_run_stage(ns._handle, 99, st) == -1 and b"stage" in L.smk_last_error()
+    # source on a grid that does not exist
+    bad = (_lib.SmkSource * 1)(_lib.SmkSource(5, 3, 3, 2, 1.0))
+    assert L.smk_sim_add_sources(ns._handle, bad, 1, st) == -1 and b"grid" in L.smk_last_error()
+    # pitch smaller than the row
+    t = torch.zeros(2, 33, 32, device="cuda")
+    desc = _lib.SmkSimDesc(2, 32, 32, 20, 0.01, 0.001, ns._dev.index, 16, 33, t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr())
+    h = C.c_void_p()
+    assert L.smk_sim_create(C.byref(desc), C.byref(h)) == -1 and b"pitch" in L.smk_last_error()
+    # fractal emit on a non-square grid: the reference raises there too
+    rect = NavierStokesSimulator((32, 48))
+    frames = torch.empty(1, 32, 48, device="cuda")
+    with pytest.raises(_lib.SmokeHipError, match="square"):
+        rect.step_into(frames, 1, add_fractal=True)
+    rect.step_into(frames, 1, add_fractal=False)             # fine without the fractal
+    with pytest.raises(ValueError):
+        ns.step_into(torch.empty(2, 32, 32, device="cuda", dtype=torch.float64))
+    with pytest.raises(ValueError):
+        ns.advection_step(torch.zeros(5, 5, device="cuda"), ns.u, ns.v)
+
+
+def test_sources_apply_in_list_order_per_grid():
+    """fp32 += is order-sensitive: two overlapping sources on one grid must equal the oracle's sequential adds."""
+    o = oracle.OracleNS((64, 64))
+    o.add_smoke_source(30, 30, 8, 1.3)
+    o.add_smoke_source(33, 31, 8, 0.7)
+    o.add_smoke_source(30, 30, 8, 0.9)
+    ns = NavierStokesSimulator((64, 64), batch_size=3)
+    ns.add_smoke_sources([(1, 30, 30, 8, 1.3), (0, 10, 10, 8, 1.0), (1, 33, 31, 8, 0.7), (1, 30, 30, 8, 0.9)])
+    got = ns.density[1].cpu().numpy()
+    assert rel_err(got, o.density) < 1e-6
+    assert float(ns.density[2].abs().sum()) == 0.0 and float(ns.density[0].abs().sum()) > 0.0
