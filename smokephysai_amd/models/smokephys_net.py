@@ -18,6 +18,20 @@ from .encoder import HipEncoder, encoder_weight_dict
 from .physics_regularizer import PhysicsRegularizer
 
 
+def _conv_block(cin: int, cout: int, k: int):
+    """Conv(k, same padding) + BatchNorm + ReLU (smokephys_net.py:25-30)."""
+    return [nn.Conv2d(cin, cout, k, padding=k // 2), nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+
+
+def _upsample_block(cin: int, cout: int):
+    """Stride-2 transposed conv (k4, p1) + BatchNorm + ReLU (smokephys_net.py:58-63)."""
+    return [nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+
+
+def _mlp(din: int, dhid: int, dout: int) -> nn.Sequential:
+    return nn.Sequential(nn.Linear(din, dhid), nn.ReLU(inplace=True), nn.Linear(dhid, dout))
+
+
 class SmokePhysNet(nn.Module):
     def __init__(self, input_dim: int = 128, hidden_dim: int = 512, num_layers: int = 6, num_heads: int = 8,
                  output_channels: int = 64, chaos_strength: float = 0.1, encoder_dtype: str = "f32"):
@@ -26,20 +40,18 @@ class SmokePhysNet(nn.Module):
         self.hidden_dim = hidden_dim
         self.num_layers = num_layers
         self.encoder_dtype = encoder_dtype
-        self.input_encoder = nn.Sequential(
-            nn.Conv2d(1, 64, 7, padding=3), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
-            nn.Conv2d(64, 128, 3, padding=1), nn.BatchNorm2d(128), nn.ReLU(inplace=True),
-            nn.AdaptiveAvgPool2d((input_dim, input_dim)))
+        # Construction order and Sequential indices follow the reference exactly: that fixes both the state_dict keys
+        # (input_encoder.{0,1,3,4}, reconstruction_head.{0,1,3,4,6}, ...) and the RNG stream of the default initialisation.
+        self.input_encoder = nn.Sequential(*_conv_block(1, 64, 7), *_conv_block(64, 128, 3),
+                                           nn.AdaptiveAvgPool2d((input_dim, input_dim)))
         self.pos_embedding = nn.Parameter(torch.randn(1, input_dim * input_dim, hidden_dim))
         self.feature_proj = nn.Linear(128, hidden_dim)
         self.chaos_layers = nn.ModuleList(
-            [ChaosTransformerLayer(hidden_dim, num_heads, chaos_strength=chaos_strength) for _ in range(num_layers)])
-        self.output_decoder = nn.Sequential(nn.Linear(hidden_dim, 256), nn.ReLU(inplace=True), nn.Linear(256, output_channels))
-        self.reconstruction_head = nn.Sequential(
-            nn.ConvTranspose2d(output_channels, 32, 4, stride=2, padding=1), nn.BatchNorm2d(32), nn.ReLU(inplace=True),
-            nn.ConvTranspose2d(32, 16, 4, stride=2, padding=1), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
-            nn.Conv2d(16, 1, 3, padding=1), nn.Sigmoid())
-        self.physics_head = nn.Sequential(nn.Linear(hidden_dim, 256), nn.ReLU(inplace=True), nn.Linear(256, 3))
+            ChaosTransformerLayer(hidden_dim, num_heads, chaos_strength=chaos_strength) for _ in range(num_layers))
+        self.output_decoder = _mlp(hidden_dim, 256, output_channels)
+        self.reconstruction_head = nn.Sequential(*_upsample_block(output_channels, 32), *_upsample_block(32, 16),
+                                                 nn.Conv2d(16, 1, 3, padding=1), nn.Sigmoid())
+        self.physics_head = _mlp(hidden_dim, 256, 3)
         self.physics_regularizer = PhysicsRegularizer()
         self._hip = None          # (HipEncoder, weight fingerprint)
         self._pos_cache = None    # (fingerprint, tensor)
