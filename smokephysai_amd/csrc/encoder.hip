@@ -121,7 +121,7 @@ __device__ __forceinline__ void conv1_pixel(const float (&patch)[49], const floa
 }
 
 // ---------------------------------------------------------------- parity hook: conv1 activations to HBM
-__global__ void k_conv1_only(const float *frames, int64_t fstride, int H, int W, EncoderDev e, float *act) {
+__global__ __launch_bounds__(256) void k_conv1_only(const float *frames, int64_t fstride, int H, int W, EncoderDev e, float *act) {
     int b = blockIdx.z;
     int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
     if (i >= H || j >= W) return;
@@ -134,11 +134,12 @@ __global__ void k_conv1_only(const float *frames, int64_t fstride, int H, int W,
             int ii = i + ki - 3, jj = j + kj - 3;
             patch[ki * 7 + kj] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? x[(size_t)ii * W + jj] : 0.f;
         }
-    for (int c0 = 0; c0 < 64; c0 += 16) {
-        float o[16];
-        conv1_pixel<16>(patch, e.w1, e.s1, e.t1, c0, o);
+#pragma unroll 1
+    for (int c0 = 0; c0 < 64; c0 += 4) {                      // 4 channels at a time: 49-tap patch + 4 sums stay in registers
+        float o[4];
+        conv1_pixel<4>(patch, e.w1, e.s1, e.t1, c0, o);
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) act[(((size_t)b * 64 + c0 + cc) * H + i) * W + j] = o[cc];
+        for (int cc = 0; cc < 4; ++cc) act[(((size_t)b * 64 + c0 + cc) * H + i) * W + j] = o[cc];
     }
 }
 
@@ -182,27 +183,27 @@ __global__ __launch_bounds__(512) void k_encoder_f32(const float *__restrict__ f
     }
     __syncthreads();
 
-    // ---- conv1 + BN + ReLU into a1s: 6 pixel chunks of 64 x 4 channel quarters = 24 wave tasks over 8 waves
-    for (int task = wave; task < 24; task += 8) {
+    // ---- conv1 + BN + ReLU into a1s: 6 pixel chunks of 64 x 8 channel eighths = 48 wave tasks over 8 waves
+    for (int task = wave; task < 48; task += 8) {
         const int chunk = task % 6, cq = task / 6;            // wave-uniform
         const int pix = chunk * 64 + lane;
         if (pix < ENC_ACS) {
             const int ar = pix / ENC_AW, ac = pix % ENC_AW;     // a1 halo coords; image coords (r0-1+ar, c0-1+ac)
             const int ii = r0 - 1 + ar, jj = c0 - 1 + ac;
-            float o[16];
+            float o[8];
             if (ii >= 0 && ii < H && jj >= 0 && jj < W) {
                 float patch[49];
 #pragma unroll
                 for (int ki = 0; ki < 7; ++ki)
 #pragma unroll
                     for (int kj = 0; kj < 7; ++kj) patch[ki * 7 + kj] = xs[(ar + ki) * ENC_XW + ac + kj];
-                conv1_pixel<16>(patch, e.w1, e.s1, e.t1, cq * 16, o);
+                conv1_pixel<8>(patch, e.w1, e.s1, e.t1, cq * 8, o);
             } else {
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc) o[cc] = 0.f;      // conv2's zero padding
+                for (int cc = 0; cc < 8; ++cc) o[cc] = 0.f;       // conv2's zero padding
             }
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) a1s[(cq * 16 + cc) * ENC_ACS + pix] = o[cc];
+            for (int cc = 0; cc < 8; ++cc) a1s[(cq * 8 + cc) * ENC_ACS + pix] = o[cc];
         }
     }
     // tap-0 weights -> LDS buffer 0
