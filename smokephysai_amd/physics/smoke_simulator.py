@@ -54,24 +54,42 @@ class SmokeSimulator(nn.Module):
         return out
 
     # ---- chaos statistics (smoke_simulator.py:47-140) -------------------------------------------------------
-    def get_chaos_features(self) -> dict:
+    def get_chaos_features(self):
+        """Un-batched: the reference's dict (or {} with fewer than 10 frames).  Batched: a list with one dict per grid."""
         if len(self.history) < 10:
-            return {}
-        return {"lyapunov_exponent": self.compute_lyapunov_exponent(),
-                "fractal_dimension": self.compute_fractal_dimension(),
-                "entropy": self.compute_entropy()}
+            return {} if self.batch_size is None else [{} for _ in range(self.ns_solver._B)]
+        if self.batch_size is None:
+            return {"lyapunov_exponent": self.compute_lyapunov_exponent(),
+                    "fractal_dimension": self.compute_fractal_dimension(),
+                    "entropy": self.compute_entropy()}
+        cur = self.history[-1]                                           # [B,H,W]
+        _, box, hist = chaos_stats(cur)
+        box, hist = box.cpu().numpy(), hist.cpu().numpy()
+        lyap = [0.0] * cur.shape[0]
+        if len(self.history) >= 20:
+            states = torch.stack(self.history[-20:], dim=1)             # [B,20,H,W]
+            lyap = [lyapunov_from_norms(frame_diff_norms(states[b]).cpu().numpy()) for b in range(cur.shape[0])]
+        return [{"lyapunov_exponent": lyap[b], "fractal_dimension": fractal_dimension_from_counts(box[b]),
+                 "entropy": entropy_from_hist(hist[b])} for b in range(cur.shape[0])]
+
+    def _single_grid(self, what):
+        if self.batch_size is not None:
+            raise ValueError(f"{what}: batched simulator -- use get_chaos_features(), which returns one dict per grid")
 
     def compute_lyapunov_exponent(self) -> float:
+        self._single_grid("compute_lyapunov_exponent")
         if len(self.history) < 20:
             return 0.0
         return lyapunov_from_frames(torch.stack(self.history[-20:]))
 
     def compute_fractal_dimension(self) -> float:
+        self._single_grid("compute_fractal_dimension")
         if not self.history:
             return 0.0
         return fractal_dimension(self.history[-1])
 
     def compute_entropy(self) -> float:
+        self._single_grid("compute_entropy")
         if not self.history:
             return 0.0
         return histogram_entropy(self.history[-1])

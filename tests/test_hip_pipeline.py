@@ -156,3 +156,26 @@ def test_train_losses_at_256_pool_the_target():
     total, recon, phys, chaos = train.batch_losses(model, model.physics_regularizer, batch, "cuda")
     assert torch.isfinite(total)
     total.backward()
+
+
+def test_batched_get_chaos_features_matches_single_grid_simulators():
+    from smokephysai_amd.physics import SmokeSimulator
+    srcs = [[(30, 30)], [(20, 40), (44, 25)]]
+    batched = SmokeSimulator((64, 64), batch_size=2)
+    singles = [SmokeSimulator((64, 64)) for _ in range(2)]
+    for b in range(2):
+        batched.add_incense_source(srcs[b], [1.0 + b] * len(srcs[b]), grid=b)
+        singles[b].add_incense_source(srcs[b], [1.0 + b] * len(srcs[b]))
+    assert batched.get_chaos_features() == [{}, {}] and singles[0].get_chaos_features() == {}
+    for _ in range(21):
+        batched.simulate_step()
+        for s in singles:
+            s.simulate_step()
+    got = batched.get_chaos_features()
+    for b in range(2):
+        ref = singles[b].get_chaos_features()
+        assert set(got[b]) == {"lyapunov_exponent", "fractal_dimension", "entropy"}
+        for k in ref:
+            assert abs(got[b][k] - ref[k]) <= 1e-6 * max(1.0, abs(ref[k])), (b, k)
+    with pytest.raises(ValueError):
+        batched.compute_entropy()
