@@ -349,7 +349,7 @@ template <bool X3> constexpr int b3_lds_total() { return b3_lds_bytes<X3>() + (X
 // BN2 scale/shift, B-ring fill) are paid once; the next tile's x halo is prefetched into registers under the K loop and
 // the B-fragment ring simply keeps running across tiles (the weights do not depend on the tile).
 template <bool X3, int PS, bool TOKENS>
-__global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ frames, int64_t fstride, int H, int W,
+__global__ __launch_bounds__(256, 2) void k_encoder_bf16(const float *__restrict__ frames, int64_t fstride, int H, int W,
                                                       EncoderDev e, float *__restrict__ features, int lg_tiles_x,
                                                       int lg_tiles_per_frame, int ntiles, int stagger) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (kn * 2 + part) * 4096, 0);
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
-    constexpr int RING = X3 ? 4 : 6;                      // B fragments in flight: RING-1 k-steps ahead (L2 latency under load);
+    constexpr int RING = 6;                      // B fragments in flight: RING-1 k-steps ahead (L2 latency under load);
                                                           // the ring stays live through conv1, so x3 (2 regs sets) keeps it shorter
     uint4 bqh[RING], bql[RING];
 #pragma unroll
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_encoder_bf16(const float *__restrict__ 
         };
         bf16x8 ahA[4], alA[4], ahB[4], alB[4];
         load_a(0, ahA, alA);
-        constexpr int UNR = RING == 6 ? 6 : 12;               // multiple of RING and of 2: ring / buffer indices are constants
+        constexpr int UNR = 6;               // multiple of RING and of 2: ring / buffer indices are constants
 #pragma unroll 1
         for (int k0 = 0; k0 < 36; k0 += UNR) {                // (a full unroll needs 352 registers: 1 wave/SIMD, slower)
 #pragma unroll
