@@ -1,0 +1,33 @@
+"""The bench line the driver consumes: required keys, types and internal consistency, checked on the committed
+round-1 line (profiles/r01/bench_default.json) and on bench.py's argument surface.  CPU only."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01", "bench_default.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    B, K = d["config"]["batch_per_gpu"], d["steps"]
+    assert abs(d["value"] - d["n_gpus"] * B * K / (d["ms_per_step"] * 1e-3 * K)) / d["value"] < 1e-6
+    for r in (d["roofline"], d["roofline_stencil"], d["roofline_encoder"]):
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert r["traffic"] is None or r["traffic"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_bench_cli_defaults_are_the_baseline_config():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, check=True).stdout
+    for flag in ("--gpus", "--steps", "--warmup", "--grid", "--batch", "--jacobi", "--encoder-dtype"):
+        assert flag in out
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'default=256' in src and 'default=64' in src and '"--jacobi", type=int, default=100' in src
