@@ -63,23 +63,30 @@ def cpu_baseline(N, J, weights, budget_frames):
     scalar; the encoder is the row-vectorised OpenMP fp32 variant on up to 16 host threads (the GPU box's CPU share)."""
     import oracle
     threads = max(1, min(16, os.cpu_count() or 1))
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     w = {k: v.cpu().numpy() for k, v in weights.items()}
-    sim = oracle.OracleSmokeSimulator((N, N), jacobi_iters=J, cache_fractal=False)
-    sim.ns_solver.add_smoke_source(N // 2, N // 2, 8, 1.0)
-    frame = sim.simulate_step(add_fractal=True)
-    oracle.encoder_features_fast(frame[None], w, input_dim=128)          # warm-up (thread pool, page faults)
-    t0 = time.perf_counter()
-    t_sim = 0.0
-    for _ in range(budget_frames):
-        ts = time.perf_counter()
+
+    def run(nthreads, frames):
+        oracle.set_threads(nthreads)
+        sim = oracle.OracleSmokeSimulator((N, N), jacobi_iters=J, cache_fractal=False)
+        sim.ns_solver.add_smoke_source(N // 2, N // 2, 8, 1.0)
         frame = sim.simulate_step(add_fractal=True)
-        t_sim += time.perf_counter() - ts
-        oracle.encoder_features_fast(frame[None], w, input_dim=128)
-    dt = time.perf_counter() - t0
+        oracle.encoder_features_fast(frame[None], w, input_dim=128)          # warm-up (thread pool, page faults)
+        t0 = time.perf_counter()
+        t_sim = 0.0
+        for _ in range(frames):
+            ts = time.perf_counter()
+            frame = sim.simulate_step(add_fractal=True)
+            t_sim += time.perf_counter() - ts
+            oracle.encoder_features_fast(frame[None], w, input_dim=128)
+        return time.perf_counter() - t0, t_sim
+
+    dt, t_sim = run(threads, budget_frames)
+    n1 = max(2, budget_frames // 10)
+    dt1, _ = run(1, n1)                                        # SURVEY 8(d): also with one thread
     return {"value": budget_frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{budget_frames} frames of one {N}x{N} grid (Jacobi-{J}, fractal recomputed per frame): scalar C stepper "
                       f"({t_sim / budget_frames * 1e3:.0f} ms/frame) + OpenMP fp32 C encoder on {threads} threads, {dt:.1f} s total",
+            "single_thread": {"value": n1 / dt1, "unit": "frames/s", "cores": 1, "sample": f"{n1} frames, {dt1:.1f} s"},
             "host_cores_available": os.cpu_count(),
             "reference_on_8_cores_in_build_container": "6.45 frames/s (BASELINE.md: actual reference code, torch CPU/oneDNN)"}
 

@@ -51,6 +51,8 @@ def lib():
         L.so_encoder_frame.argtypes = [f32p, C.c_int, C.c_int, C.c_int] + [f32p] * 12 + [C.c_void_p, f32p]
         L.so_encoder_frame_fast.argtypes = [f32p, C.c_int, C.c_int, C.c_int] + [f32p] * 12 + [f32p]
         L.so_encoder_frame_fast.restype = None
+        L.so_set_threads.argtypes = [C.c_int]
+        L.so_set_threads.restype = None
         for fn in ("so_linspace so_add_source so_diffuse so_buoyancy so_divergence so_jacobi so_grad_subtract "
                    "so_project so_bilinear so_advect so_step so_perlin so_mandelbrot_counts so_fractal_field "
                    "so_apply_fractal so_box_counts so_hist256 so_encoder_frame").split():
@@ -235,6 +237,11 @@ def encoder_features(frames, weights, input_dim=128, want_conv1=False):
         lib().so_encoder_frame(frames[b], H, W, input_dim, *ws,
                                c1[b].ctypes.data if want_conv1 else None, out[b])
     return (out, c1) if want_conv1 else out
+
+
+def set_threads(n):
+    """OpenMP threads used by encoder_features_fast."""
+    lib().so_set_threads(int(n))
 
 
 def encoder_features_fast(frames, weights, input_dim=128):

@@ -376,6 +376,18 @@ SO_API void so_encoder_frame(const float *frame, int H, int W, int input_dim,
     free(a1); free(a2); free(pl);
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* thread count of the timing-grade encoder below (bench.py reports the baseline on all allotted cores and on one) */
+SO_API void so_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------ timing-grade encoder (cpu_baseline only)
  * Same maths as so_encoder_frame, fp32 accumulation, rows vectorised, OpenMP over output channels: the port that
  * bench.py times as the CPU baseline.  Checked against the fp64 version in tests/test_oracle_golden.py. */
