@@ -141,7 +141,7 @@ def main():
                     help="bf16x3 (headline; BASELINE configs[2] says \"encoder bf16\"): split-bf16 MFMA, fp32 accumulate, "
                          "features within 3e-6 (max-norm) of the reference; i8x3: 16-bit fixed point on int8 MFMA, within "
                          "3.5e-5 and ~1.6x faster. The other one of these two is timed too and reported under alt.")
-    ap.add_argument("--cpu-frames", type=int, default=40, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=240, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
     ap.add_argument("--no-alt", action="store_true", help="time only --encoder-dtype (profiling runs)")
     ap.add_argument("--no-inference", action="store_true", help="skip the per-frame inference-ms measurement (metric M2)")
