@@ -107,25 +107,29 @@ def hbm_copy_gbs(dev):
 
 def inference_ms(dev, N, frames, encoder_dtype):
     """Metric M2 (BASELINE.json): SmokePhysNet.forward wall time per frame, eval mode, full 27.8 M-parameter network
-    (HIP encoder + PyTorch-ROCm transformer/heads, fp32), device-synchronised, at the reference's batch sizes
-    (benchmark.py uses 4, inference.py uses 1) and at the simulation batch."""
-    from smokephysai_amd.models import SmokePhysNet
+    (HIP encoder + transformer/heads, fp32-accurate), device-synchronised, at the reference's batch sizes (benchmark.py
+    uses 4, inference.py uses 1) and at the simulation batch.  The headline figures replay the forward from a captured
+    hipGraph (GraphedSmokePhysNet; bit-identical to the eager call); the eager figures are reported beside them."""
+    from smokephysai_amd.models import SmokePhysNet, GraphedSmokePhysNet
     torch.manual_seed(0)
     model = SmokePhysNet(encoder_dtype=encoder_dtype).to(dev).eval()
-    res = {}
+    graphed = GraphedSmokePhysNet(model)
+    res, eager = {}, {}
     with torch.no_grad():
         for bs in (1, 4, frames.shape[0]):
-            x = frames[:bs, None]
-            for _ in range(2):
-                model(x)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                model(x)
-            torch.cuda.synchronize(dev)
-            res[f"batch{bs}"] = (time.perf_counter() - t0) / reps / bs * 1e3
-    res["note"] = f"{N}x{N} frames; reference README: 610.92 ms/frame (hardware unstated)"
+            x = frames[:bs, None].contiguous()
+            for name, fwd, out in (("eager", model, eager), ("graph", graphed, res)):
+                for _ in range(2):
+                    fwd(x)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                reps = 10 if bs <= 4 else 5
+                for _ in range(reps):
+                    fwd(x)
+                torch.cuda.synchronize(dev)
+                out[f"batch{bs}"] = (time.perf_counter() - t0) / reps / bs * 1e3
+    res["eager"] = eager
+    res["note"] = f"{N}x{N} frames; hipGraph replay (eager launch beside it); reference README: 610.92 ms/frame (hardware unstated)"
     return res
 
 

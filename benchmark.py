@@ -29,7 +29,7 @@ def load_model(config: dict, checkpoint_path: str, device: str) -> SmokePhysNet:
     model = SmokePhysNet(input_dim=config["model"]["input_dim"], hidden_dim=config["model"]["hidden_dim"],
                          num_layers=config["model"]["num_layers"], num_heads=config["model"]["num_heads"],
                          chaos_strength=config["model"]["chaos_strength"],
-                         encoder_dtype=hw.get("encoder_dtype", "f32")).to(device)
+                         encoder_dtype=hw.get("encoder_dtype", "bf16x3")).to(device)
     if checkpoint_path:
         checkpoint = torch.load(checkpoint_path, map_location=device)
         model.load_state_dict(checkpoint["model_state_dict"])
@@ -44,9 +44,16 @@ def _pearson(a: np.ndarray, b: np.ndarray) -> float:
     return float((a * b).sum() / den) if den > 0 else float("nan")
 
 
-def evaluate_model(model, test_loader, device):
-    """benchmark.py:116-159; inference_time = sum of per-batch forward wall time / dataset size, synchronised."""
+def evaluate_model(model, test_loader, device, hip_graph: bool = True):
+    """benchmark.py:116-159; inference_time = sum of per-batch forward wall time / dataset size, synchronised.
+    hip_graph: the forward is replayed from a captured hipGraph (captured on the first batch of each shape, outside
+    the timed region)."""
     model.eval()
+    forward = model
+    if hip_graph:
+        from smokephysai_amd.models import GraphedSmokePhysNet
+        forward = GraphedSmokePhysNet(model)
+        shapes_seen = set()
     total_mse, total_ssim, total_time = 0.0, 0.0, 0.0
     physics_corr = []
     with torch.no_grad():
@@ -54,9 +61,12 @@ def evaluate_model(model, test_loader, device):
             inputs = batch["input"].to(device)
             targets = batch["target"].to(device)
             chaos_targets = batch["chaos_features"].to(device)
+            if hip_graph and tuple(inputs.shape) not in shapes_seen:
+                forward(inputs)                       # capture for this batch shape (untimed)
+                shapes_seen.add(tuple(inputs.shape))
             torch.cuda.synchronize(device)
             start_time = time.time()
-            outputs = model(inputs)
+            outputs = forward(inputs)
             torch.cuda.synchronize(device)
             total_time += time.time() - start_time
             total_mse += torch.nn.functional.mse_loss(outputs["reconstructed"], targets).item()
@@ -102,7 +112,8 @@ def main():
                                          jacobi_iters=hw.get("jacobi_iters", 20))
     test_loader = torch.utils.data.DataLoader(test_dataset, batch_size=4, shuffle=False)
     print("\nEvaluating SmokePhysAI model...")
-    model_results = evaluate_model(model, test_loader, device)
+    model_results = evaluate_model(model, test_loader, device,
+                                   hip_graph=bool((config.get("mi355x", {}) or {}).get("hip_graph", True)))
     print_results(model_results, {})
 
 

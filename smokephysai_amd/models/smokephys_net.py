@@ -34,7 +34,7 @@ def _mlp(din: int, dhid: int, dout: int) -> nn.Sequential:
 
 class SmokePhysNet(nn.Module):
     def __init__(self, input_dim: int = 128, hidden_dim: int = 512, num_layers: int = 6, num_heads: int = 8,
-                 output_channels: int = 64, chaos_strength: float = 0.1, encoder_dtype: str = "f32"):
+                 output_channels: int = 64, chaos_strength: float = 0.1, encoder_dtype: str = "bf16x3"):
         super().__init__()
         self.input_dim = input_dim
         self.hidden_dim = hidden_dim

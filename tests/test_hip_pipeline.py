@@ -179,3 +179,31 @@ def test_batched_get_chaos_features_matches_single_grid_simulators():
             assert abs(got[b][k] - ref[k]) <= 1e-6 * max(1.0, abs(ref[k])), (b, k)
     with pytest.raises(ValueError):
         batched.compute_entropy()
+
+
+def test_hip_graph_replay_equals_eager_forward(golden):
+    """GraphedSmokePhysNet: the captured forward (HIP encoder launch included) is bit-identical to the eager call for
+    pinned chaos noise, follows new inputs, draws fresh noise per replay when unpinned, and re-captures after a
+    weight update."""
+    from smokephysai_amd.models import GraphedSmokePhysNet
+    g = golden("model_small.npz")
+    model = _load_small(g)
+    graphed = GraphedSmokePhysNet(model, clone=True)
+    x = torch.from_numpy(g["frames"]).cuda()[:, None]
+    noise = torch.from_numpy(g["chaos_noise"]).cuda()
+    with torch.no_grad():
+        for xin in (x, x.flip(0) * 0.5):
+            ref = model(xin, chaos_noise=noise)
+            out = graphed(xin, chaos_noise=noise)
+            for k in ref:
+                assert torch.equal(ref[k], out[k]), k
+        a = graphed(x)["latent_features"]
+        b = graphed(x)["latent_features"]
+        assert not torch.equal(a, b)                              # fresh randn per replay, as an eager eval call
+        model.input_encoder[0].weight.mul_(1.25)                  # folded encoder weights must be rebuilt
+        model.pos_embedding.add_(0.01)
+        ref = model(x, chaos_noise=noise)
+        out = graphed(x, chaos_noise=noise)
+        for k in ref:
+            assert torch.equal(ref[k], out[k]), k
+    assert rel_err(out["physics_features"].cpu().numpy(), g["physics_features"]) > 1e-6   # the update was seen

@@ -137,7 +137,7 @@ def main():
     model = SmokePhysNet(input_dim=config["model"]["input_dim"], hidden_dim=config["model"]["hidden_dim"],
                          num_layers=config["model"]["num_layers"], num_heads=config["model"]["num_heads"],
                          chaos_strength=config["model"]["chaos_strength"],
-                         encoder_dtype=hw.get("encoder_dtype", "f32")).to(device)
+                         encoder_dtype=hw.get("encoder_dtype", "bf16x3")).to(device)
     physics_regularizer = PhysicsRegularizer(conservation_weight=config["physics"]["conservation_weight"],
                                              continuity_weight=config["physics"]["continuity_weight"],
                                              energy_weight=config["physics"]["energy_weight"])
