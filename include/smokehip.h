@@ -163,6 +163,32 @@ int smk_encoder_forward_tokens(smk_encoder *enc, const float *frames, int64_t fr
 int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H,
                       int32_t W, float *act, void *stream);
 
+/* ------------------------------------------------------------------ transformer-body linear layers */
+/* One nn.Linear of SmokePhysNet's token path -- feature_proj (smokephys_net.py:38,97), q/k/v/out projections
+ * (chaos_attention.py:25-28,77-79,113), FFN (smokephys_net.py:153-158), output_decoder (smokephys_net.py:50-54) --
+ * with its weights re-laid-out on the device for the split-bf16 MFMA kernel (fp32-class accuracy: results within
+ * 1e-4 relative of the fp32 GEMM the reference runs; measured ~1e-6).
+ * weight [out_features][in_features] fp32 (PyTorch layout), bias [out_features] or NULL; both are read once, on `stream`.
+ * Requires in_features % 64 == 0 and out_features % 32 == 0 (else SMK_ERR_UNSUPPORTED). */
+typedef struct smk_linear smk_linear;
+typedef enum smk_activation { SMK_ACT_NONE = 0, SMK_ACT_GELU = 1 /* erf form, nn.GELU() */ } smk_activation;
+
+int smk_linear_create(const float *weight, const float *bias, int32_t out_features, int32_t in_features,
+                      int32_t device_id, void *stream, smk_linear **out);
+int smk_linear_destroy(smk_linear *lin);
+
+/* y = act(x W^T + b + addend) + residual over `rows` token rows:
+ *   x [rows][in_features], row pitch ldx floats (16-byte aligned rows); y [rows][out_features], row pitch ldy;
+ *   residual (or NULL) [rows][out_features], row pitch ldr -- the `x + sublayer(x)` of the pre-LN block
+ *   (smokephys_net.py:161-167); may alias y;
+ *   periodic_add (or NULL) [rows / rows_per_group][period][out_features]: row i of group g receives
+ *   periodic_add[g][(i % rows_per_group) % period] before the activation -- the chaos term folded into Q
+ *   (the 5-step Lorenz field tiled along the sequence, chaos_attention.py:61-65,85-100); rows_per_group % 32 == 0.
+ * Enqueued on `stream`, no synchronisation. */
+int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy,
+                       const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
+                       int32_t period, int32_t activation, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

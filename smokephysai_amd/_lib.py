@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmokehip.so")
 
 SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
+SMK_ACT_NONE, SMK_ACT_GELU = 0, 1
 STAGE_BUOY_DIFFUSE, STAGE_PROJECT, STAGE_ADVECT_U, STAGE_ADVECT_V, STAGE_ADVECT_D = range(5)
 DTYPES = {"f32": SMK_F32, "fp32": SMK_F32, "float32": SMK_F32, "bf16x3": SMK_BF16X3, "bf16": SMK_BF16, "i8x3": SMK_I8X3}
 
@@ -57,6 +58,10 @@ _SIGNATURES = {
     "smk_encoder_forward_tokens": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_int32, C.c_void_p],
     "smk_encoder_conv1": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
+    "smk_linear_create": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
+    "smk_linear_destroy": [C.c_void_p],
+    "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
 EXPORTS = ["smk_abi_version", "smk_last_error"] + list(_SIGNATURES)
 

@@ -5,6 +5,7 @@
 
 #include "chaos.h"
 #include "encoder.h"
+#include "linear.h"
 #include "stencil.h"
 
 namespace smk {
@@ -25,6 +26,11 @@ struct smk_sim {
     int *dev_first = nullptr;
     int src_cap = 0;
     int jacobi_iters = 20;
+    int device = 0;
+};
+
+struct smk_linear {
+    LinearDev l;
     int device = 0;
 };
 
@@ -467,6 +473,69 @@ int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_strid
     int rc = set_device(enc->device);
     if (rc) return rc;
     return check_launch(launch_conv1_only(frames, frame_stride, B, H, W, enc->e, act, (hipStream_t)stream), "conv1");
+}
+
+// ------------------------------------------------------------------ transformer-body linear layers
+int smk_linear_create(const float *weight, const float *bias, int32_t out_features, int32_t in_features,
+                      int32_t device_id, void *stream, smk_linear **out) {
+    SMK_REQUIRE(weight && out, "null weight/out");
+    SMK_REQUIRE(out_features >= 1 && in_features >= 1, "positive feature counts");
+    if (in_features % 64 != 0 || out_features % 32 != 0 || (int64_t)in_features * out_features > (1 << 28)) {
+        set_error("linear: HIP path is built for in_features % 64 == 0, out_features % 32 == 0, at most 2^28 weights");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    int rc = set_device(device_id);
+    if (rc) return rc;
+    smk_linear *lin = new smk_linear();
+    lin->device = device_id;
+    lin->l.N = out_features;
+    lin->l.K = in_features;
+    lin->l.wq = nullptr;
+    lin->l.bias = nullptr;
+    hipError_t e = hipMalloc((void **)&lin->l.wq, (size_t)in_features * out_features * 2 * sizeof(unsigned short));
+    if (e == hipSuccess) e = hipMalloc((void **)&lin->l.bias, (size_t)out_features * sizeof(float));
+    if (e != hipSuccess) {
+        smk_linear_destroy(lin);
+        set_error(std::string("smk_linear_create: ") + hipGetErrorString(e));
+        return SMK_ERR_HIP;
+    }
+    rc = check_launch(launch_split_linear_weights(weight, bias, lin->l, (hipStream_t)stream), "split_linear_weights");
+    if (rc) { smk_linear_destroy(lin); return rc; }
+    *out = lin;
+    return SMK_OK;
+}
+
+int smk_linear_destroy(smk_linear *lin) {
+    if (!lin) return SMK_OK;
+    (void)hipSetDevice(lin->device);
+    if (lin->l.wq) (void)hipFree(lin->l.wq);
+    if (lin->l.bias) (void)hipFree(lin->l.bias);
+    delete lin;
+    return SMK_OK;
+}
+
+int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy,
+                       const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
+                       int32_t period, int32_t activation, void *stream) {
+    SMK_REQUIRE(lin && x && y, "null lin/x/y");
+    SMK_REQUIRE(rows >= 1 && rows < (1LL << 31) - 256, "1 <= rows < 2^31 - 256");
+    SMK_REQUIRE(ldx >= lin->l.K && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "x rows: pitch >= in_features, 16-byte aligned");
+    SMK_REQUIRE(ldy >= lin->l.N, "ldy >= out_features");
+    SMK_REQUIRE(!residual || ldr >= lin->l.N, "ldr >= out_features");
+    SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_GELU, "activation");
+    if (periodic_add)
+        SMK_REQUIRE(period >= 1 && rows_per_group >= 32 && rows_per_group % 32 == 0 && rows % rows_per_group == 0,
+                    "periodic_add: period >= 1, rows_per_group a multiple of 32 that divides rows");
+    int rc = set_device(lin->device);
+    if (rc) return rc;
+    LinearCall c;
+    c.x = x; c.ldx = ldx;
+    c.y = y; c.ldy = ldy;
+    c.res = residual; c.ldr = ldr;
+    c.padd = periodic_add; c.rows_per_group = periodic_add ? rows_per_group : 1; c.period = periodic_add ? period : 1;
+    c.M = (int)rows;
+    c.act = activation;
+    return check_launch(launch_linear_x3(lin->l, c, (hipStream_t)stream), "linear_x3");
 }
 
 }  // extern "C"

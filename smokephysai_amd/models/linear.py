@@ -1,0 +1,85 @@
+"""Host side of libsmokehip's split-bf16 linear kernel: the nn.Linear layers of SmokePhysNet's token path
+(smokephys_net.py:38,50-54,153-158; chaos_attention.py:25-28) as one fused launch each --
+``y = act(x W^T + b + periodic_add) + residual`` -- with fp32-class accuracy on the bf16 matrix cores."""
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import _lib
+
+
+def hip_linear_supported(in_features: int, out_features: int) -> bool:
+    """Shapes the HIP kernel is built for (include/smokehip.h: smk_linear_create)."""
+    return in_features % 64 == 0 and out_features % 32 == 0
+
+
+class HipLinear:
+    """Device-resident, re-laid-out copy of one nn.Linear's weights + the launch wrapper."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device=None):
+        self._dev = _lib.require_cuda(device if device is not None else weight.device, "HipLinear")
+        self._L = _lib.load()
+        self._handle = None
+        w = weight.detach().to(self._dev, torch.float32).contiguous()
+        b = None if bias is None else bias.detach().to(self._dev, torch.float32).contiguous()
+        self.out_features, self.in_features = w.shape
+        handle = C.c_void_p()
+        _lib.check(self._L.smk_linear_create(w.data_ptr(), 0 if b is None else b.data_ptr(), self.out_features,
+                                             self.in_features, self._dev.index, _lib.stream_ptr(self._dev),
+                                             C.byref(handle)))
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(self._dev).synchronize()      # the split kernel has read w / b
+        else:
+            self._keep = (w, b)
+        self._handle = handle
+
+    @classmethod
+    def from_module(cls, lin: nn.Linear) -> "HipLinear":
+        return cls(lin.weight, lin.bias)
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._L.smk_linear_destroy(self._handle)
+            self._handle = None
+
+    __del__ = close
+
+    def __call__(self, x: torch.Tensor, activation: Optional[str] = None, residual: Optional[torch.Tensor] = None,
+                 periodic_add: Optional[torch.Tensor] = None, rows_per_group: int = 0,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [..., in_features] -> [..., out_features].  residual: same shape as the result, added after the activation.
+        periodic_add [groups, period, out_features]: row i of group g gets periodic_add[g, i % period] before the
+        activation (rows_per_group rows per group, default = x.shape[-2])."""
+        if x.device != self._dev or x.dtype != torch.float32:
+            raise ValueError(f"HipLinear: x must be float32 on {self._dev}")
+        if x.shape[-1] != self.in_features:
+            raise ValueError(f"HipLinear: last dim {x.shape[-1]} != in_features {self.in_features}")
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, self.in_features)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        y = out if out is not None else torch.empty(*lead, self.out_features, device=self._dev, dtype=torch.float32)
+        y2 = y.view(-1, self.out_features)
+        res_ptr, ldr = 0, 0
+        if residual is not None:
+            r2 = residual.reshape(-1, self.out_features)
+            if r2.stride(1) != 1:
+                r2 = r2.contiguous()
+            if r2.shape[0] != rows or r2.dtype != torch.float32 or r2.device != self._dev:
+                raise ValueError("HipLinear: residual must match the output")
+            res_ptr, ldr = r2.data_ptr(), r2.stride(0)
+        pa_ptr, period, rpg = 0, 1, 1
+        if periodic_add is not None:
+            pa = periodic_add.to(torch.float32).contiguous()
+            rpg = rows_per_group or x.shape[-2]
+            if pa.dim() != 3 or pa.shape[2] != self.out_features or pa.shape[0] * rpg != rows:
+                raise ValueError("HipLinear: periodic_add must be [rows / rows_per_group, period, out_features]")
+            pa_ptr, period = pa.data_ptr(), pa.shape[1]
+        act = {None: _lib.SMK_ACT_NONE, "none": _lib.SMK_ACT_NONE, "gelu": _lib.SMK_ACT_GELU}[activation]
+        _lib.check(self._L.smk_linear_forward(self._handle, x2.data_ptr(), rows, x2.stride(0), y2.data_ptr(),
+                                              y2.stride(0), res_ptr, ldr, pa_ptr, rpg, period, act,
+                                              _lib.stream_ptr(self._dev)))
+        return y

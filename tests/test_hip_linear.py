@@ -1,0 +1,83 @@
+"""GPU parity of libsmokehip's split-bf16 linear kernel (smk_linear_*) against the fp32/fp64 GEMM the reference runs
+through nn.Linear (smokephys_net.py:38,50-54,153-158; chaos_attention.py:25-28).  Tolerance: 1e-4 relative (max-norm),
+the bar SURVEY 8(c) sets for the aten-backed layers; measured errors are ~1e-6."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+from smokephysai_amd.models.linear import HipLinear, hip_linear_supported      # noqa: E402
+
+TOL = 1e-4
+
+
+def _ref(x, w, b, act=None, residual=None, padd=None):
+    y = x.double() @ w.double().t() + (0 if b is None else b.double())
+    if padd is not None:
+        G, P, N = padd.shape
+        L = x.shape[-2]
+        idx = torch.arange(L, device=x.device) % P
+        y = y + padd.double()[:, idx]
+    if act == "gelu":
+        y = 0.5 * y * (1 + torch.erf(y / math.sqrt(2.0)))
+    if residual is not None:
+        y = residual.double() + y
+    return y
+
+
+@pytest.mark.parametrize("M,K,N", [(1024, 128, 512), (4096, 512, 512), (8192, 512, 2048), (8192, 2048, 512),
+                                   (2048, 512, 256), (2048, 256, 64), (1000, 512, 512), (37, 64, 32), (65536, 512, 512)])
+def test_linear_matches_fp64_gemm(M, K, N):
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)
+    b = torch.randn(N, device="cuda", generator=g)
+    lin = HipLinear(w, b)
+    y = lin(x)
+    ref = _ref(x, w, b)
+    assert y.shape == (M, N)
+    e_hip = rel_err(y.cpu().numpy(), ref.cpu().numpy())
+    e_f32 = rel_err(torch.nn.functional.linear(x, w, b).cpu().numpy(), ref.cpu().numpy())
+    assert e_hip < TOL, (e_hip, e_f32)
+    assert e_hip < 2e-5, (e_hip, e_f32)          # split-bf16 drops lo*lo (~2^-17 per product): a few 1e-6 in practice
+
+
+def test_linear_epilogues_gelu_residual_periodic_add():
+    g = torch.Generator(device="cuda").manual_seed(7)
+    B, L, D = 3, 1024, 512
+    x = torch.randn(B, L, D, device="cuda", generator=g)
+    w1 = torch.randn(4 * D, D, device="cuda", generator=g) / math.sqrt(D)
+    b1 = torch.randn(4 * D, device="cuda", generator=g)
+    w2 = torch.randn(D, 4 * D, device="cuda", generator=g) / math.sqrt(4 * D)
+    b2 = torch.randn(D, device="cuda", generator=g)
+    h = HipLinear(w1, b1)(x, activation="gelu")
+    assert rel_err(h.cpu().numpy(), _ref(x, w1, b1, act="gelu").cpu().numpy()) < TOL
+    y = HipLinear(w2, b2)(h, residual=x)
+    assert rel_err(y.cpu().numpy(), _ref(h, w2, b2, residual=x).cpu().numpy()) < TOL
+    # in-place residual (y aliases the residual): the pre-LN block's x = x + sublayer(x)
+    xc = x.clone()
+    HipLinear(w2, b2)(h, residual=xc, out=xc)
+    assert torch.equal(xc, y)
+    # row-periodic addend (chaos term folded into Q: 5 distinct rows tiled along the sequence)
+    wq = torch.randn(D, D, device="cuda", generator=g) / math.sqrt(D)
+    padd = torch.randn(B, 5, D, device="cuda", generator=g)
+    q = HipLinear(wq, None)(x, periodic_add=padd)
+    assert rel_err(q.cpu().numpy(), _ref(x, wq, None, padd=padd).cpu().numpy()) < TOL
+
+
+def test_linear_strided_rows_and_unsupported_shapes():
+    g = torch.Generator(device="cuda").manual_seed(11)
+    big = torch.randn(512, 1536, device="cuda", generator=g)
+    x = big[:, 512:1024]                                          # row pitch 1536, 16-byte aligned rows
+    w = torch.randn(512, 512, device="cuda", generator=g) / 22.6
+    y = HipLinear(w)(x)
+    assert rel_err(y.cpu().numpy(), _ref(x, w, None).cpu().numpy()) < TOL
+    assert not hip_linear_supported(3, 512) and not hip_linear_supported(512, 3)
+    with pytest.raises(Exception, match="HIP path is built for"):
+        HipLinear(torch.randn(3, 512, device="cuda"))
+    with pytest.raises(Exception):
+        HipLinear(torch.randn(64, 64))                            # CPU tensor: no CPU path
