@@ -178,12 +178,13 @@ int smk_linear_create(const float *weight, const float *bias, int32_t out_featur
 int smk_linear_destroy(smk_linear *lin);
 
 /* y = act(x W^T + b + addend) + residual over `rows` token rows:
- *   x [rows][in_features], row pitch ldx floats (16-byte aligned rows); y [rows][out_features], row pitch ldy;
+ *   x [rows][in_features], row pitch ldx floats; y [rows][out_features], row pitch ldy (all row starts 16-byte aligned);
  *   residual (or NULL) [rows][out_features], row pitch ldr -- the `x + sublayer(x)` of the pre-LN block
  *   (smokephys_net.py:161-167); may alias y;
  *   periodic_add (or NULL) [rows / rows_per_group][period][out_features]: row i of group g receives
  *   periodic_add[g][(i % rows_per_group) % period] before the activation -- the chaos term folded into Q
  *   (the 5-step Lorenz field tiled along the sequence, chaos_attention.py:61-65,85-100); rows_per_group % 32 == 0.
+ *   residual and periodic_add are mutually exclusive (no layer of the path uses both).
  * Enqueued on `stream`, no synchronisation. */
 int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy,
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,

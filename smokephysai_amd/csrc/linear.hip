@@ -23,9 +23,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LN_PITCH = 144;      // bytes per staged row per plane: 64 bf16 + 16 pad (9 x 16 B, odd: 16 rows hit 16 bank groups)
+#ifndef SMK_LINEAR_SCHED
+#define SMK_LINEAR_SCHED 1
+#endif
 constexpr int LN_RING = 4;         // B fragments in flight: 3 k-steps ahead; 4 k-steps per chunk keep the ring indices static
 template <int MB> constexpr int ln_plane_bytes() { return MB * 32 * LN_PITCH; }
-template <int MB> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>(); }   // MB = 4: 73,728 B -> 2 workgroups per CU
+template <int MB> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 512; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
 
 __global__ __launch_bounds__(256) void k_split_linear_weights(const float *__restrict__ w, const float *__restrict__ bias, LinearDev l) {
     const long long total = (long long)l.N * l.K;
@@ -47,27 +50,50 @@ hipError_t launch_split_linear_weights(const float *w, const float *bias, const 
     return hipGetLastError();
 }
 
-__device__ __forceinline__ float gelu_erf(float v) {       // nn.GELU() default (smokephys_net.py:155)
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+// nn.GELU() default (smokephys_net.py:155): 0.5 v (1 + erf(v / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// i.e. ~1e-7 of |v| on the result -- far inside the 1e-4 parity bar) in ~15 VALU instructions; the library erff costs
+// about as much as the tile's MFMAs in the 512 -> 2048 layer.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
+    const float erf_abs = fmaf(-(p * t), e, 1.0f);
+    return 0.5f * v * (1.0f + copysignf(erf_abs, v));
 }
 
 struct LinearArgs {
     LinearDev l;
     LinearCall c;
     int tiles_m, tiles_n;
+    int swz, stagger, num_cu;
+    int dbg;              // timing ablations (SMK_LINEAR_DBG; results are wrong when non-zero): 1 A loads re-read tile 0,
+                          // 2 B ring re-reads k-step 0, 4 no epilogue
 };
 
 template <int MB, int ACT>
 __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
+    constexpr bool sched = SMK_LINEAR_SCHED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TM = MB * 32, PLANE = ln_plane_bytes<MB>();
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.l.K, N = a.l.N, M = a.c.M;
     const int nchunks = K >> 6, nks = K >> 4;
-    const int tn = blockIdx.x % a.tiles_n;                   // fixed for the life of the workgroup (gridDim.x % tiles_n == 0)
+    // Workgroups are dealt to the 8 XCDs round-robin (id % 8).  vid renumbers them so that one XCD holds a contiguous id range:
+    // the tiles_n workgroups that share a row block (the same A rows) then run on ONE XCD at the same time and A is fetched
+    // from HBM once (L2 hits for the others) instead of once per XCD.  (gridDim.x % (8 * tiles_n) == 0 or swz == 0.)
+    const int vid = a.swz ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int tn = vid % a.tiles_n;                          // fixed for the life of the workgroup (gridDim.x % tiles_n == 0)
     const int tm_step = gridDim.x / a.tiles_n;
-    int tm = blockIdx.x / a.tiles_n;
+    int tm = vid / a.tiles_n;
+    // Two workgroups share a CU and run the same program with the same period: delay every other dispatch round by about
+    // half a tile so that one's epilogue / staging stalls overlap the other's MFMA stretch (speed only).
+    if (a.stagger > 0 && ((blockIdx.x / a.num_cu) & 1))
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     const int n = tn * 128 + wave * 32 + r;                  // this lane's output column
     const bool n_ok = n < N;
 
@@ -77,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.l.wq), 0, K * N * 4, 0x00020000);
     const int frag_bytes = N * 32;                           // one (k-step, part) plane
     auto load_b = [&](int kn, int part) -> uint4 {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (kn * 2 + part) * frag_bytes, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (((a.dbg & 2) ? 0 : kn) * 2 + part) * frag_bytes, 0);
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
     uint4 bqh[LN_RING], bql[LN_RING];
@@ -90,37 +116,46 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     // ---- A staging: thread = float4 column sc of rows sr, sr+16, ... of the 32*MB x 64 chunk (a wave reads 4 full 256-B rows)
     const int sc = tid & 15, sr = tid >> 4;
     float4 stage[2 * MB];
-    auto stage_load = [&](int tmx, int cx) {
-#pragma unroll
-        for (int j = 0; j < 2 * MB; ++j) {
-            const long long row = (long long)tmx * TM + sr + 16 * j;
-            stage[j] = row < M ? *reinterpret_cast<const float4 *>(a.c.x + row * a.c.ldx + cx * 64 + sc * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    auto stage_load = [&](int tmx, int cx, int j) {
+        // rows past M (ragged last tile, or the chunk stream running past this workgroup's last tile) are clamped, not
+        // predicated: their products land in accumulator rows that are never stored, and a predicated load would split the
+        // k-step into basic blocks and undo the MFMA / staging interleave below
+        long long row = (long long)((a.dbg & 1) ? 0 : tmx) * TM + sr + 16 * j;
+        row = row < M ? row : M - 1;
+        stage[j] = *reinterpret_cast<const float4 *>(a.c.x + row * a.c.ldx + cx * 64 + sc * 4);
     };
-    auto stage_store = [&](int buf) {
-        unsigned char *ph = smem + buf * 2 * PLANE + sr * LN_PITCH + sc * 8, *pl = ph + PLANE;
+    auto stage_store = [&](int buf, int j) {
+        unsigned char *ph = smem + buf * 2 * PLANE + (sr + 16 * j) * LN_PITCH + sc * 8;
+        const float v[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
+        bf16x4 vh, vl;
 #pragma unroll
-        for (int j = 0; j < 2 * MB; ++j) {
-            const float v[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
-            bf16x4 vh, vl;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const __bf16 h = (__bf16)v[i];
-                vh[i] = h;
-                vl[i] = (__bf16)(v[i] - (float)h);
-            }
-            *reinterpret_cast<bf16x4 *>(ph + 16 * j * LN_PITCH) = vh;
-            *reinterpret_cast<bf16x4 *>(pl + 16 * j * LN_PITCH) = vl;
+        for (int i = 0; i < 4; ++i) {
+#ifdef SMK_LN_NOCONV      /* timing-only build: no split arithmetic (wrong results) */
+            vh[i] = __builtin_bit_cast(__bf16, (unsigned short)(__builtin_bit_cast(unsigned, v[i]) >> 16));
+            vl[i] = vh[i];
+#else
+            const __bf16 h = (__bf16)v[i];
+            vh[i] = h;
+            vl[i] = (__bf16)(v[i] - (float)h);
+#endif
         }
+        *reinterpret_cast<bf16x4 *>(ph) = vh;
+        *reinterpret_cast<bf16x4 *>(ph + PLANE) = vl;
     };
     // the chunk stream: (tile row, chunk) pairs in the order this workgroup consumes them; rows past M read as zeros
     int ld_tm = tm, ld_c = 0;
     auto advance = [&]() {
         if (++ld_c == nchunks) { ld_c = 0; ld_tm += tm_step; }
     };
-    stage_load(ld_tm, ld_c); advance();
-    stage_store(0);
-    stage_load(ld_tm, ld_c); advance();
+#pragma unroll
+    for (int j = 0; j < 2 * MB; ++j) stage_load(ld_tm, ld_c, j);
+    advance();
+#pragma unroll
+    for (int j = 0; j < 2 * MB; ++j) {
+        stage_store(0, j);
+        stage_load(ld_tm, ld_c, j);
+    }
+    advance();
     __syncthreads();
 
     const int frag_off = r * LN_PITCH + hi * 16;
@@ -135,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     bf16x8 ahA[MB], alA[MB], ahB[MB], alB[MB];
     int buf = 0;
     load_a(0, 0, ahA, alA);
-    const float bias = n_ok ? a.l.bias[n] : 0.f;
+    const bool nw_ok = tn * 128 + wave * 32 < N;
+    float *bias_s = reinterpret_cast<float *>(smem + 4 * PLANE);       // this workgroup's 128 bias values
+    if (tid < 128) bias_s[tid] = tn * 128 + tid < N ? a.l.bias[tn * 128 + tid] : 0.f;   // visible after the first barrier below             // N % 32 == 0: a wave's 32 columns are all inside or all outside
 
     for (; tm < a.tiles_m; tm += tm_step) {
         f32x16 acc[MB];
@@ -155,12 +192,20 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
                     bqh[(u + LN_RING - 1) % LN_RING] = load_b(kn, 0);
                     bql[(u + LN_RING - 1) % LN_RING] = load_b(kn, 1);
                 }
-                if (u == 0) {   // the staged registers hold the chunk after this one: split + write it to the other buffer
-                    stage_store(buf ^ 1);        // (last read before the previous chunk's barrier), then refill them
-                    stage_load(ld_tm, ld_c);
-                    advance();
+                if (u < 2) {
+                    // the staged registers hold the chunk after this one: split + write half of it per k-step to the other
+                    // buffer (last read before the previous chunk's barrier) and re-issue each piece's load at once for
+                    // the chunk after that (4 k-steps of MFMAs to land)
+#pragma unroll
+                    for (int j = u * MB; j < (u + 1) * MB; ++j) {
+                        stage_store(buf ^ 1, j);
+                        stage_load(ld_tm, ld_c, j);
+                    }
+                    if (u == 1) advance();
                 }
+#ifndef SMK_LN_NOBAR
                 if (u == 3) __syncthreads();     // other buffer complete and visible; every read of this buffer has returned
+#endif
                 if (u & 1) load_a(u == 3 ? buf ^ 1 : buf, (u + 1) & 3, ahA, alA);
                 else load_a(buf, u + 1, ahB, alB);
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, bqh[u]);
@@ -168,49 +213,88 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < MB; ++mi) {
                     if (u & 1) {
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alB[mi], bh, acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahB[mi], bl, acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahB[mi], bh, acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, alB[mi], acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ahB[mi], acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ahB[mi], acc[mi], 0, 0, 0);
                     } else {
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alA[mi], bh, acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahA[mi], bl, acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahA[mi], bh, acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, alA[mi], acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ahA[mi], acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ahA[mi], acc[mi], 0, 0, 0);
                     }
+                }
+                // Schedule of one k-step: next k-step's fragment reads, the ring refill and (k-steps 0,1) the staging work are
+                // issued INSIDE the gaps of this k-step's MFMAs (left alone, hipcc sinks every ds_read to just before its
+                // consumer and waits on it there).
+                if (sched) {
+                    constexpr int NMF = 3 * MB, NDS = 2 * MB;
+#pragma unroll
+                    for (int i = 0; i < NMF; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
+                        if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // 1 DS read
+                        else if (i < NDS + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 1 VMEM read (ring)
+                        if (u < 2) {
+                            if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);         // split arithmetic
+                            else {
+                                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                  // 2 DS writes
+                                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  // 1 staged global load
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             buf ^= 1;
         }
 
-        // ---- epilogue.  acc[mi][g]: row (g&3) + 8(g>>2) + 4hi of row block mi, column n
-        if (n_ok) {
-            const int row0 = tm * TM;
-            const float *padd = nullptr;
-            int ph0 = 0;
-            float inv_period = 0.f;
-            if (a.c.padd) {                                  // a tile lies inside one group (launcher: rows_per_group % TM == 0)
-                const int grp = row0 / a.c.rows_per_group;
-                ph0 = row0 - grp * a.c.rows_per_group;
-                padd = a.c.padd + (size_t)grp * a.c.period * N + n;
-                inv_period = 1.0f / (float)a.c.period;
-            }
+        // ---- epilogue.  The weights are the MFMA's row operand, so acc[mi][4q + i] = output row mi*32 + r (this lane's token),
+        //      column 8q + 4hi + i of the wave's 32: four consecutive columns per lane -> 16-byte loads and stores.
+        if (nw_ok && !(a.dbg & 4)) {
+            const int row0 = tm * TM, ncol = tn * 128 + wave * 32 + 4 * hi;
+            const float *bias_w = bias_s + wave * 32 + 4 * hi;
+            // Global loads (residual, periodic addend) of row block mi+1 are issued BEFORE the stores of block mi: vmcnt retires in
+            // order, so a load issued after a store could only be consumed once that store had been acknowledged by memory.
+            float4 ex[2][4];                                 // per column group: residual (+ addend) of the block being finished
+            const bool any_ex = a.c.res || a.c.padd;
+            auto fetch_extra = [&](int mi, float4 (&e)[4]) {
+                const int row = row0 + mi * 32 + r;
 #pragma unroll
-            for (int mi = 0; mi < MB; ++mi)
+                for (int q = 0; q < 4; ++q) e[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row >= M) return;
+                if (a.c.padd) {                              // a tile lies inside one group (launcher: rows_per_group % TM == 0)
+                    const int grp = row0 / a.c.rows_per_group;
+                    const int xx = row - grp * a.c.rows_per_group;                      // (row in group) mod period, no integer division
+                    int ph = xx - (int)((float)xx * (1.0f / (float)a.c.period)) * a.c.period;
+                    ph = ph < 0 ? ph + a.c.period : (ph >= a.c.period ? ph - a.c.period : ph);
+                    const float *pp = a.c.padd + ((size_t)grp * a.c.period + ph) * N + ncol;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int lr = mi * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi, row = row0 + lr;
-                    if (row < M) {
-                        float v = acc[mi][g] + bias;
-                        if (padd) {                          // (ph0 + lr) mod period without an integer division
-                            const int xx = ph0 + lr;
-                            int ph = xx - (int)((float)xx * inv_period) * a.c.period;
-                            ph = ph < 0 ? ph + a.c.period : (ph >= a.c.period ? ph - a.c.period : ph);
-                            v += padd[(size_t)ph * N];
-                        }
-                        if (ACT == 1) v = gelu_erf(v);
-                        if (a.c.res) v = a.c.res[(long long)row * a.c.ldr + n] + v;
-                        a.c.y[(long long)row * a.c.ldy + n] = v;
-                    }
+                    for (int q = 0; q < 4; ++q) e[q] = *reinterpret_cast<const float4 *>(pp + 8 * q);
+                } else {
+                    const float *rp = a.c.res + (long long)row * a.c.ldr + ncol;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e[q] = *reinterpret_cast<const float4 *>(rp + 8 * q);
                 }
+            };
+            if (any_ex) fetch_extra(0, ex[0]);
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) {
+                if (any_ex && mi + 1 < MB) fetch_extra(mi + 1, ex[(mi + 1) & 1]);
+                const int row = row0 + mi * 32 + r;
+                float *yp = a.c.y + (long long)row * a.c.ldy + ncol;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bq = *reinterpret_cast<const float4 *>(bias_w + 8 * q);
+                    const float4 eq = ex[mi & 1][q];
+                    float v[4] = {acc[mi][4 * q] + bq.x, acc[mi][4 * q + 1] + bq.y, acc[mi][4 * q + 2] + bq.z, acc[mi][4 * q + 3] + bq.w};
+                    if (a.c.padd) { v[0] += eq.x; v[1] += eq.y; v[2] += eq.z; v[3] += eq.w; }
+                    if (ACT == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+                    }
+                    if (a.c.res && !a.c.padd) { v[0] = eq.x + v[0]; v[1] = eq.y + v[1]; v[2] = eq.z + v[2]; v[3] = eq.w + v[3]; }
+                    if (row < M) *reinterpret_cast<float4 *>(yp + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
         }
     }
 }
@@ -228,8 +312,14 @@ static hipError_t launch_mb(const LinearArgs &a, int nwg_max, hipStream_t st) {
     long long nwg = tiles < nwg_max ? tiles : nwg_max;
     nwg -= nwg % a.tiles_n;                               // every workgroup keeps one column tile
     if (nwg < a.tiles_n) nwg = a.tiles_n;
-    if (a.c.act == 1) hipLaunchKernelGGL((k_linear_x3<MB, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_linear_x3<MB, 0>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    LinearArgs b = a;
+    static int swz_env = -1, stg_env = -1;
+    if (swz_env < 0) { const char *s = getenv("SMK_LINEAR_SWZ"); swz_env = s ? atoi(s) : 1; }
+    if (stg_env < 0) { const char *s = getenv("SMK_LINEAR_STAGGER"); stg_env = s ? atoi(s) : 1; }
+    b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
+    b.stagger = nwg > b.num_cu ? stg_env : 0;
+    if (a.c.act == 1) hipLaunchKernelGGL((k_linear_x3<MB, 1>), dim3((unsigned)nwg), dim3(256), lds, st, b);
+    else hipLaunchKernelGGL((k_linear_x3<MB, 0>), dim3((unsigned)nwg), dim3(256), lds, st, b);
     return hipGetLastError();
 }
 
@@ -245,6 +335,12 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     a.l = l;
     a.c = c;
     a.tiles_n = cdiv(l.N, 128);
+    static int dbg = -1;
+    if (dbg < 0) { const char *s = getenv("SMK_LINEAR_DBG"); dbg = s ? atoi(s) : 0; }
+    a.dbg = dbg;
+    a.num_cu = num_cu;
+    a.swz = 0;
+    a.stagger = 0;
     // row-block count per tile: the largest that still gives every CU about two workgroups (small M: finer tiles)
     static int force_mb = -1;
     if (force_mb < 0) { const char *s = getenv("SMK_LINEAR_MB"); force_mb = s ? atoi(s) : 0; }
