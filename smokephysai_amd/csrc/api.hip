@@ -520,6 +520,7 @@ int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ld
     SMK_REQUIRE(lin && x && y, "null lin/x/y");
     SMK_REQUIRE(rows >= 1 && rows < (1LL << 31) - 256, "1 <= rows < 2^31 - 256");
     SMK_REQUIRE(ldx >= lin->l.K && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "x rows: pitch >= in_features, 16-byte aligned");
+    SMK_REQUIRE((rows + 256) * ldx < (1LL << 30), "x: (rows + 256) * ldx < 2^30 floats (32-bit buffer offsets)");
     SMK_REQUIRE(ldy >= lin->l.N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0, "y rows: pitch >= out_features, 16-byte aligned");
     SMK_REQUIRE(!residual || (ldr >= lin->l.N && ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0),
                 "residual rows: pitch >= out_features, 16-byte aligned");

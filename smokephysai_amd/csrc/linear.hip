@@ -13,6 +13,8 @@
 // 1 KiB buffer loads; every workgroup keeps one column tile for its whole life, so the ring never restarts.
 // One barrier per chunk, placed before the chunk's LAST k-step: the next chunk's first fragments are read under that
 // k-step's MFMAs and the matrix pipe never waits on the barrier + LDS latency.
+#include <type_traits>
+
 #include "linear.h"
 
 namespace smk {
@@ -65,11 +67,16 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.0f + copysignf(erf_abs, v));
 }
 
+#ifdef SMK_LN_STAMPS      /* diagnostic build only (tools/README.md): s_memtime phase stamps into a debug buffer */
+#define LN_STAMP(v) unsigned long long v; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define LN_RSTAMP(v) unsigned long long v; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#endif
 struct LinearArgs {
     LinearDev l;
     LinearCall c;
     int tiles_m, tiles_n;
     int swz, stagger, num_cu;
+    unsigned long long *stamps;
     int dbg;              // timing ablations (SMK_LINEAR_DBG; results are wrong when non-zero): 1 A loads re-read tile 0,
                           // 2 B ring re-reads k-step 0, 4 no epilogue
 };
@@ -116,13 +123,20 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     // ---- A staging: thread = float4 column sc of rows sr, sr+16, ... of the 32*MB x 64 chunk (a wave reads 4 full 256-B rows)
     const int sc = tid & 15, sr = tid >> 4;
     float4 stage[2 * MB];
+    // x through a buffer resource: a row past M (ragged last tile, or the chunk stream running past this workgroup's last
+    // tile) is out of range and reads as zero in hardware -- no clamp, no predicate (either would cost VALU issue slots or
+    // split the k-step into basic blocks and undo the MFMA / staging interleave below).  One v_add per load: the offset
+    // must sit in the VGPR operand to be range-checked.
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.c.x), 0, (int)(((long long)(M - 1) * a.c.ldx + K) * 4), 0x00020000);
+    const int ldxb = (int)a.c.ldx * 4;
+    const int lane_x = sr * ldxb + sc * 16;
     auto stage_load = [&](int tmx, int cx, int j) {
-        // rows past M (ragged last tile, or the chunk stream running past this workgroup's last tile) are clamped, not
-        // predicated: their products land in accumulator rows that are never stored, and a predicated load would split the
-        // k-step into basic blocks and undo the MFMA / staging interleave below
-        long long row = (long long)((a.dbg & 1) ? 0 : tmx) * TM + sr + 16 * j;
-        row = row < M ? row : M - 1;
-        stage[j] = *reinterpret_cast<const float4 *>(a.c.x + row * a.c.ldx + cx * 64 + sc * 4);
+        const unsigned row_u = (unsigned)((a.dbg & 1) ? 0 : tmx) * TM + 16 * j;          // wave-uniform part (SALU); tmx <= tiles_m
+        const unsigned off = row_u * (unsigned)ldxb + (unsigned)cx * 256u;                // < 2^32: api.hip bounds (rows + 256) * ldx
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
+        // (not __builtin_bit_cast(float, v[i]): hipcc 7.2 then emits a 1-dword load and leaves v[1..3] undefined)
+        stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     auto stage_store = [&](int buf, int j) {
         unsigned char *ph = smem + buf * 2 * PLANE + (sr + 16 * j) * LN_PITCH + sc * 8;
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     // the chunk stream: (tile row, chunk) pairs in the order this workgroup consumes them; rows past M read as zeros
     int ld_tm = tm, ld_c = 0;
     auto advance = [&]() {
-        if (++ld_c == nchunks) { ld_c = 0; ld_tm += tm_step; }
+        if (++ld_c == nchunks) { ld_c = 0; ld_tm = ld_tm + tm_step < a.tiles_m ? ld_tm + tm_step : a.tiles_m; }   // past the end: row >= M
     };
 #pragma unroll
     for (int j = 0; j < 2 * MB; ++j) stage_load(ld_tm, ld_c, j);
@@ -174,7 +188,15 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     float *bias_s = reinterpret_cast<float *>(smem + 4 * PLANE);       // this workgroup's 128 bias values
     if (tid < 128) bias_s[tid] = tn * 128 + tid < N ? a.l.bias[tn * 128 + tid] : 0.f;   // visible after the first barrier below             // N % 32 == 0: a wave's 32 columns are all inside or all outside
 
+#ifdef SMK_LN_STAMPS
+    unsigned long long sum_k = 0, sum_e = 0, ntl = 0, sum_u[5] = {0, 0, 0, 0, 0}, t_prev = 0;
+    LN_STAMP(t_begin);
+    LN_RSTAMP(r_begin);
+#endif
     for (; tm < a.tiles_m; tm += tm_step) {
+#ifdef SMK_LN_STAMPS
+        LN_STAMP(t_k0);
+#endif
         f32x16 acc[MB];
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
@@ -183,8 +205,14 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
 
 #pragma unroll 1
         for (int c = 0; c < nchunks; ++c) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            auto kstep = [&](auto U) {
+                constexpr int u = decltype(U)::value;
+#ifdef SMK_LN_STAMPS
+                LN_STAMP(t_u);
+                if (u > 0) sum_u[u - 1] += t_u - t_prev;
+                else if (c > 0) sum_u[3] += t_u - t_prev;
+                t_prev = t_u;
+#endif
                 {   // refill the ring slot consumed one k-step ago (k index wraps: the next tile uses the same weights)
                     int kn = c * 4 + u + LN_RING - 1;
                     kn = kn >= nks ? kn - nks : kn;
@@ -192,19 +220,23 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
                     bqh[(u + LN_RING - 1) % LN_RING] = load_b(kn, 0);
                     bql[(u + LN_RING - 1) % LN_RING] = load_b(kn, 1);
                 }
-                if (u < 2) {
-                    // the staged registers hold the chunk after this one: split + write half of it per k-step to the other
-                    // buffer (last read before the previous chunk's barrier) and re-issue each piece's load at once for
-                    // the chunk after that (4 k-steps of MFMAs to land)
+                // The staged registers hold the chunk after this one: k-steps 0..2 each split + write a share of its 2*MB
+                // pieces to the other buffer (last read before the previous chunk's barrier; complete before this chunk's) and
+                // re-issue each piece's load at once for the chunk after that (a whole chunk of MFMAs to land).
+                constexpr int NP = 2 * MB, P0 = (NP * 3 + 7) / 8, P1 = (NP * 6 + 7) / 8;      // MB = 4: pieces 0-2 | 3-5 | 6-7
+                constexpr int pbeg = u == 0 ? 0 : u == 1 ? P0 : u == 2 ? P1 : NP, pend = u == 0 ? P0 : u == 1 ? P1 : NP;
 #pragma unroll
-                    for (int j = u * MB; j < (u + 1) * MB; ++j) {
-                        stage_store(buf ^ 1, j);
-                        stage_load(ld_tm, ld_c, j);
-                    }
-                    if (u == 1) advance();
+                for (int j = pbeg; j < pend; ++j) {
+                    stage_store(buf ^ 1, j);
+                    stage_load(ld_tm, ld_c, j);
                 }
+                if (u == 2) advance();
+#ifdef SMK_LN_STAMPS
+                if (u == 3) { LN_STAMP(t_b0); __syncthreads(); LN_STAMP(t_b1); sum_u[4] += t_b1 - t_b0; }
+#else
 #ifndef SMK_LN_NOBAR
                 if (u == 3) __syncthreads();     // other buffer complete and visible; every read of this buffer has returned
+#endif
 #endif
                 if (u & 1) load_a(u == 3 ? buf ^ 1 : buf, (u + 1) & 3, ahA, alA);
                 else load_a(buf, u + 1, ahB, alB);
@@ -226,27 +258,34 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
                 // issued INSIDE the gaps of this k-step's MFMAs (left alone, hipcc sinks every ds_read to just before its
                 // consumer and waits on it there).
                 if (sched) {
-                    constexpr int NMF = 3 * MB, NDS = 2 * MB;
+                    // per SIMD an MFMA gap hides about five other vector-issue slots (MI355X_MICROARCH.md, constants table), shared
+                    // by the two resident waves: the split arithmetic is spread at ~12 VALU per piece over the k-step's gaps
+                    constexpr int NMF = 3 * MB, NDS = 2 * MB, NPC = pend - pbeg;
+                    constexpr int VPER = NPC ? (14 * NPC + NMF - 1) / NMF : 0;
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
-                        if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // 1 DS read
-                        else if (i < NDS + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 1 VMEM read (ring)
-                        if (u < 2) {
-                            if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);         // split arithmetic
-                            else {
-                                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                  // 2 DS writes
-                                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  // 1 staged global load
-                            }
+                        if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // 1 DS read (next k-step's fragment)
+                        if (VPER) __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);             // split arithmetic
+                        if (i >= NMF - NPC) {
+                            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                      // a finished piece: 2 DS writes
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      //   + its re-issued load
                         }
+                        if (i >= NMF - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // ring refill
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            };
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+            kstep(std::integral_constant<int, 2>{});
+            kstep(std::integral_constant<int, 3>{});
             buf ^= 1;
         }
 
+#ifdef SMK_LN_STAMPS
+        LN_STAMP(t_k1);
+#endif
         // ---- epilogue.  The weights are the MFMA's row operand, so acc[mi][4q + i] = output row mi*32 + r (this lane's token),
         //      column 8q + 4hi + i of the wave's 32: four consecutive columns per lane -> 16-byte loads and stores.
         if (nw_ok && !(a.dbg & 4)) {
@@ -296,7 +335,19 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
                 }
             }
         }
+#ifdef SMK_LN_STAMPS
+        LN_STAMP(t_e);
+        sum_k += t_k1 - t_k0; sum_e += t_e - t_k1; ++ntl;
+#endif
     }
+#ifdef SMK_LN_STAMPS
+    LN_STAMP(t_end);
+    LN_RSTAMP(r_end);
+    if (a.stamps && lane == 0) {
+        unsigned long long *rec = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        rec[0] = sum_k; rec[1] = sum_e; rec[2] = t_end - t_begin; rec[3] = r_end - r_begin; rec[4] = ntl; rec[5] = sum_u[0] | (sum_u[1] << 32); rec[6] = sum_u[2] | (sum_u[3] << 32); rec[7] = sum_u[4];
+    }
+#endif
 }
 
 template <int MB>
@@ -315,7 +366,7 @@ static hipError_t launch_mb(const LinearArgs &a, int nwg_max, hipStream_t st) {
     LinearArgs b = a;
     static int swz_env = -1, stg_env = -1;
     if (swz_env < 0) { const char *s = getenv("SMK_LINEAR_SWZ"); swz_env = s ? atoi(s) : 1; }
-    if (stg_env < 0) { const char *s = getenv("SMK_LINEAR_STAGGER"); stg_env = s ? atoi(s) : 1; }
+    if (stg_env < 0) { const char *s = getenv("SMK_LINEAR_STAGGER"); stg_env = s ? atoi(s) : 0; }
     b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
     b.stagger = nwg > b.num_cu ? stg_env : 0;
     if (a.c.act == 1) hipLaunchKernelGGL((k_linear_x3<MB, 1>), dim3((unsigned)nwg), dim3(256), lds, st, b);
@@ -338,6 +389,13 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     static int dbg = -1;
     if (dbg < 0) { const char *s = getenv("SMK_LINEAR_DBG"); dbg = s ? atoi(s) : 0; }
     a.dbg = dbg;
+    a.stamps = nullptr;
+#ifdef SMK_LN_STAMPS
+    static unsigned long long *stamp_buf = nullptr;
+    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, 8 * 8 * 4096);
+    (void)hipMemsetAsync(stamp_buf, 0, 8 * 8 * 4096, st);
+    a.stamps = stamp_buf;
+#endif
     a.num_cu = num_cu;
     a.swz = 0;
     a.stagger = 0;
@@ -351,11 +409,30 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     if (c.padd && c.rows_per_group % (32 * mb) != 0) return hipErrorInvalidValue;   // api.hip checks rows_per_group % 32 == 0
     a.tiles_m = cdiv(c.M, 32 * mb);
     const int nwg_max = 2 * num_cu;
+#ifdef SMK_LN_STAMPS
+    {   // diagnostic: run, wait, print the per-wave averages (cycles per tile; clock = core cycles / 100 MHz real-time ticks)
+        hipError_t e = mb == 4 ? launch_mb<4>(a, nwg_max, st) : mb == 2 ? launch_mb<2>(a, nwg_max, st) : launch_mb<1>(a, nwg_max, st);
+        if (getenv("SMK_LN_STAMPS_PRINT")) {
+            static unsigned long long h[8 * 4096];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
+            double k = 0, ep = 0, tot = 0, real = 0, nt = 0, us[5] = {0, 0, 0, 0, 0}; int n = 0;
+            for (int w = 0; w < 4096; ++w) if (h[w * 8 + 4]) { ++n; k += h[w*8]; ep += h[w*8+1]; tot += h[w*8+2]; real += h[w*8+3]; nt += h[w*8+4];
+                us[0] += h[w*8+5] & 0xffffffffULL; us[1] += h[w*8+5] >> 32; us[2] += h[w*8+6] & 0xffffffffULL; us[3] += h[w*8+6] >> 32; us[4] += h[w*8+7]; }
+            const double nch = nt * (l.K / 64);
+            if (n) fprintf(stderr, "LN_KSTEPS per chunk: k0 %.0f k1 %.0f k2 %.0f k3(incl barrier) %.0f barrier %.0f\n", us[0] / nch, us[1] / nch, us[2] / nch, us[3] / nch, us[4] / nch);
+            if (n) fprintf(stderr, "LN_STAMPS M=%d K=%d N=%d mb=%d waves=%d tiles/wave=%.1f | per tile: kloop %.0f epilogue %.0f | wave total %.0f cyc = %.1f us, clock %.0f MHz\n",
+                           c.M, l.K, l.N, mb, n, nt / n, k / nt, ep / nt, tot / n, real / n / 100.0, tot / real * 100.0);
+        }
+        return e;
+    }
+#endif
     switch (mb) {
         case 4: return launch_mb<4>(a, nwg_max, st);
         case 2: return launch_mb<2>(a, nwg_max, st);
-        default: return launch_mb<1>(a, nwg_max, st);
+        default: break;
     }
+    return launch_mb<1>(a, nwg_max, st);
 }
 
 }  // namespace smk
