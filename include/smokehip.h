@@ -171,7 +171,7 @@ int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_strid
  * weight [out_features][in_features] fp32 (PyTorch layout), bias [out_features] or NULL; both are read once, on `stream`.
  * Requires in_features % 64 == 0 and out_features % 32 == 0 (else SMK_ERR_UNSUPPORTED). */
 typedef struct smk_linear smk_linear;
-typedef enum smk_activation { SMK_ACT_NONE = 0, SMK_ACT_GELU = 1 /* erf form, nn.GELU() */ } smk_activation;
+typedef enum smk_activation { SMK_ACT_NONE = 0, SMK_ACT_GELU = 1 /* erf form, nn.GELU() */, SMK_ACT_RELU = 2 } smk_activation;
 
 int smk_linear_create(const float *weight, const float *bias, int32_t out_features, int32_t in_features,
                       int32_t device_id, void *stream, smk_linear **out);

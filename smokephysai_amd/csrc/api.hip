@@ -525,7 +525,7 @@ int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ld
     SMK_REQUIRE(!residual || (ldr >= lin->l.N && ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0),
                 "residual rows: pitch >= out_features, 16-byte aligned");
     SMK_REQUIRE(!periodic_add || ((uintptr_t)periodic_add & 15) == 0, "periodic_add 16-byte aligned");
-    SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_GELU, "activation");
+    SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_GELU || activation == SMK_ACT_RELU, "activation");
     SMK_REQUIRE(!(residual && periodic_add), "residual and periodic_add are exclusive (no layer of the path needs both)");
     if (periodic_add)
         SMK_REQUIRE(period >= 1 && rows_per_group >= 32 && rows_per_group % 32 == 0 && rows % rows_per_group == 0,

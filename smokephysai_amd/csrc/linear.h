@@ -17,7 +17,7 @@ struct LinearCall {
     const float *padd;                    // optional row-periodic addend [M / rows_per_group][period][N], added before the activation
     int rows_per_group, period;
     int M;
-    int act;                              // 0 none, 1 GELU (erf form)
+    int act;                              // 0 none, 1 GELU (erf form), 2 ReLU
 };
 
 hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st);

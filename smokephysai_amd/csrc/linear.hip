@@ -81,7 +81,7 @@ struct LinearArgs {
                           // 2 B ring re-reads k-step 0, 4 no epilogue
 };
 
-template <int MB, int ACT>
+template <int MB>
 __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     constexpr bool sched = SMK_LINEAR_SCHED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -326,9 +326,12 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
                     const float4 eq = ex[mi & 1][q];
                     float v[4] = {acc[mi][4 * q] + bq.x, acc[mi][4 * q + 1] + bq.y, acc[mi][4 * q + 2] + bq.z, acc[mi][4 * q + 3] + bq.w};
                     if (a.c.padd) { v[0] += eq.x; v[1] += eq.y; v[2] += eq.z; v[3] += eq.w; }
-                    if (ACT == 1) {
+                    if (a.c.act == 1) {                       // wave-uniform, epilogue only
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+                    } else if (a.c.act == 2) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
                     }
                     if (a.c.res && !a.c.padd) { v[0] = eq.x + v[0]; v[1] = eq.y + v[1]; v[2] = eq.z + v[2]; v[3] = eq.w + v[3]; }
                     if (row < M) *reinterpret_cast<float4 *>(yp + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
@@ -355,8 +358,7 @@ static hipError_t launch_mb(const LinearArgs &a, int nwg_max, hipStream_t st) {
     constexpr int lds = ln_lds_bytes<MB>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
@@ -369,8 +371,7 @@ static hipError_t launch_mb(const LinearArgs &a, int nwg_max, hipStream_t st) {
     if (stg_env < 0) { const char *s = getenv("SMK_LINEAR_STAGGER"); stg_env = s ? atoi(s) : 0; }
     b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
     b.stagger = nwg > b.num_cu ? stg_env : 0;
-    if (a.c.act == 1) hipLaunchKernelGGL((k_linear_x3<MB, 1>), dim3((unsigned)nwg), dim3(256), lds, st, b);
-    else hipLaunchKernelGGL((k_linear_x3<MB, 0>), dim3((unsigned)nwg), dim3(256), lds, st, b);
+    hipLaunchKernelGGL((k_linear_x3<MB>), dim3((unsigned)nwg), dim3(256), lds, st, b);
     return hipGetLastError();
 }
 

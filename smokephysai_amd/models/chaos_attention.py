@@ -62,15 +62,19 @@ class ChaosAttention(nn.Module):
         reps = (seq_len + field.size(1) - 1) // field.size(1)
         return field.repeat(1, reps, 1)[:, :seq_len, :]
 
+    def chaos_addend(self, batch_size: int, device, dtype, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The chaos term folded into Q, on the 5 distinct rows of the tiled Lorenz field: chaos_strength * gate(C) * C with
+        C = chaos_proj(field) (chaos_attention.py:85-100).  [B,5,D]; row l of the sequence receives row l % 5."""
+        c5 = self.chaos_proj(self.chaos_states(batch_size, device, noise).to(dtype))
+        return self.chaos_strength * torch.sigmoid(self.chaos_gate(c5)) * c5
+
     def forward(self, x: torch.Tensor, mask: torch.Tensor = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, L, D = x.shape
         H, d = self.num_heads, self.head_dim
         q = self.q_proj(x)
         k = self.k_proj(x).view(B, L, H, d).transpose(1, 2)
         v = self.v_proj(x).view(B, L, H, d).transpose(1, 2)
-        # chaos features on the 5 distinct rows, gate, fold into Q (chaos_attention.py:85-100)
-        c5 = self.chaos_proj(self.chaos_states(B, x.device, noise).to(x.dtype))      # [B,5,D]
-        add5 = self.chaos_strength * torch.sigmoid(self.chaos_gate(c5)) * c5         # [B,5,D]
+        add5 = self.chaos_addend(B, x.device, x.dtype, noise)                        # [B,5,D]
         reps = (L + 4) // 5
         q = (q + add5.repeat(1, reps, 1)[:, :L]).view(B, L, H, d).transpose(1, 2)
         attn_mask = None

@@ -51,10 +51,9 @@ class GraphedSmokePhysNet:
                  encoder_dtype: Optional[str] = None) -> dict:
         if self.model.training:
             raise RuntimeError("GraphedSmokePhysNet replays the eval forward; call model.eval() first")
-        # the encoder's folded weights and the resized pos-embedding live outside the parameter tensors the graph reads,
+        # the encoder's folded weights, the split linear weights and the resized pos-embedding live outside the parameter tensors the graph reads,
         # so a weight update (load_state_dict, an optimizer step) invalidates what was captured
-        pe = self.model.pos_embedding
-        weights_now = (self.model._encoder_fingerprint(), pe.data_ptr(), pe._version)
+        weights_now = self.model.hip_weights_fingerprint()
         if weights_now != self._weights_seen:
             self._graphs.clear()
             self._weights_seen = weights_now

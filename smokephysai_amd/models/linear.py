@@ -78,7 +78,7 @@ class HipLinear:
             if pa.dim() != 3 or pa.shape[2] != self.out_features or pa.shape[0] * rpg != rows:
                 raise ValueError("HipLinear: periodic_add must be [rows / rows_per_group, period, out_features]")
             pa_ptr, period = pa.data_ptr(), pa.shape[1]
-        act = {None: _lib.SMK_ACT_NONE, "none": _lib.SMK_ACT_NONE, "gelu": _lib.SMK_ACT_GELU}[activation]
+        act = {None: _lib.SMK_ACT_NONE, "none": _lib.SMK_ACT_NONE, "gelu": _lib.SMK_ACT_GELU, "relu": _lib.SMK_ACT_RELU}[activation]
         _lib.check(self._L.smk_linear_forward(self._handle, x2.data_ptr(), rows, x2.stride(0), y2.data_ptr(),
                                               y2.stride(0), res_ptr, ldr, pa_ptr, rpg, period, act,
                                               _lib.stream_ptr(self._dev)))

@@ -2,11 +2,14 @@
 state_dict keys, so a reference best_model.pth loads unchanged).
 
 Inference (eval mode): frames go through the fused HIP encoder (csrc/encoder.hip: conv7x7+BN+ReLU, conv3x3+BN+ReLU
-on MFMA, both adaptive pools as one block mean) -- there is no CPU fallback for it.  The transformer body and the heads
-run as PyTorch-ROCm ops (hipBLASLt GEMMs + fused SDPA with the chaos term folded into Q).
+on MFMA, both adaptive pools as one block mean) -- there is no CPU fallback for it.  The token-wise linear layers of the
+transformer body (feature_proj, q/k/v/out projections, FFN, output_decoder) run on libsmokehip's split-bf16 MFMA kernel
+(csrc/linear.hip) with bias / pos-embedding / chaos-term / GELU / residual fused into the GEMM epilogue; LayerNorm, the
+softmax attention (SDPA with the chaos term folded into Q) and the conv heads are PyTorch-ROCm ops.
 Training (train mode): the encoder runs as autograd-tracked PyTorch ops with batch-statistics BatchNorm, exactly the
 reference's op sequence (smokephys_net.py:87-91).
 """
+import math
 from typing import Optional
 
 import torch
@@ -15,6 +18,7 @@ import torch.nn.functional as F
 
 from .chaos_attention import ChaosAttention
 from .encoder import HipEncoder, encoder_weight_dict
+from .linear import HipLinear, hip_linear_supported
 from .physics_regularizer import PhysicsRegularizer
 
 
@@ -34,12 +38,16 @@ def _mlp(din: int, dhid: int, dout: int) -> nn.Sequential:
 
 class SmokePhysNet(nn.Module):
     def __init__(self, input_dim: int = 128, hidden_dim: int = 512, num_layers: int = 6, num_heads: int = 8,
-                 output_channels: int = 64, chaos_strength: float = 0.1, encoder_dtype: str = "bf16x3"):
+                 output_channels: int = 64, chaos_strength: float = 0.1, encoder_dtype: str = "bf16x3",
+                 linear_dtype: str = "bf16x3"):
         super().__init__()
         self.input_dim = input_dim
         self.hidden_dim = hidden_dim
         self.num_layers = num_layers
         self.encoder_dtype = encoder_dtype
+        if linear_dtype not in ("bf16x3", "f32"):
+            raise ValueError("linear_dtype: 'bf16x3' (libsmokehip split-bf16 MFMA kernel) or 'f32' (PyTorch-ROCm GEMMs)")
+        self.linear_dtype = linear_dtype
         # Construction order and Sequential indices follow the reference exactly: that fixes both the state_dict keys
         # (input_encoder.{0,1,3,4}, reconstruction_head.{0,1,3,4,6}, ...) and the RNG stream of the default initialisation.
         self.input_encoder = nn.Sequential(*_conv_block(1, 64, 7), *_conv_block(64, 128, 3),
@@ -55,6 +63,7 @@ class SmokePhysNet(nn.Module):
         self.physics_regularizer = PhysicsRegularizer()
         self._hip = None          # (HipEncoder, weight fingerprint)
         self._pos_cache = None    # (fingerprint, tensor)
+        self._hip_linears = {}    # nn.Linear name -> (HipLinear, weight fingerprint)
 
     # ---- HIP encoder plumbing -------------------------------------------------------------------------------
     def _encoder_fingerprint(self):
@@ -93,6 +102,69 @@ class SmokePhysNet(nn.Module):
             self._pos_cache = (fp, pe.detach())
         return pe
 
+    # ---- transformer body on libsmokehip's split-bf16 linear kernel (eval only) -------------------------------------
+    def _hl(self, name: str, lin: nn.Linear) -> HipLinear:
+        """Device copy of one nn.Linear in the kernel's layout, rebuilt when its tensors change."""
+        fp = (lin.weight.data_ptr(), lin.weight._version,
+              None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+        hit = self._hip_linears.get(name)
+        if hit is None or hit[1] != fp:
+            if hit is not None:
+                hit[0].close()
+            hit = self._hip_linears[name] = (HipLinear.from_module(lin), fp)
+        return hit[0]
+
+    def hip_weights_fingerprint(self):
+        """Identity + version of every tensor libsmokehip keeps a re-laid-out copy of (GraphedSmokePhysNet re-captures
+        when this changes)."""
+        fp = [self._encoder_fingerprint(), (self.pos_embedding.data_ptr(), self.pos_embedding._version)]
+        for name, (_, f) in self._hip_linears.items():
+            lin = self.get_submodule(name)
+            fp.append((lin.weight.data_ptr(), lin.weight._version,
+                       None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version)))
+        return tuple(fp)
+
+    def _body_hip(self, tokens: torch.Tensor, chaos_noise: Optional[torch.Tensor], pool_size: int):
+        """feature_proj + pos-embed, the pre-LN chaos transformer layers and output_decoder (smokephys_net.py:95-114,
+        136-168; chaos_attention.py:68-114) with every token-wise nn.Linear as one fused libsmokehip launch:
+        bias, the pos-embedding / chaos-term addend, GELU / ReLU and the residual add ride in the GEMM epilogue.
+        LayerNorm, softmax-attention (SDPA with the chaos term folded into Q) and the tiny per-batch chaos MLP stay on
+        PyTorch-ROCm.  Returns (features [B,L,D], decoded [B,L,C])."""
+        B, L, _ = tokens.shape
+        D = self.hidden_dim
+        x = self._hl("feature_proj", self.feature_proj)(tokens, periodic_add=self._pos_embed(pool_size),
+                                                        rows_per_group=B * L)
+        for li, layer in enumerate(self.chaos_layers):
+            att, pre = layer.chaos_attention, f"chaos_layers.{li}."
+            H, d = att.num_heads, att.head_dim
+            h = F.layer_norm(x, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+            add5 = att.chaos_addend(B, x.device, x.dtype, None if chaos_noise is None else chaos_noise[li])
+            q = self._hl(pre + "chaos_attention.q_proj", att.q_proj)(h, periodic_add=add5, rows_per_group=L)
+            k = self._hl(pre + "chaos_attention.k_proj", att.k_proj)(h)
+            v = self._hl(pre + "chaos_attention.v_proj", att.v_proj)(h)
+            o = F.scaled_dot_product_attention(q.view(B, L, H, d).transpose(1, 2), k.view(B, L, H, d).transpose(1, 2),
+                                               v.view(B, L, H, d).transpose(1, 2),
+                                               scale=1.0 / (math.sqrt(d) * att.temperature))
+            o = o.transpose(1, 2).reshape(B, L, D)
+            self._hl(pre + "chaos_attention.out_proj", att.out_proj)(o, residual=x, out=x)          # x += attn
+            h = F.layer_norm(x, (D,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+            f = self._hl(pre + "ffn.0", layer.ffn[0])(h, activation="gelu")
+            self._hl(pre + "ffn.3", layer.ffn[3])(f, residual=x, out=x)                             # x += ffn
+        dec = self._hl("output_decoder.0", self.output_decoder[0])(x, activation="relu")
+        dec = self._hl("output_decoder.2", self.output_decoder[2])(dec)
+        return x, dec
+
+    def _hip_body_ok(self, tokens: torch.Tensor) -> bool:
+        if self.linear_dtype != "bf16x3" or self.training or torch.is_grad_enabled():
+            return False
+        if not tokens.is_cuda or tokens.dtype != torch.float32:
+            return False
+        lins = [self.feature_proj, self.output_decoder[0], self.output_decoder[2]]
+        for layer in self.chaos_layers:
+            a = layer.chaos_attention
+            lins += [a.q_proj, a.k_proj, a.v_proj, a.out_proj, layer.ffn[0], layer.ffn[3]]
+        return all(hip_linear_supported(m.in_features, m.out_features) for m in lins) and tokens.shape[1] % 32 == 0
+
     def forward(self, x: torch.Tensor, return_features: bool = False, chaos_noise: Optional[torch.Tensor] = None,
                 encoder_dtype: Optional[str] = None) -> dict:
         """x: [B,1,H,W].  chaos_noise (optional): [num_layers,3,B,1] standard-normal draws replacing the reference's
@@ -105,11 +177,14 @@ class SmokePhysNet(nn.Module):
             flattened = self.hip_encoder().tokens(x, input_dim=self.input_dim, dtype=dt)
         else:
             flattened = self.encode_frames(x, encoder_dtype).flatten(2).transpose(1, 2)
-        features = self.feature_proj(flattened)
-        features = features + self._pos_embed(pool_size)
-        for li, layer in enumerate(self.chaos_layers):
-            features = layer(features, noise=None if chaos_noise is None else chaos_noise[li])
-        output_features = self.output_decoder(features)
+        if self._hip_body_ok(flattened):
+            features, output_features = self._body_hip(flattened.contiguous(), chaos_noise, pool_size)
+        else:
+            features = self.feature_proj(flattened)
+            features = features + self._pos_embed(pool_size)
+            for li, layer in enumerate(self.chaos_layers):
+                features = layer(features, noise=None if chaos_noise is None else chaos_noise[li])
+            output_features = self.output_decoder(features)
         output_reshaped = output_features.transpose(1, 2).reshape(B, -1, pool_size, pool_size)
         reconstructed = self.reconstruction_head(output_reshaped)
         pooled_features = features.mean(dim=1)

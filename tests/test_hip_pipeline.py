@@ -207,3 +207,25 @@ def test_hip_graph_replay_equals_eager_forward(golden):
         for k in ref:
             assert torch.equal(ref[k], out[k]), k
     assert rel_err(out["physics_features"].cpu().numpy(), g["physics_features"]) > 1e-6   # the update was seen
+
+
+def test_hip_body_matches_fp32_torch_body(golden):
+    """Default-size network, same weights and chaos noise: the libsmokehip split-bf16 linear path (linear_dtype='bf16x3')
+    against the PyTorch-ROCm fp32 GEMM path (linear_dtype='f32') -- all outputs within 1e-4 (max-norm), batch of 2."""
+    g = golden("model_full_checksums.npz")
+    torch.manual_seed(0)
+    model = SmokePhysNet().cuda().eval()
+    assert model.linear_dtype == "bf16x3"
+    x = torch.from_numpy(g["frames"]).cuda()[:, None].repeat(2, 1, 1, 1)
+    x[1] = x[1].flip(-1) * 0.7
+    noise = torch.from_numpy(g["chaos_noise"]).cuda().repeat(1, 1, 2, 1)
+    with torch.no_grad():
+        assert model._hip_body_ok(torch.empty(2, 1024, 128, device="cuda"))
+        hip = model(x, return_features=True, chaos_noise=noise)
+        assert len(model._hip_linears) == 3 + 6 * len(model.chaos_layers)
+        model.linear_dtype = "f32"
+        ref = model(x, return_features=True, chaos_noise=noise)
+        model.linear_dtype = "bf16x3"
+    for k in ref:
+        assert hip[k].shape == ref[k].shape
+        assert rel_err(hip[k].cpu().numpy(), ref[k].cpu().numpy()) < 1e-4, k
