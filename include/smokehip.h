@@ -190,6 +190,16 @@ int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ld
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, void *stream);
 
+/* The chaos term of one ChaosAttention layer folded into Q (chaos_attention.py:39-66 lorenz_system + generate_chaos_field,
+ * :85-100 chaos_proj / chaos_gate / chaos_strength): noise [3][B] = the three randn(B,1) draws (before the 0.1 scale),
+ * proj_w [D][3], proj_b [D], gate_w [D], gate_b [1] (PyTorch layouts) -> addend [B][5][D], the value row l of the
+ * sequence adds to its query: strength * sigmoid(gate(C_t)) * C_t, C_t = chaos_proj(Lorenz state t), t = l mod 5
+ * (5 explicit-Euler steps, sigma/rho/beta/dt as given; reference: 10, 28, 8/3, 0.01).  Feed it to smk_linear_forward's
+ * periodic_add of q_proj.  Replaces ~90 tiny elementwise launches per layer. */
+int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj_w, const float *proj_b,
+                     const float *gate_w, const float *gate_b, double strength, double sigma, double rho, double beta,
+                     double dt, float *addend, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ class ChaosAttention(nn.Module):
         self.register_buffer("lorenz_sigma", torch.tensor(10.0))
         self.register_buffer("lorenz_rho", torch.tensor(28.0))
         self.register_buffer("lorenz_beta", torch.tensor(8.0 / 3.0))
+        self._lorenz_host = None
 
     def lorenz_system(self, x, y, z, dt: float = 0.01):
         """chaos_attention.py:39-45 (explicit Euler)."""
@@ -67,6 +68,27 @@ class ChaosAttention(nn.Module):
         C = chaos_proj(field) (chaos_attention.py:85-100).  [B,5,D]; row l of the sequence receives row l % 5."""
         c5 = self.chaos_proj(self.chaos_states(batch_size, device, noise).to(dtype))
         return self.chaos_strength * torch.sigmoid(self.chaos_gate(c5)) * c5
+
+    def chaos_addend_hip(self, batch_size: int, device, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """chaos_addend as ONE libsmokehip launch (smk_chaos_addend) instead of ~90 elementwise launches; the three
+        randn(B,1) draws are made exactly like the reference makes them (same generator calls, same order)."""
+        from .. import _lib
+        dev = _lib.require_cuda(device, "ChaosAttention.chaos_addend_hip")
+        if noise is None:
+            noise = torch.stack([torch.randn(batch_size, 1, device=dev) for _ in range(3)])
+        n3 = noise.to(dev, torch.float32).reshape(3, batch_size).contiguous()
+        out = torch.empty(batch_size, 5, self.dim, device=dev, dtype=torch.float32)
+        if self._lorenz_host is None:        # buffers are constants of the model; read them once (no sync per forward)
+            self._lorenz_host = (float(self.lorenz_sigma), float(self.lorenz_rho), float(self.lorenz_beta))
+        sg, rh, bt = self._lorenz_host
+        w = self.chaos_proj.weight
+        if not (w.is_contiguous() and self.chaos_gate.weight.is_contiguous()):
+            raise ValueError("chaos_proj / chaos_gate weights must be contiguous")
+        _lib.check(_lib.load().smk_chaos_addend(n3.data_ptr(), batch_size, self.dim, w.data_ptr(),
+                                               self.chaos_proj.bias.data_ptr(), self.chaos_gate.weight.data_ptr(),
+                                               self.chaos_gate.bias.data_ptr(), float(self.chaos_strength), sg, rh, bt,
+                                               0.01, out.data_ptr(), _lib.stream_ptr(dev)))
+        return out
 
     def forward(self, x: torch.Tensor, mask: torch.Tensor = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, L, D = x.shape

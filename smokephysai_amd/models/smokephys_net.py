@@ -138,7 +138,7 @@ class SmokePhysNet(nn.Module):
             att, pre = layer.chaos_attention, f"chaos_layers.{li}."
             H, d = att.num_heads, att.head_dim
             h = F.layer_norm(x, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-            add5 = att.chaos_addend(B, x.device, x.dtype, None if chaos_noise is None else chaos_noise[li])
+            add5 = att.chaos_addend_hip(B, x.device, None if chaos_noise is None else chaos_noise[li])
             q = self._hl(pre + "chaos_attention.q_proj", att.q_proj)(h, periodic_add=add5, rows_per_group=L)
             k = self._hl(pre + "chaos_attention.k_proj", att.k_proj)(h)
             v = self._hl(pre + "chaos_attention.v_proj", att.v_proj)(h)
