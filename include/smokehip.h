@@ -200,6 +200,14 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
                      const float *gate_w, const float *gate_b, double strength, double sigma, double rho, double beta,
                      double dt, float *addend, void *stream);
 
+/* Softmax attention of ChaosAttention (chaos_attention.py:102-112) once the chaos term is folded into Q
+ * (softmax(((Q + addend) K^T) * scale) V, heads merged back): q, k, v [B][L][ld*] fp32 with head h in columns
+ * head_dim*h .. of a token row (the layout q_proj / k_proj / v_proj write), out [B][L][ldo] in the same convention
+ * (what out_proj reads -- no transpose copy).  Flash style (no L x L tensor), split-bf16 MFMA, fp32-class accuracy.
+ * Requires head_dim == 64 and L % 128 == 0 (else SMK_ERR_UNSUPPORTED); scale = 1 / (sqrt(head_dim) * temperature). */
+int smk_attention(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t L, int32_t H,
+                  int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

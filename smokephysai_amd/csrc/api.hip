@@ -556,5 +556,28 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
     return check_launch(launch_chaos_addend(a, (hipStream_t)stream), "chaos_addend");
 }
 
+// ------------------------------------------------------------------ softmax attention (chaos term folded into Q)
+int smk_attention(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t L, int32_t H,
+                  int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, void *stream) {
+    SMK_REQUIRE(q && k && v && out, "null q/k/v/out");
+    SMK_REQUIRE(B >= 1 && H >= 1 && L >= 128, "B >= 1, H >= 1, L >= 128");
+    if (head_dim != 64 || L % 128 != 0) {
+        set_error("attention: HIP path is built for head_dim 64 and L a multiple of 128");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    const int64_t cols = (int64_t)H * 64;
+    SMK_REQUIRE(ldq >= cols && ldk >= cols && ldv >= cols && ldo >= cols, "row pitches >= H * head_dim");
+    SMK_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "row pitches multiples of 4 floats");
+    SMK_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "16-byte aligned tensors");
+    SMK_REQUIRE((int64_t)B * L * ldk < (1LL << 29) && (int64_t)B * L * ldv < (1LL << 29) && (int64_t)B * H * (L / 128) < (1LL << 31),
+                "B * L * ld < 2^29 floats (32-bit buffer offsets)");
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = out;
+    a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo;
+    a.B = B; a.L = L; a.H = H;
+    a.scale_log2e = (float)(scale * 1.4426950408889634074);
+    return check_launch(launch_attention_x3(a, (hipStream_t)stream), "attention_x3");
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -13,4 +13,13 @@ struct ChaosAddendArgs {
 };
 hipError_t launch_chaos_addend(const ChaosAddendArgs &a, hipStream_t st);
 
+struct AttnArgs {
+    const float *q, *k, *v;              // [B][L][ld*]: head h = columns 64h .. 64h+63 of a token row
+    float *o;                            // [B][L][ldo], same column convention
+    int ldq, ldk, ldv, ldo;              // row pitches in floats
+    int B, L, H;
+    float scale_log2e;                   // softmax scale * log2(e), folded into Q
+};
+hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st);
+
 }  // namespace smk

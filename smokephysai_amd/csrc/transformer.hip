@@ -56,4 +56,216 @@ hipError_t launch_chaos_addend(const ChaosAddendArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Softmax attention of ChaosAttention (chaos_attention.py:102-112: scores / sqrt(d) / temperature, softmax over keys, @ V,
+// heads merged back to [B, L, D]) with the chaos term already folded into Q -- flash style (no L x L score tensor), head
+// dim 64, fp32 accuracy on the bf16 matrix cores through split operands (x = hi + lo; hi*hi + hi*lo + lo*hi).
+//
+// Workgroup = 256 threads = one (batch, head, 128-query block); wave w owns queries 32w..32w+31 with Q (pre-scaled by
+// scale*log2 e, split) in registers.  K/V tiles of 64 keys are split on the fly and staged through LDS, double buffered:
+// K row-major [key][d] (pitch 144 B), V TRANSPOSED [d][key] (pitch 136 B; a staging thread holds a 4-key x 4-d block, so the
+// transposed image is written with 8-byte stores).
+//   S^T = mfma(K, Q): the query is the lane (column), 16 keys per 32-key block sit in the lane's accumulator registers, the
+//         other 16 in lane ^ 32 -> row max / sum are lane-local plus one cross-half exchange; alpha is a per-lane scalar.
+//   O^T = mfma(V^T, P): exp2'd accumulator registers 8s..8s+7 ARE the B fragment of k-step s (cdna_hip_programming.md, "An
+//         accumulator tile as the next MFMA's operand"); their fixed k-permutation -- element j of lane half h is key
+//         16s + 8(j>>2) + 4h + (j&3) -- is matched on the A side by reading V^T at keys 16s+4h..+3 and 16s+8+4h..+3
+//         (two ds_read_b64).
+// O^T leaves each lane with 4 consecutive d of its query per register quad -> 16-byte stores into [B][L][H*64].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AT_QB = 128, AT_KV = 64;
+constexpr int AT_KPITCH = 144, AT_VPITCH = 136;
+constexpr int AT_KPLANE = 64 * AT_KPITCH, AT_VPLANE = 64 * AT_VPITCH;          // 9216, 8704
+constexpr int AT_BUF = 2 * AT_KPLANE + 2 * AT_VPLANE;                          // 35,840 B per tile (K hi|lo, V^T hi|lo)
+constexpr int AT_LDS = 2 * AT_BUF;                                             // 71,680 B -> 2 workgroups per CU
+
+__device__ __forceinline__ void at_split4(const float4 &v, bf16x4 &h, bf16x4 &l) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 t = (__bf16)f[i];
+        h[i] = t;
+        l[i] = (__bf16)(f[i] - (float)t);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_attention_x3(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the L/128 query blocks of one (batch, head) read the same K/V: give them consecutive ids on ONE XCD (ids are dealt to the
+    // 8 XCDs round-robin; needs gridDim.x % 8 == 0, else the plain order)
+    const int vid = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int nqb = a.L / AT_QB;
+    const int qb = vid % nqb, bh = vid / nqb, head = bh % a.H, b = bh / a.H;
+    const int NT = a.L / AT_KV;
+
+    // ---- Q fragments (B operand: column = query r, k = d 16s + 8hh + j), pre-scaled, split
+    bf16x8 qh[4], ql[4];
+    {
+        const float *qp = a.q + ((size_t)b * a.L + qb * AT_QB + wave * 32 + r) * a.ldq + head * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(qp + 16 * s), v1 = *reinterpret_cast<const float4 *>(qp + 16 * s + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = f[j] * a.scale_log2e;
+                const __bf16 t = (__bf16)x;
+                qh[s][j] = t;
+                ql[s][j] = (__bf16)(x - (float)t);
+            }
+        }
+    }
+
+    // ---- K / V staging through buffer resources (one v_add per load; offsets < 2^31: api.hip)
+    const int c4 = tid & 15, rq = tid >> 4;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.k), 0, (int)((size_t)a.B * a.L * a.ldk * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.v), 0, (int)((size_t)a.B * a.L * a.ldv * 4), 0x00020000);
+    const int lane_k = (rq * a.ldk + head * 64 + c4 * 4) * 4;                  // K: rows rq + 16j of the tile
+    const int lane_v = (rq * 4 * a.ldv + head * 64 + c4 * 4) * 4;              // V: rows 4rq + i
+    float4 kst[4], vst[4];
+    auto stage_load = [&](int t) {
+        const int tt = t < NT ? t : NT - 1;                                    // past the end: a harmless re-read
+        const unsigned row0 = (unsigned)b * a.L + tt * AT_KV;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 kv = __builtin_amdgcn_raw_buffer_load_b128(krs, (int)((row0 + 16 * j) * (unsigned)a.ldk * 4u) + lane_k, 0, 0);
+            kst[j] = make_float4(__uint_as_float(kv.x), __uint_as_float(kv.y), __uint_as_float(kv.z), __uint_as_float(kv.w));
+            const u32x4 vv = __builtin_amdgcn_raw_buffer_load_b128(vrs, (int)((row0 + j) * (unsigned)a.ldv * 4u) + lane_v, 0, 0);
+            vst[j] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
+        }
+    };
+    auto stage_store = [&](int buf) {
+        unsigned char *base = smem + buf * AT_BUF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                         // K[key rq + 16j][d 4c4..]
+            bf16x4 h, l;
+            at_split4(kst[j], h, l);
+            unsigned char *p = base + (rq + 16 * j) * AT_KPITCH + c4 * 8;
+            *reinterpret_cast<bf16x4 *>(p) = h;
+            *reinterpret_cast<bf16x4 *>(p + AT_KPLANE) = l;
+        }
+        bf16x4 vh[4], vl[4];                                                   // [key i][d e] of the 4 x 4 block
+#pragma unroll
+        for (int i = 0; i < 4; ++i) at_split4(vst[i], vh[i], vl[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                         // V^T[d 4c4 + e][keys 4rq .. 4rq+3]
+            bf16x4 h, l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { h[i] = vh[i][e]; l[i] = vl[i][e]; }
+            unsigned char *p = base + 2 * AT_KPLANE + (c4 * 4 + e) * AT_VPITCH + rq * 8;
+            *reinterpret_cast<bf16x4 *>(p) = h;
+            *reinterpret_cast<bf16x4 *>(p + AT_VPLANE) = l;
+        }
+    };
+
+    stage_load(0);
+    stage_store(0);
+    stage_load(1);
+    __syncthreads();
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) oacc[db][g] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        const unsigned char *kb_h = smem + (t & 1) * AT_BUF + r * AT_KPITCH + hh * 16;
+        const unsigned char *vt_h = smem + (t & 1) * AT_BUF + 2 * AT_KPLANE + r * AT_VPITCH + hh * 8;
+        // ---- S^T = K Q^T (log2 units): sacc[kb][g] = score(query r, key 32kb + (g&3) + 8(g>>2) + 4hh)
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sacc[kb][g] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(kb_h + kb * 32 * AT_KPITCH + s * 32);
+                const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(kb_h + AT_KPLANE + kb * 32 * AT_KPITCH + s * 32);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        // the staged registers hold tile t+1: split + write it to the other buffer (its last reads ended before the barrier
+        // that closed tile t-1), then re-issue the loads for tile t+2
+        if (t + 1 < NT) stage_store((t + 1) & 1);
+        stage_load(t + 2);
+
+        // ---- online softmax (per lane: its query's 32 of the tile's 64 keys; lane ^ 32 holds the other 32)
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, sacc[kb][g]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);             // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 ph[4], pl[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = __builtin_amdgcn_exp2f(sacc[s4 >> 1][8 * (s4 & 1) + j] - m_new);
+                psum += p;
+                const __bf16 t16 = (__bf16)p;
+                ph[s4][j] = t16;
+                pl[s4][j] = (__bf16)(p - (float)t16);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) oacc[db][g] *= alpha;
+
+        // ---- O^T += V^T P: oacc[db][g] = O(query r, d 32db + (g&3) + 8(g>>2) + 4hh)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const unsigned char *p0 = vt_h + db * 32 * AT_VPITCH + s4 * 32;          // keys 16 s4 + 4hh .. +3 | +8
+                const bf16x4 h0 = *reinterpret_cast<const bf16x4 *>(p0), h1 = *reinterpret_cast<const bf16x4 *>(p0 + 16);
+                const bf16x4 l0 = *reinterpret_cast<const bf16x4 *>(p0 + AT_VPLANE), l1 = *reinterpret_cast<const bf16x4 *>(p0 + AT_VPLANE + 16);
+                const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s4], oacc[db], 0, 0, 0);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s4], oacc[db], 0, 0, 0);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s4], oacc[db], 0, 0, 0);
+            }
+        __syncthreads();                                       // tile t+1 visible; every read of tile t's buffer has returned
+    }
+
+    // ---- normalise and store: 4 consecutive d per register quad
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    float *op = a.o + ((size_t)b * a.L + qb * AT_QB + wave * 32 + r) * a.ldo + head * 64 + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            *reinterpret_cast<float4 *>(op + 32 * db + 8 * q4) =
+                make_float4(oacc[db][4 * q4] * inv, oacc[db][4 * q4 + 1] * inv, oacc[db][4 * q4 + 2] * inv, oacc[db][4 * q4 + 3] * inv);
+}
+
+hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_attention_x3, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
+        attr_done = true;
+    }
+    const int nwg = a.B * a.H * (a.L / AT_QB);
+    hipLaunchKernelGGL(k_attention_x3, dim3(nwg), dim3(256), AT_LDS, st, a);
+    return hipGetLastError();
+}
+
 }  // namespace smk

@@ -1,0 +1,29 @@
+"""Host side of libsmokehip's flash attention (smk_attention): softmax(Q K^T * scale) V over token-major tensors."""
+from typing import Optional
+
+import torch
+
+from .. import _lib
+
+
+def hip_attention_supported(L: int, head_dim: int) -> bool:
+    return head_dim == 64 and L % 128 == 0 and L >= 128
+
+
+def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, scale: float,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q, k, v: [B, L, H*64] float32 on a ROCm device (row pitch may exceed H*64, e.g. slices of a fused qkv tensor);
+    returns [B, L, H*64] -- the layout `out.transpose(1, 2).contiguous().view(B, L, D)` has in the reference
+    (chaos_attention.py:111-112)."""
+    dev = _lib.require_cuda(q.device, "hip_attention")
+    B, L, D = q.shape
+    d = D // num_heads
+    for t in (q, k, v):
+        if t.dtype != torch.float32 or t.shape != q.shape or t.device != q.device or t.stride(2) != 1 or t.stride(0) != L * t.stride(1):
+            raise ValueError("hip_attention: q, k, v must be float32 [B, L, H*d] with unit inner stride and dense batches")
+    if out is None:
+        out = torch.empty(B, L, D, device=dev, dtype=torch.float32)
+    _lib.check(_lib.load().smk_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, L, num_heads, d,
+                                        q.stride(1), k.stride(1), v.stride(1), out.stride(1), float(scale),
+                                        _lib.stream_ptr(dev)))
+    return out

@@ -4,8 +4,9 @@ state_dict keys, so a reference best_model.pth loads unchanged).
 Inference (eval mode): frames go through the fused HIP encoder (csrc/encoder.hip: conv7x7+BN+ReLU, conv3x3+BN+ReLU
 on MFMA, both adaptive pools as one block mean) -- there is no CPU fallback for it.  The token-wise linear layers of the
 transformer body (feature_proj, q/k/v/out projections, FFN, output_decoder) run on libsmokehip's split-bf16 MFMA kernel
-(csrc/linear.hip) with bias / pos-embedding / chaos-term / GELU / residual fused into the GEMM epilogue; LayerNorm, the
-softmax attention (SDPA with the chaos term folded into Q) and the conv heads are PyTorch-ROCm ops.
+(csrc/linear.hip) with bias / pos-embedding / chaos-term / GELU / residual fused into the GEMM epilogue, the softmax
+attention on its split-bf16 flash kernel (csrc/transformer.hip, chaos term folded into Q); LayerNorm and the conv heads
+are PyTorch-ROCm ops.
 Training (train mode): the encoder runs as autograd-tracked PyTorch ops with batch-statistics BatchNorm, exactly the
 reference's op sequence (smokephys_net.py:87-91).
 """
@@ -18,6 +19,7 @@ import torch.nn.functional as F
 
 from .chaos_attention import ChaosAttention
 from .encoder import HipEncoder, encoder_weight_dict
+from .attention import hip_attention, hip_attention_supported
 from .linear import HipLinear, hip_linear_supported
 from .physics_regularizer import PhysicsRegularizer
 
@@ -128,8 +130,8 @@ class SmokePhysNet(nn.Module):
         """feature_proj + pos-embed, the pre-LN chaos transformer layers and output_decoder (smokephys_net.py:95-114,
         136-168; chaos_attention.py:68-114) with every token-wise nn.Linear as one fused libsmokehip launch:
         bias, the pos-embedding / chaos-term addend, GELU / ReLU and the residual add ride in the GEMM epilogue.
-        LayerNorm, softmax-attention (SDPA with the chaos term folded into Q) and the tiny per-batch chaos MLP stay on
-        PyTorch-ROCm.  Returns (features [B,L,D], decoded [B,L,C])."""
+        softmax attention runs on libsmokehip's flash kernel (smk_attention, chaos term folded into Q) and the
+        per-layer Lorenz / chaos-gate chain on smk_chaos_addend; LayerNorm stays on PyTorch-ROCm.  Returns (features [B,L,D], decoded [B,L,C])."""
         B, L, _ = tokens.shape
         D = self.hidden_dim
         x = self._hl("feature_proj", self.feature_proj)(tokens, periodic_add=self._pos_embed(pool_size),
@@ -142,10 +144,13 @@ class SmokePhysNet(nn.Module):
             q = self._hl(pre + "chaos_attention.q_proj", att.q_proj)(h, periodic_add=add5, rows_per_group=L)
             k = self._hl(pre + "chaos_attention.k_proj", att.k_proj)(h)
             v = self._hl(pre + "chaos_attention.v_proj", att.v_proj)(h)
-            o = F.scaled_dot_product_attention(q.view(B, L, H, d).transpose(1, 2), k.view(B, L, H, d).transpose(1, 2),
-                                               v.view(B, L, H, d).transpose(1, 2),
-                                               scale=1.0 / (math.sqrt(d) * att.temperature))
-            o = o.transpose(1, 2).reshape(B, L, D)
+            scale = 1.0 / (math.sqrt(d) * att.temperature)
+            if hip_attention_supported(L, d):
+                o = hip_attention(q, k, v, H, scale)                       # [B, L, D]: heads already merged
+            else:
+                o = F.scaled_dot_product_attention(q.view(B, L, H, d).transpose(1, 2), k.view(B, L, H, d).transpose(1, 2),
+                                                   v.view(B, L, H, d).transpose(1, 2), scale=scale)
+                o = o.transpose(1, 2).reshape(B, L, D)
             self._hl(pre + "chaos_attention.out_proj", att.out_proj)(o, residual=x, out=x)          # x += attn
             h = F.layer_norm(x, (D,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
             f = self._hl(pre + "ffn.0", layer.ffn[0])(h, activation="gelu")

@@ -34,3 +34,45 @@ def test_chaos_addend_draws_noise_like_the_reference():
         noise = torch.stack([torch.randn(4, 1, device="cuda") for _ in range(3)])
         b = att.chaos_addend(4, noise.device, torch.float32, noise)
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def _attention_ref(q, k, v, H, scale):
+    B, L, D = q.shape
+    d = D // H
+    qh, kh, vh = (t.double().view(B, L, H, d).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, L, D)
+
+
+@pytest.mark.parametrize("B,L,H,spread,tol", [(1, 128, 8, 1.0, 2e-5), (2, 1024, 8, 1.0, 2e-5), (3, 256, 2, 4.0, 1e-4),
+                                               (1, 1024, 8, 12.0, 5e-4)])
+def test_attention_matches_fp64_softmax_attention(B, L, H, spread, tol):
+    """smk_attention against softmax(QK^T / 8) V in fp64 (chaos_attention.py:102-112); `spread` widens the score range so
+    that the online-softmax rescale path is exercised hard (running max grows across key tiles).  The logits are split-bf16
+    products: their absolute error grows with |score| (~1e-5 |s|), so the wide-range stress cases get wider bounds; at
+    the model's score range (|s| of a few units) the result is within 2e-5.  spread 12 = logits up to ~+-150."""
+    from smokephysai_amd.models.attention import hip_attention
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + L + H)
+    D = H * 64
+    q = torch.randn(B, L, D, device="cuda", generator=g) * spread
+    k = torch.randn(B, L, D, device="cuda", generator=g)
+    k[:, :, :] *= torch.linspace(0.2, 2.0, L, device="cuda")[None, :, None]      # later keys score higher: max keeps moving
+    v = torch.randn(B, L, D, device="cuda", generator=g)
+    out = hip_attention(q, k, v, H, 0.125)
+    ref = _attention_ref(q, k, v, H, 0.125)
+    sdpa = torch.nn.functional.scaled_dot_product_attention(*(t.view(B, L, H, 64).transpose(1, 2) for t in (q, k, v)), scale=0.125)
+    e_hip = rel_err(out.cpu().numpy(), ref.cpu().numpy())
+    e_sdpa = rel_err(sdpa.transpose(1, 2).reshape(B, L, D).cpu().numpy(), ref.cpu().numpy())
+    assert e_hip < tol, (e_hip, e_sdpa)
+
+
+def test_attention_reads_strided_qkv_and_rejects_other_head_dims():
+    from smokephysai_amd.models.attention import hip_attention, hip_attention_supported
+    g = torch.Generator(device="cuda").manual_seed(5)
+    qkv = torch.randn(2, 256, 3 * 512, device="cuda", generator=g)
+    q, k, v = qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:]
+    out = hip_attention(q, k, v, 8, 0.125)
+    assert rel_err(out.cpu().numpy(), _attention_ref(q, k, v, 8, 0.125).cpu().numpy()) < 2e-5
+    assert not hip_attention_supported(1024, 32) and not hip_attention_supported(100, 64)
+    with pytest.raises(Exception, match="head_dim 64"):
+        hip_attention(qkv[..., :256].contiguous(), qkv[..., :256].contiguous(), qkv[..., :256].contiguous(), 8, 0.125)
