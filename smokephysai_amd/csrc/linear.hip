@@ -30,7 +30,7 @@ constexpr int LN_PITCH = 144;      // bytes per staged row per plane: 64 bf16 + 
 #endif
 constexpr int LN_RING = 4;         // B fragments in flight: 3 k-steps ahead; 4 k-steps per chunk keep the ring indices static
 template <int MB> constexpr int ln_plane_bytes() { return MB * 32 * LN_PITCH; }
-template <int MB> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 512; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
+template <int MB> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 1024; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
 
 __global__ __launch_bounds__(256) void k_split_linear_weights(const float *__restrict__ w, const float *__restrict__ bias, LinearDev l) {
     const long long total = (long long)l.N * l.K;
@@ -81,8 +81,9 @@ struct LinearArgs {
                           // 2 B ring re-reads k-step 0, 4 no epilogue
 };
 
-template <int MB>
-__global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
+template <int MB, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
+    constexpr int TN = NW * 32, RP = NW * 4;      // tile columns; rows staged per pass (NW*64 threads / 16 float4 columns)
     constexpr bool sched = SMK_LINEAR_SCHED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TM = MB * 32, PLANE = ln_plane_bytes<MB>();
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     // half a tile so that one's epilogue / staging stalls overlap the other's MFMA stretch (speed only).
     if (a.stagger > 0 && ((blockIdx.x / a.num_cu) & 1))
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    const int n = tn * 128 + wave * 32 + r;                  // this lane's output column
+    const int n = tn * TN + wave * 32 + r;                  // this lane's output column
     const bool n_ok = n < N;
 
     // ---- B ring: 16 bytes per lane at a per-lane constant offset from a wave-uniform (scalar) fragment base
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
 
     // ---- A staging: thread = float4 column sc of rows sr, sr+16, ... of the 32*MB x 64 chunk (a wave reads 4 full 256-B rows)
     const int sc = tid & 15, sr = tid >> 4;
-    float4 stage[2 * MB];
+    float4 stage[TM / RP];
     // x through a buffer resource: a row past M (ragged last tile, or the chunk stream running past this workgroup's last
     // tile) is out of range and reads as zero in hardware -- no clamp, no predicate (either would cost VALU issue slots or
     // split the k-step into basic blocks and undo the MFMA / staging interleave below).  One v_add per load: the offset
@@ -132,14 +133,14 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     const int ldxb = (int)a.c.ldx * 4;
     const int lane_x = sr * ldxb + sc * 16;
     auto stage_load = [&](int tmx, int cx, int j) {
-        const unsigned row_u = (unsigned)((a.dbg & 1) ? 0 : tmx) * TM + 16 * j;          // wave-uniform part (SALU); tmx <= tiles_m
+        const unsigned row_u = (unsigned)((a.dbg & 1) ? 0 : tmx) * TM + RP * j;          // wave-uniform part (SALU); tmx <= tiles_m
         const unsigned off = row_u * (unsigned)ldxb + (unsigned)cx * 256u;                // < 2^32: api.hip bounds (rows + 256) * ldx
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
         // (not __builtin_bit_cast(float, v[i]): hipcc 7.2 then emits a 1-dword load and leaves v[1..3] undefined)
         stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     auto stage_store = [&](int buf, int j) {
-        unsigned char *ph = smem + buf * 2 * PLANE + (sr + 16 * j) * LN_PITCH + sc * 8;
+        unsigned char *ph = smem + buf * 2 * PLANE + (sr + RP * j) * LN_PITCH + sc * 8;
         const float v[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
         bf16x4 vh, vl;
 #pragma unroll
@@ -162,10 +163,10 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
         if (++ld_c == nchunks) { ld_c = 0; ld_tm = ld_tm + tm_step < a.tiles_m ? ld_tm + tm_step : a.tiles_m; }   // past the end: row >= M
     };
 #pragma unroll
-    for (int j = 0; j < 2 * MB; ++j) stage_load(ld_tm, ld_c, j);
+    for (int j = 0; j < TM / RP; ++j) stage_load(ld_tm, ld_c, j);
     advance();
 #pragma unroll
-    for (int j = 0; j < 2 * MB; ++j) {
+    for (int j = 0; j < TM / RP; ++j) {
         stage_store(0, j);
         stage_load(ld_tm, ld_c, j);
     }
@@ -184,9 +185,9 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     bf16x8 ahA[MB], alA[MB], ahB[MB], alB[MB];
     int buf = 0;
     load_a(0, 0, ahA, alA);
-    const bool nw_ok = tn * 128 + wave * 32 < N;
+    const bool nw_ok = tn * TN + wave * 32 < N;
     float *bias_s = reinterpret_cast<float *>(smem + 4 * PLANE);       // this workgroup's 128 bias values
-    if (tid < 128) bias_s[tid] = tn * 128 + tid < N ? a.l.bias[tn * 128 + tid] : 0.f;   // visible after the first barrier below             // N % 32 == 0: a wave's 32 columns are all inside or all outside
+    if (tid < TN) bias_s[tid] = tn * TN + tid < N ? a.l.bias[tn * TN + tid] : 0.f;   // visible after the first barrier below             // N % 32 == 0: a wave's 32 columns are all inside or all outside
 
 #ifdef SMK_LN_STAMPS
     unsigned long long sum_k = 0, sum_e = 0, ntl = 0, sum_u[5] = {0, 0, 0, 0, 0}, t_prev = 0;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
                 // The staged registers hold the chunk after this one: k-steps 0..2 each split + write a share of its 2*MB
                 // pieces to the other buffer (last read before the previous chunk's barrier; complete before this chunk's) and
                 // re-issue each piece's load at once for the chunk after that (a whole chunk of MFMAs to land).
-                constexpr int NP = 2 * MB, P0 = (NP * 3 + 7) / 8, P1 = (NP * 6 + 7) / 8;      // MB = 4: pieces 0-2 | 3-5 | 6-7
+                constexpr int NP = TM / RP, P0 = (NP * 3 + 7) / 8, P1 = (NP * 6 + 7) / 8;      // MB = 4: pieces 0-2 | 3-5 | 6-7
                 constexpr int pbeg = u == 0 ? 0 : u == 1 ? P0 : u == 2 ? P1 : NP, pend = u == 0 ? P0 : u == 1 ? P1 : NP;
 #pragma unroll
                 for (int j = pbeg; j < pend; ++j) {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
         // ---- epilogue.  The weights are the MFMA's row operand, so acc[mi][4q + i] = output row mi*32 + r (this lane's token),
         //      column 8q + 4hi + i of the wave's 32: four consecutive columns per lane -> 16-byte loads and stores.
         if (nw_ok && !(a.dbg & 4)) {
-            const int row0 = tm * TM, ncol = tn * 128 + wave * 32 + 4 * hi;
+            const int row0 = tm * TM, ncol = tn * TN + wave * 32 + 4 * hi;
             const float *bias_w = bias_s + wave * 32 + 4 * hi;
             // Global loads (residual, periodic addend) of row block mi+1 are issued BEFORE the stores of block mi: vmcnt retires in
             // order, so a load issued after a store could only be consumed once that store had been acknowledged by memory.
@@ -347,20 +348,21 @@ __global__ __launch_bounds__(256, 2) void k_linear_x3(const LinearArgs a) {
     LN_STAMP(t_end);
     LN_RSTAMP(r_end);
     if (a.stamps && lane == 0) {
-        unsigned long long *rec = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long *rec = a.stamps + (((size_t)blockIdx.x * NW + wave) & 4095) * 8;
         rec[0] = sum_k; rec[1] = sum_e; rec[2] = t_end - t_begin; rec[3] = r_end - r_begin; rec[4] = ntl; rec[5] = sum_u[0] | (sum_u[1] << 32); rec[6] = sum_u[2] | (sum_u[3] << 32); rec[7] = sum_u[4];
     }
 #endif
 }
 
-template <int MB>
-static hipError_t launch_mb(const LinearArgs &a, int nwg_max, hipStream_t st) {
+template <int MB, int NW>
+static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     constexpr int lds = ln_lds_bytes<MB>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
+    const int nwg_max = (NW == 8 ? 1 : 2) * a.num_cu;     // 8 waves per CU either way
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
     long long nwg = tiles < nwg_max ? tiles : nwg_max;
     nwg -= nwg % a.tiles_n;                               // every workgroup keeps one column tile
@@ -371,7 +373,7 @@ static hipError_t launch_mb(const LinearArgs &a, int nwg_max, hipStream_t st) {
     if (stg_env < 0) { const char *s = getenv("SMK_LINEAR_STAGGER"); stg_env = s ? atoi(s) : 0; }
     b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
     b.stagger = nwg > b.num_cu ? stg_env : 0;
-    hipLaunchKernelGGL((k_linear_x3<MB>), dim3((unsigned)nwg), dim3(256), lds, st, b);
+    hipLaunchKernelGGL((k_linear_x3<MB, NW>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
     return hipGetLastError();
 }
 
@@ -386,54 +388,57 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     LinearArgs a;
     a.l = l;
     a.c = c;
-    a.tiles_n = cdiv(l.N, 128);
+    // 8-wave workgroups (128 x 256 tile) halve the per-MFMA staging work (split arithmetic, LDS writes) and the re-reads of A;
+    // 4-wave ones (x 128) serve narrow layers and small problems (more workgroups)
+    static int force_mb = -1, force_nw = -1;
+    if (force_mb < 0) { const char *s = getenv("SMK_LINEAR_MB"); force_mb = s ? atoi(s) : 0; }
+    if (force_nw < 0) { const char *s = getenv("SMK_LINEAR_NW"); force_nw = s ? atoi(s) : 0; }
     static int dbg = -1;
     if (dbg < 0) { const char *s = getenv("SMK_LINEAR_DBG"); dbg = s ? atoi(s) : 0; }
     a.dbg = dbg;
+    a.num_cu = num_cu;
+    a.swz = 0;
+    a.stagger = 0;
     a.stamps = nullptr;
+    int nw = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) >= num_cu) ? 8 : 4;
+    if (force_nw == 4 || force_nw == 8) nw = force_nw;
+    a.tiles_n = cdiv(l.N, nw * 32);
+    // row-block count per tile: the largest that still gives every CU its share of workgroups (small M: finer tiles)
+    const long long want = (nw == 8 ? 1LL : 2LL) * num_cu;
+    int mb = 4;
+    while (mb > 1 && (long long)cdiv(c.M, 32 * mb) * a.tiles_n < want) mb >>= 1;
+    if (force_mb == 1 || force_mb == 2 || force_mb == 4) mb = force_mb;
+    if (nw == 8) mb = 4;                                   // the 8-wave form is built for full 128-row tiles only
+    while (c.padd && mb > 1 && c.rows_per_group % (32 * mb) != 0) mb >>= 1;
+    if (c.padd && c.rows_per_group % (32 * mb) != 0) return hipErrorInvalidValue;   // api.hip checks rows_per_group % 32 == 0
+    if (c.padd && nw == 8 && mb != 4) { nw = 4; a.tiles_n = cdiv(l.N, 128); }
+    a.tiles_m = cdiv(c.M, 32 * mb);
 #ifdef SMK_LN_STAMPS
     static unsigned long long *stamp_buf = nullptr;
     if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, 8 * 8 * 4096);
     (void)hipMemsetAsync(stamp_buf, 0, 8 * 8 * 4096, st);
     a.stamps = stamp_buf;
 #endif
-    a.num_cu = num_cu;
-    a.swz = 0;
-    a.stagger = 0;
-    // row-block count per tile: the largest that still gives every CU about two workgroups (small M: finer tiles)
-    static int force_mb = -1;
-    if (force_mb < 0) { const char *s = getenv("SMK_LINEAR_MB"); force_mb = s ? atoi(s) : 0; }
-    int mb = 4;
-    while (mb > 1 && (long long)cdiv(c.M, 32 * mb) * a.tiles_n < 2LL * num_cu) mb >>= 1;
-    if (force_mb == 1 || force_mb == 2 || force_mb == 4) mb = force_mb;
-    while (c.padd && mb > 1 && c.rows_per_group % (32 * mb) != 0) mb >>= 1;
-    if (c.padd && c.rows_per_group % (32 * mb) != 0) return hipErrorInvalidValue;   // api.hip checks rows_per_group % 32 == 0
-    a.tiles_m = cdiv(c.M, 32 * mb);
-    const int nwg_max = 2 * num_cu;
+    hipError_t e;
+    if (nw == 8) e = launch_mb<4, 8>(a, st);
+    else if (mb == 4) e = launch_mb<4, 4>(a, st);
+    else if (mb == 2) e = launch_mb<2, 4>(a, st);
+    else e = launch_mb<1, 4>(a, st);
 #ifdef SMK_LN_STAMPS
-    {   // diagnostic: run, wait, print the per-wave averages (cycles per tile; clock = core cycles / 100 MHz real-time ticks)
-        hipError_t e = mb == 4 ? launch_mb<4>(a, nwg_max, st) : mb == 2 ? launch_mb<2>(a, nwg_max, st) : launch_mb<1>(a, nwg_max, st);
-        if (getenv("SMK_LN_STAMPS_PRINT")) {
-            static unsigned long long h[8 * 4096];
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
-            double k = 0, ep = 0, tot = 0, real = 0, nt = 0, us[5] = {0, 0, 0, 0, 0}; int n = 0;
-            for (int w = 0; w < 4096; ++w) if (h[w * 8 + 4]) { ++n; k += h[w*8]; ep += h[w*8+1]; tot += h[w*8+2]; real += h[w*8+3]; nt += h[w*8+4];
-                us[0] += h[w*8+5] & 0xffffffffULL; us[1] += h[w*8+5] >> 32; us[2] += h[w*8+6] & 0xffffffffULL; us[3] += h[w*8+6] >> 32; us[4] += h[w*8+7]; }
-            const double nch = nt * (l.K / 64);
-            if (n) fprintf(stderr, "LN_KSTEPS per chunk: k0 %.0f k1 %.0f k2 %.0f k3(incl barrier) %.0f barrier %.0f\n", us[0] / nch, us[1] / nch, us[2] / nch, us[3] / nch, us[4] / nch);
-            if (n) fprintf(stderr, "LN_STAMPS M=%d K=%d N=%d mb=%d waves=%d tiles/wave=%.1f | per tile: kloop %.0f epilogue %.0f | wave total %.0f cyc = %.1f us, clock %.0f MHz\n",
-                           c.M, l.K, l.N, mb, n, nt / n, k / nt, ep / nt, tot / n, real / n / 100.0, tot / real * 100.0);
-        }
-        return e;
+    if (getenv("SMK_LN_STAMPS_PRINT")) {   // diagnostic: wait, print the per-wave averages (cycles per tile; clock = core cycles / 100 MHz ticks)
+        static unsigned long long h[8 * 4096];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
+        double k = 0, ep = 0, tot = 0, real = 0, nt = 0, us[5] = {0, 0, 0, 0, 0}; int n = 0;
+        for (int w = 0; w < 4096; ++w) if (h[w * 8 + 4]) { ++n; k += h[w*8]; ep += h[w*8+1]; tot += h[w*8+2]; real += h[w*8+3]; nt += h[w*8+4];
+            us[0] += h[w*8+5] & 0xffffffffULL; us[1] += h[w*8+5] >> 32; us[2] += h[w*8+6] & 0xffffffffULL; us[3] += h[w*8+6] >> 32; us[4] += h[w*8+7]; }
+        const double nch = nt * (l.K / 64);
+        if (n) fprintf(stderr, "LN_KSTEPS per chunk: k0 %.0f k1 %.0f k2 %.0f k3(incl barrier) %.0f barrier %.0f\n", us[0] / nch, us[1] / nch, us[2] / nch, us[3] / nch, us[4] / nch);
+        if (n) fprintf(stderr, "LN_STAMPS M=%d K=%d N=%d mb=%d nw=%d waves=%d tiles/wave=%.1f | per tile: kloop %.0f epilogue %.0f | wave total %.0f cyc = %.1f us, clock %.0f MHz\n",
+                       c.M, l.K, l.N, mb, nw, n, nt / n, k / nt, ep / nt, tot / n, real / n / 100.0, tot / real * 100.0);
     }
 #endif
-    switch (mb) {
-        case 4: return launch_mb<4>(a, nwg_max, st);
-        case 2: return launch_mb<2>(a, nwg_max, st);
-        default: break;
-    }
-    return launch_mb<1>(a, nwg_max, st);
+    return e;
 }
 
 }  // namespace smk
