@@ -129,6 +129,12 @@ def inference_ms(dev, N, frames, encoder_dtype):
                 torch.cuda.synchronize(dev)
                 out[f"batch{bs}"] = (time.perf_counter() - t0) / reps / bs * 1e3
     res["eager"] = eager
+    # ~68.7 GFLOP per 256^2 frame (61.1 at 128^2) for the whole forward, reference formulation
+    gflop = {256: 68.7, 128: 61.1}.get(N)
+    if gflop:
+        res["counted_TFLOPs_at_sim_batch"] = gflop / res[f"batch{frames.shape[0]}"]
+    res["body"] = ("libsmokehip split-bf16 kernels: fused encoder, token linears (bias/pos-embed/chaos-term/GELU/residual epilogues), "
+                   "flash attention, chaos addend; LayerNorm + conv heads on PyTorch-ROCm")
     res["note"] = f"{N}x{N} frames; hipGraph replay (eager launch beside it); reference README: 610.92 ms/frame (hardware unstated)"
     return res
 
