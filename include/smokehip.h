@@ -192,13 +192,14 @@ int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ld
 
 /* The chaos term of one ChaosAttention layer folded into Q (chaos_attention.py:39-66 lorenz_system + generate_chaos_field,
  * :85-100 chaos_proj / chaos_gate / chaos_strength): noise [3][B] = the three randn(B,1) draws (before the 0.1 scale),
- * proj_w [D][3], proj_b [D], gate_w [D], gate_b [1] (PyTorch layouts) -> addend [B][5][D], the value row l of the
+ * proj_w [D][3], proj_b [D], gate_w [D], gate_b [1] (PyTorch layouts) -> addend [B][5][ld_addend] (columns 0..D-1
+ * written; a wider pitch lets it land in the q columns of a fused q|k|v addend), the value row l of the
  * sequence adds to its query: strength * sigmoid(gate(C_t)) * C_t, C_t = chaos_proj(Lorenz state t), t = l mod 5
  * (5 explicit-Euler steps, sigma/rho/beta/dt as given; reference: 10, 28, 8/3, 0.01).  Feed it to smk_linear_forward's
  * periodic_add of q_proj.  Replaces ~90 tiny elementwise launches per layer. */
 int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj_w, const float *proj_b,
                      const float *gate_w, const float *gate_b, double strength, double sigma, double rho, double beta,
-                     double dt, float *addend, void *stream);
+                     double dt, float *addend, int64_t ld_addend, void *stream);
 
 /* Softmax attention of ChaosAttention (chaos_attention.py:102-112) once the chaos term is folded into Q
  * (softmax(((Q + addend) K^T) * scale) V, heads merged back): q, k, v [B][L][ld*] fp32 with head h in columns

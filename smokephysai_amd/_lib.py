@@ -59,7 +59,7 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_int32, C.c_void_p],
     "smk_encoder_conv1": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
     "smk_chaos_addend": [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
-                         C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
+                         C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p],
     "smk_attention": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                       C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p],
     "smk_linear_create": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],

@@ -546,12 +546,12 @@ int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ld
 // ------------------------------------------------------------------ chaos term of ChaosAttention
 int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj_w, const float *proj_b,
                      const float *gate_w, const float *gate_b, double strength, double sigma, double rho, double beta,
-                     double dt, float *addend, void *stream) {
+                     double dt, float *addend, int64_t ld_addend, void *stream) {
     SMK_REQUIRE(noise && proj_w && proj_b && gate_w && gate_b && addend, "null pointer");
-    SMK_REQUIRE(B >= 1 && D >= 1, "B >= 1, D >= 1");
+    SMK_REQUIRE(B >= 1 && D >= 1 && ld_addend >= D && ld_addend < (1LL << 30), "B >= 1, D >= 1, ld_addend >= D");
     ChaosAddendArgs a;
     a.noise = noise; a.proj_w = proj_w; a.proj_b = proj_b; a.gate_w = gate_w; a.gate_b = gate_b; a.addend = addend;
-    a.B = B; a.D = D;
+    a.B = B; a.D = D; a.ld = (int)ld_addend;
     a.strength = (float)strength; a.sigma = (float)sigma; a.rho = (float)rho; a.beta = (float)beta; a.dt = (float)dt;
     return check_launch(launch_chaos_addend(a, (hipStream_t)stream), "chaos_addend");
 }

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_chaos_addend(const ChaosAddendArgs a) {
         const float w0 = a.proj_w[3 * d], w1 = a.proj_w[3 * d + 1], w2 = a.proj_w[3 * d + 2], pb = a.proj_b[d];
 #pragma unroll
         for (int t = 0; t < 5; ++t)
-            a.addend[((size_t)b * 5 + t) * a.D + d] = g[t] * (((sx[t] * w0 + sy[t] * w1) + sz[t] * w2) + pb);
+            a.addend[((size_t)b * 5 + t) * a.ld + d] = g[t] * (((sx[t] * w0 + sy[t] * w1) + sz[t] * w2) + pb);
     }
 }
 

@@ -69,7 +69,8 @@ class ChaosAttention(nn.Module):
         c5 = self.chaos_proj(self.chaos_states(batch_size, device, noise).to(dtype))
         return self.chaos_strength * torch.sigmoid(self.chaos_gate(c5)) * c5
 
-    def chaos_addend_hip(self, batch_size: int, device, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def chaos_addend_hip(self, batch_size: int, device, noise: Optional[torch.Tensor] = None,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """chaos_addend as ONE libsmokehip launch (smk_chaos_addend) instead of ~90 elementwise launches; the three
         randn(B,1) draws are made exactly like the reference makes them (same generator calls, same order)."""
         from .. import _lib
@@ -77,7 +78,10 @@ class ChaosAttention(nn.Module):
         if noise is None:
             noise = torch.stack([torch.randn(batch_size, 1, device=dev) for _ in range(3)])
         n3 = noise.to(dev, torch.float32).reshape(3, batch_size).contiguous()
-        out = torch.empty(batch_size, 5, self.dim, device=dev, dtype=torch.float32)
+        if out is None:                      # out: [B, 5, >= dim] float32, columns 0..dim-1 are written
+            out = torch.empty(batch_size, 5, self.dim, device=dev, dtype=torch.float32)
+        elif out.shape[:2] != (batch_size, 5) or out.shape[2] < self.dim or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("chaos_addend_hip: out must be a contiguous float32 [B, 5, >= dim] tensor")
         if self._lorenz_host is None:        # buffers are constants of the model; read them once (no sync per forward)
             self._lorenz_host = (float(self.lorenz_sigma), float(self.lorenz_rho), float(self.lorenz_beta))
         sg, rh, bt = self._lorenz_host
@@ -87,7 +91,7 @@ class ChaosAttention(nn.Module):
         _lib.check(_lib.load().smk_chaos_addend(n3.data_ptr(), batch_size, self.dim, w.data_ptr(),
                                                self.chaos_proj.bias.data_ptr(), self.chaos_gate.weight.data_ptr(),
                                                self.chaos_gate.bias.data_ptr(), float(self.chaos_strength), sg, rh, bt,
-                                               0.01, out.data_ptr(), _lib.stream_ptr(dev)))
+                                               0.01, out.data_ptr(), out.shape[2], _lib.stream_ptr(dev)))
         return out
 
     def forward(self, x: torch.Tensor, mask: torch.Tensor = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:

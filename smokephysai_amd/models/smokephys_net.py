@@ -66,6 +66,7 @@ class SmokePhysNet(nn.Module):
         self._hip = None          # (HipEncoder, weight fingerprint)
         self._pos_cache = None    # (fingerprint, tensor)
         self._hip_linears = {}    # nn.Linear name -> (HipLinear, weight fingerprint)
+        self._addend_bufs = {}    # (layer, batch) -> [B,5,3D] chaos addend of the fused q|k|v projection
 
     # ---- HIP encoder plumbing -------------------------------------------------------------------------------
     def _encoder_fingerprint(self):
@@ -116,14 +117,29 @@ class SmokePhysNet(nn.Module):
             hit = self._hip_linears[name] = (HipLinear.from_module(lin), fp)
         return hit[0]
 
+    def _hl_qkv(self, name: str, att: ChaosAttention) -> HipLinear:
+        """q_proj | k_proj | v_proj as ONE [3D, D] layer: x is read once and the three projections are a single launch."""
+        mods = (att.q_proj, att.k_proj, att.v_proj)
+        fp = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
+        hit = self._hip_linears.get(name)
+        if hit is None or hit[1] != fp:
+            if hit is not None:
+                hit[0].close()
+            hit = self._hip_linears[name] = (HipLinear(torch.cat([m.weight for m in mods]), torch.cat([m.bias for m in mods])), fp)
+        return hit[0]
+
     def hip_weights_fingerprint(self):
         """Identity + version of every tensor libsmokehip keeps a re-laid-out copy of (GraphedSmokePhysNet re-captures
         when this changes)."""
         fp = [self._encoder_fingerprint(), (self.pos_embedding.data_ptr(), self.pos_embedding._version)]
-        for name, (_, f) in self._hip_linears.items():
-            lin = self.get_submodule(name)
-            fp.append((lin.weight.data_ptr(), lin.weight._version,
-                       None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version)))
+        for name in self._hip_linears:
+            if name.endswith(".qkv"):
+                mods = [self.get_submodule(name[:-3] + p) for p in ("q_proj", "k_proj", "v_proj")]
+            else:
+                mods = [self.get_submodule(name)]
+            for lin in mods:
+                fp.append((lin.weight.data_ptr(), lin.weight._version,
+                           None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version)))
         return tuple(fp)
 
     def _body_hip(self, tokens: torch.Tensor, chaos_noise: Optional[torch.Tensor], pool_size: int):
@@ -140,10 +156,14 @@ class SmokePhysNet(nn.Module):
             att, pre = layer.chaos_attention, f"chaos_layers.{li}."
             H, d = att.num_heads, att.head_dim
             h = F.layer_norm(x, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-            add5 = att.chaos_addend_hip(B, x.device, None if chaos_noise is None else chaos_noise[li])
-            q = self._hl(pre + "chaos_attention.q_proj", att.q_proj)(h, periodic_add=add5, rows_per_group=L)
-            k = self._hl(pre + "chaos_attention.k_proj", att.k_proj)(h)
-            v = self._hl(pre + "chaos_attention.v_proj", att.v_proj)(h)
+            # fused q|k|v projection; the chaos addend only touches the q columns
+            key = (li, B)
+            add15 = self._addend_bufs.get(key)
+            if add15 is None or add15.device != x.device:   # [B,5,3D]; the k|v columns stay zero, the q columns are rewritten per call
+                add15 = self._addend_bufs[key] = torch.zeros(B, 5, 3 * D, device=x.device)
+            att.chaos_addend_hip(B, x.device, None if chaos_noise is None else chaos_noise[li], out=add15)
+            qkv = self._hl_qkv(pre + "chaos_attention.qkv", att)(h, periodic_add=add15, rows_per_group=L)
+            q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
             scale = 1.0 / (math.sqrt(d) * att.temperature)
             if hip_attention_supported(L, d):
                 o = hip_attention(q, k, v, H, scale)                       # [B, L, D]: heads already merged
@@ -167,6 +187,8 @@ class SmokePhysNet(nn.Module):
         lins = [self.feature_proj, self.output_decoder[0], self.output_decoder[2]]
         for layer in self.chaos_layers:
             a = layer.chaos_attention
+            if a.q_proj.bias is None or a.k_proj.bias is None or a.v_proj.bias is None:
+                return False
             lins += [a.q_proj, a.k_proj, a.v_proj, a.out_proj, layer.ffn[0], layer.ffn[3]]
         return all(hip_linear_supported(m.in_features, m.out_features) for m in lins) and tokens.shape[1] % 32 == 0
 
