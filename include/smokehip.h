@@ -209,6 +209,11 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
 int smk_attention(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t L, int32_t H,
                   int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, void *stream);
 
+/* nn.LayerNorm over the last dimension (smokephys_net.py:149-150, applied at :161,:165; biased variance, eps as given):
+ * x [rows][ldx] -> y [rows][ldy], weight / bias [D].  D % 4 == 0, D <= 2048 (else SMK_ERR_UNSUPPORTED). */
+int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const float *weight, const float *bias, double eps,
+                  float *y, int64_t ldy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,8 @@ _SIGNATURES = {
                          C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p],
     "smk_attention": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                       C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p],
+    "smk_layernorm": [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64,
+                      C.c_void_p],
     "smk_linear_create": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
     "smk_linear_destroy": [C.c_void_p],
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

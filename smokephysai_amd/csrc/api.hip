@@ -579,5 +579,21 @@ int smk_attention(const float *q, const float *k, const float *v, float *out, in
     return check_launch(launch_attention_x3(a, (hipStream_t)stream), "attention_x3");
 }
 
+// ------------------------------------------------------------------ LayerNorm
+int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const float *weight, const float *bias, double eps,
+                  float *y, int64_t ldy, void *stream) {
+    SMK_REQUIRE(x && y && weight && bias, "null x/y/weight/bias");
+    SMK_REQUIRE(rows >= 1 && rows < (1LL << 31) - 4, "1 <= rows < 2^31");
+    if (D < 4 || D % 4 != 0 || D > 2048) {
+        set_error("layernorm: HIP path is built for D a multiple of 4, at most 2048");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    SMK_REQUIRE(ldx >= D && ldy >= D && ldx % 4 == 0 && ldy % 4 == 0, "row pitches >= D, multiples of 4 floats");
+    SMK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0, "16-byte aligned tensors");
+    LayerNormArgs a;
+    a.x = x; a.y = y; a.w = weight; a.b = bias; a.ldx = ldx; a.ldy = ldy; a.rows = (int)rows; a.D = D; a.eps = (float)eps;
+    return check_launch(launch_layernorm(a, (hipStream_t)stream), "layernorm");
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -22,4 +22,13 @@ struct AttnArgs {
 };
 hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st);
 
+struct LayerNormArgs {
+    const float *x; float *y;            // [rows][ld*]
+    const float *w, *b;                  // [D]
+    long long ldx, ldy;
+    int rows, D;
+    float eps;
+};
+hipError_t launch_layernorm(const LayerNormArgs &a, hipStream_t st);
+
 }  // namespace smk

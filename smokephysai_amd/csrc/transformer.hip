@@ -268,4 +268,59 @@ hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// nn.LayerNorm over the last dimension (smokephys_net.py:149-150,161,165; eps 1e-5, biased variance): one wave per token row,
+// the row held in registers (D <= 2048: up to 8 float4 per lane), mean and centred second moment by wave reductions, one
+// read and one write of the row -- an HBM-bound stream.
+template <int NV>   // float4 per lane
+__global__ __launch_bounds__(256) void k_layernorm(const LayerNormArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float *xp = a.x + (long long)row * a.ldx;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < a.D ? *reinterpret_cast<const float4 *>(xp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)a.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < a.D) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)a.D + a.eps);
+    float *yp = a.y + (long long)row * a.ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < a.D) {
+            const float4 w = *reinterpret_cast<const float4 *>(a.w + c), b = *reinterpret_cast<const float4 *>(a.b + c);
+            *reinterpret_cast<float4 *>(yp + c) = make_float4((v[i].x - mean) * rstd * w.x + b.x, (v[i].y - mean) * rstd * w.y + b.y,
+                                                              (v[i].z - mean) * rstd * w.z + b.z, (v[i].w - mean) * rstd * w.w + b.w);
+        }
+    }
+}
+
+hipError_t launch_layernorm(const LayerNormArgs &a, hipStream_t st) {
+    const dim3 grid((a.rows + 3) / 4), block(256);
+    const int nv = (a.D + 255) / 256;
+    if (nv <= 1) hipLaunchKernelGGL(k_layernorm<1>, grid, block, 0, st, a);
+    else if (nv <= 2) hipLaunchKernelGGL(k_layernorm<2>, grid, block, 0, st, a);
+    else if (nv <= 4) hipLaunchKernelGGL(k_layernorm<4>, grid, block, 0, st, a);
+    else if (nv <= 8) hipLaunchKernelGGL(k_layernorm<8>, grid, block, 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 }  // namespace smk

@@ -27,3 +27,22 @@ def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: 
                                         q.stride(1), k.stride(1), v.stride(1), out.stride(1), float(scale),
                                         _lib.stream_ptr(dev)))
     return out
+
+
+def hip_layernorm_supported(D: int) -> bool:
+    return D % 4 == 0 and 4 <= D <= 2048
+
+
+def hip_layernorm(x: torch.Tensor, ln: torch.nn.LayerNorm, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.LayerNorm over the last dimension as one libsmokehip launch (smk_layernorm); x [..., D] float32, dense rows."""
+    dev = _lib.require_cuda(x.device, "hip_layernorm")
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if x2.stride(1) != 1 or x.dtype != torch.float32:
+        raise ValueError("hip_layernorm: float32 rows with unit inner stride")
+    if out is None:
+        out = torch.empty(x.shape, device=dev, dtype=torch.float32)
+    y2 = out.view(-1, D)
+    _lib.check(_lib.load().smk_layernorm(x2.data_ptr(), x2.shape[0], D, x2.stride(0), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                        float(ln.eps), y2.data_ptr(), y2.stride(0), _lib.stream_ptr(dev)))
+    return out

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from .chaos_attention import ChaosAttention
 from .encoder import HipEncoder, encoder_weight_dict
-from .attention import hip_attention, hip_attention_supported
+from .attention import hip_attention, hip_attention_supported, hip_layernorm, hip_layernorm_supported
 from .linear import HipLinear, hip_linear_supported
 from .physics_regularizer import PhysicsRegularizer
 
@@ -147,7 +147,7 @@ class SmokePhysNet(nn.Module):
         136-168; chaos_attention.py:68-114) with every token-wise nn.Linear as one fused libsmokehip launch:
         bias, the pos-embedding / chaos-term addend, GELU / ReLU and the residual add ride in the GEMM epilogue.
         softmax attention runs on libsmokehip's flash kernel (smk_attention, chaos term folded into Q) and the
-        per-layer Lorenz / chaos-gate chain on smk_chaos_addend; LayerNorm stays on PyTorch-ROCm.  Returns (features [B,L,D], decoded [B,L,C])."""
+        per-layer Lorenz / chaos-gate chain on smk_chaos_addend, LayerNorm on smk_layernorm.  Returns (features [B,L,D], decoded [B,L,C])."""
         B, L, _ = tokens.shape
         D = self.hidden_dim
         x = self._hl("feature_proj", self.feature_proj)(tokens, periodic_add=self._pos_embed(pool_size),
@@ -155,7 +155,7 @@ class SmokePhysNet(nn.Module):
         for li, layer in enumerate(self.chaos_layers):
             att, pre = layer.chaos_attention, f"chaos_layers.{li}."
             H, d = att.num_heads, att.head_dim
-            h = F.layer_norm(x, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+            h = self._ln(x, layer.norm1)
             # fused q|k|v projection; the chaos addend only touches the q columns
             key = (li, B)
             add15 = self._addend_bufs.get(key)
@@ -172,12 +172,18 @@ class SmokePhysNet(nn.Module):
                                                    v.view(B, L, H, d).transpose(1, 2), scale=scale)
                 o = o.transpose(1, 2).reshape(B, L, D)
             self._hl(pre + "chaos_attention.out_proj", att.out_proj)(o, residual=x, out=x)          # x += attn
-            h = F.layer_norm(x, (D,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+            h = self._ln(x, layer.norm2)
             f = self._hl(pre + "ffn.0", layer.ffn[0])(h, activation="gelu")
             self._hl(pre + "ffn.3", layer.ffn[3])(f, residual=x, out=x)                             # x += ffn
         dec = self._hl("output_decoder.0", self.output_decoder[0])(x, activation="relu")
         dec = self._hl("output_decoder.2", self.output_decoder[2])(dec)
         return x, dec
+
+    @staticmethod
+    def _ln(x: torch.Tensor, ln: nn.LayerNorm) -> torch.Tensor:
+        if hip_layernorm_supported(x.shape[-1]) and ln.elementwise_affine and ln.bias is not None:
+            return hip_layernorm(x, ln)
+        return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
 
     def _hip_body_ok(self, tokens: torch.Tensor) -> bool:
         if self.linear_dtype != "bf16x3" or self.training or torch.is_grad_enabled():

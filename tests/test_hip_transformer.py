@@ -76,3 +76,17 @@ def test_attention_reads_strided_qkv_and_rejects_other_head_dims():
     assert not hip_attention_supported(1024, 32) and not hip_attention_supported(100, 64)
     with pytest.raises(Exception, match="head_dim 64"):
         hip_attention(qkv[..., :256].contiguous(), qkv[..., :256].contiguous(), qkv[..., :256].contiguous(), 8, 0.125)
+
+
+@pytest.mark.parametrize("rows,D", [(1024, 512), (4099, 512), (37, 64), (256, 2048), (5, 132)])
+def test_layernorm_matches_torch(rows, D):
+    from smokephysai_amd.models.attention import hip_layernorm
+    g = torch.Generator(device="cuda").manual_seed(rows + D)
+    ln = torch.nn.LayerNorm(D).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(D, device="cuda", generator=g))
+        ln.bias.copy_(torch.randn(D, device="cuda", generator=g))
+        x = torch.randn(rows, D, device="cuda", generator=g) * 3 + 1.5
+        ref = torch.nn.functional.layer_norm(x.double(), (D,), ln.weight.double(), ln.bias.double(), ln.eps)
+        out = hip_layernorm(x, ln)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-6
