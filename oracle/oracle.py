@@ -268,3 +268,79 @@ def draw_sources(grid_size, rng=np.random):
         pos.append((x, y))
         inten.append(i)
     return pos, inten
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Transformer body: numpy restatements in the REFERENCE's own formulation (the chaos scores are a
+# separate term here, not folded into Q), double precision unless the reference's fp32 order matters.  Checker only.
+def linear(x, weight, bias=None):                             # nn.Linear (smokephys_net.py:38,50-54,153-158)
+    y = np.asarray(x, np.float64) @ np.asarray(weight, np.float64).T
+    return y if bias is None else y + np.asarray(bias, np.float64)
+
+
+def gelu(v):                                                  # nn.GELU() default = erf form (smokephys_net.py:155)
+    from scipy.special import erf
+    v = np.asarray(v, np.float64)
+    return 0.5 * v * (1.0 + erf(v / np.sqrt(2.0)))
+
+
+def layernorm(x, weight, bias, eps=1e-5):                     # nn.LayerNorm (smokephys_net.py:149-150): biased variance
+    x = np.asarray(x, np.float64)
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * np.asarray(weight, np.float64) + np.asarray(bias, np.float64)
+
+
+def lorenz_states(noise, sigma=10.0, rho=28.0, beta=8.0 / 3.0, dt=0.01):
+    """chaos_attention.py:39-59: x0,y0,z0 = randn(B,1)*0.1 (noise [3,B] = the three draws), five explicit-Euler steps, in
+    fp32 with the reference's operation order.  Returns [B,5,3] float32."""
+    f = np.float32
+    n = np.asarray(noise, np.float32).reshape(3, -1)
+    x, y, z = n[0] * f(0.1), n[1] * f(0.1), n[2] * f(0.1)
+    sigma, rho, beta, dt = f(sigma), f(rho), f(beta), f(dt)
+    out = []
+    for _ in range(5):
+        dx = sigma * (y - x)
+        dy = x * (rho - z) - y
+        dz = x * y - beta * z
+        x, y, z = x + dt * dx, y + dt * dy, z + dt * dz
+        out.append(np.stack([x, y, z], -1))
+    return np.stack(out, 1).astype(np.float32)
+
+
+def chaos_field(noise, seq_len):                              # chaos_attention.py:61-65: the 5 states tiled along the sequence
+    s = lorenz_states(noise)
+    reps = (seq_len + 4) // 5
+    return np.tile(s, (1, reps, 1))[:, :seq_len]
+
+
+def chaos_attention(x, w, noise, num_heads, chaos_strength=0.1, temperature=1.0, prefix=""):
+    """ChaosAttention.forward (chaos_attention.py:68-114) as written there: scores + strength * gate * chaos_scores, softmax,
+    @ V, merge heads, out_proj.  w: dict of the module's tensors (keys '<prefix>q_proj.weight', ...)."""
+    g = lambda k: np.asarray(w[prefix + k], np.float64)
+    x = np.asarray(x, np.float64)
+    B, L, D = x.shape
+    H, d = num_heads, D // num_heads
+    heads = lambda t: t.reshape(B, L, H, d).transpose(0, 2, 1, 3)
+    q = heads(linear(x, g("q_proj.weight"), g("q_proj.bias")))
+    k = heads(linear(x, g("k_proj.weight"), g("k_proj.bias")))
+    v = heads(linear(x, g("v_proj.weight"), g("v_proj.bias")))
+    scores = q @ k.transpose(0, 1, 3, 2) / np.sqrt(d)
+    cf = linear(chaos_field(noise, L), g("chaos_proj.weight"), g("chaos_proj.bias"))          # [B,L,D]
+    gate = 1.0 / (1.0 + np.exp(-linear(cf, g("chaos_gate.weight"), g("chaos_gate.bias"))))   # [B,L,1]
+    chaos_scores = heads(cf) @ k.transpose(0, 1, 3, 2) / np.sqrt(d)
+    final = (scores + chaos_strength * chaos_scores * gate[:, None]) / temperature
+    final = final - final.max(-1, keepdims=True)
+    p = np.exp(final)
+    p /= p.sum(-1, keepdims=True)
+    out = (p @ v).transpose(0, 2, 1, 3).reshape(B, L, D)
+    return linear(out, g("out_proj.weight"), g("out_proj.bias"))
+
+
+def chaos_transformer_layer(x, w, noise, num_heads, chaos_strength=0.1):
+    """ChaosTransformerLayer.forward in eval mode (smokephys_net.py:161-167): pre-LN block, dropout off."""
+    x = np.asarray(x, np.float64)
+    x = x + chaos_attention(layernorm(x, w["norm1.weight"], w["norm1.bias"]), w, noise, num_heads, chaos_strength,
+                            prefix="chaos_attention.")
+    h = gelu(linear(layernorm(x, w["norm2.weight"], w["norm2.bias"]), w["ffn.0.weight"], w["ffn.0.bias"]))
+    return x + linear(h, w["ffn.3.weight"], w["ffn.3.bias"])

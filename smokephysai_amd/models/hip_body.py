@@ -1,0 +1,92 @@
+"""The eval-mode transformer body on libsmokehip: caches the re-laid-out weights of every token-wise nn.Linear and runs
+one pre-LN ChaosTransformerLayer (smokephys_net.py:136-168; chaos_attention.py:68-114) as 7 launches --
+LayerNorm, chaos addend, fused q|k|v projection (+ chaos term on the q columns), flash attention, out_proj (+ residual),
+LayerNorm, FFN up (+ GELU), FFN down (+ residual)."""
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .attention import hip_attention, hip_attention_supported, hip_layernorm, hip_layernorm_supported
+from .linear import HipLinear, hip_linear_supported
+
+
+def _fp(lin: nn.Linear):
+    return (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+
+
+class HipBody:
+    def __init__(self):
+        self.linears: Dict[str, Tuple[HipLinear, tuple]] = {}      # name -> (handle, fingerprint of the source tensors)
+        self.sources: Dict[str, tuple] = {}                        # name -> the nn.Linear modules the handle mirrors
+        self.addend_bufs: Dict[tuple, torch.Tensor] = {}           # (name, batch) -> [B,5,3D] addend of the fused q|k|v layer
+
+    # ---- weight mirrors ----------------------------------------------------------------------------------------
+    def linear(self, name: str, lin: nn.Linear) -> HipLinear:
+        """Device copy of one nn.Linear in the kernel's layout, rebuilt when its tensors change."""
+        fp = _fp(lin)
+        hit = self.linears.get(name)
+        if hit is None or hit[1] != fp:
+            if hit is not None:
+                hit[0].close()
+            hit = self.linears[name] = (HipLinear.from_module(lin), fp)
+            self.sources[name] = (lin,)
+        return hit[0]
+
+    def qkv(self, name: str, att) -> HipLinear:
+        """q_proj | k_proj | v_proj as ONE [3D, D] layer: x is read once and the three projections are a single launch."""
+        mods = (att.q_proj, att.k_proj, att.v_proj)
+        fp = tuple(_fp(m) for m in mods)
+        hit = self.linears.get(name)
+        if hit is None or hit[1] != fp:
+            if hit is not None:
+                hit[0].close()
+            hit = self.linears[name] = (HipLinear(torch.cat([m.weight for m in mods]), torch.cat([m.bias for m in mods])), fp)
+            self.sources[name] = mods
+        return hit[0]
+
+    def fingerprint(self) -> tuple:
+        return tuple(_fp(m) for mods in self.sources.values() for m in mods)
+
+    # ---- ops ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def layernorm(x: torch.Tensor, ln: nn.LayerNorm) -> torch.Tensor:
+        if hip_layernorm_supported(x.shape[-1]) and ln.elementwise_affine and ln.bias is not None:
+            return hip_layernorm(x, ln)
+        return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
+
+    @staticmethod
+    def layer_supported(layer, L: int) -> bool:
+        a = layer.chaos_attention
+        if a.q_proj.bias is None or a.k_proj.bias is None or a.v_proj.bias is None or L % 32 != 0:
+            return False
+        lins = [a.q_proj, a.k_proj, a.v_proj, a.out_proj, layer.ffn[0], layer.ffn[3]]
+        return all(hip_linear_supported(m.in_features, m.out_features) for m in lins)
+
+    def layer(self, name: str, layer, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One ChaosTransformerLayer, eval mode, IN PLACE on x [B,L,D] (the residual stream).  noise: the layer's three
+        randn(B,1) draws [3,B,1] or None to draw them like the reference does."""
+        B, L, D = x.shape
+        att = layer.chaos_attention
+        H, d = att.num_heads, att.head_dim
+        h = self.layernorm(x, layer.norm1)
+        add15 = self.addend_bufs.get((name, B))
+        if add15 is None or add15.device != x.device:       # the k|v columns stay zero, the q columns are rewritten per call
+            add15 = self.addend_bufs[(name, B)] = torch.zeros(B, 5, 3 * D, device=x.device)
+        att.chaos_addend_hip(B, x.device, noise, out=add15)
+        qkv = self.qkv(name + "chaos_attention.qkv", att)(h, periodic_add=add15, rows_per_group=L)
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        scale = 1.0 / (math.sqrt(d) * att.temperature)
+        if hip_attention_supported(L, d):
+            o = hip_attention(q, k, v, H, scale)                           # [B, L, D]: heads already merged
+        else:
+            o = F.scaled_dot_product_attention(q.view(B, L, H, d).transpose(1, 2), k.view(B, L, H, d).transpose(1, 2),
+                                               v.view(B, L, H, d).transpose(1, 2), scale=scale)
+            o = o.transpose(1, 2).reshape(B, L, D)
+        self.linear(name + "chaos_attention.out_proj", att.out_proj)(o, residual=x, out=x)        # x += attn
+        h = self.layernorm(x, layer.norm2)
+        f = self.linear(name + "ffn.0", layer.ffn[0])(h, activation="gelu")
+        self.linear(name + "ffn.3", layer.ffn[3])(f, residual=x, out=x)                           # x += ffn
+        return x

@@ -10,7 +10,6 @@ are PyTorch-ROCm ops.
 Training (train mode): the encoder runs as autograd-tracked PyTorch ops with batch-statistics BatchNorm, exactly the
 reference's op sequence (smokephys_net.py:87-91).
 """
-import math
 from typing import Optional
 
 import torch
@@ -19,8 +18,8 @@ import torch.nn.functional as F
 
 from .chaos_attention import ChaosAttention
 from .encoder import HipEncoder, encoder_weight_dict
-from .attention import hip_attention, hip_attention_supported, hip_layernorm, hip_layernorm_supported
-from .linear import HipLinear, hip_linear_supported
+from .hip_body import HipBody
+from .linear import hip_linear_supported
 from .physics_regularizer import PhysicsRegularizer
 
 
@@ -65,8 +64,7 @@ class SmokePhysNet(nn.Module):
         self.physics_regularizer = PhysicsRegularizer()
         self._hip = None          # (HipEncoder, weight fingerprint)
         self._pos_cache = None    # (fingerprint, tensor)
-        self._hip_linears = {}    # nn.Linear name -> (HipLinear, weight fingerprint)
-        self._addend_bufs = {}    # (layer, batch) -> [B,5,3D] chaos addend of the fused q|k|v projection
+        self._hip_body = HipBody()   # libsmokehip mirrors of the token-wise linear layers + per-layer scratch
 
     # ---- HIP encoder plumbing -------------------------------------------------------------------------------
     def _encoder_fingerprint(self):
@@ -105,85 +103,28 @@ class SmokePhysNet(nn.Module):
             self._pos_cache = (fp, pe.detach())
         return pe
 
-    # ---- transformer body on libsmokehip's split-bf16 linear kernel (eval only) -------------------------------------
-    def _hl(self, name: str, lin: nn.Linear) -> HipLinear:
-        """Device copy of one nn.Linear in the kernel's layout, rebuilt when its tensors change."""
-        fp = (lin.weight.data_ptr(), lin.weight._version,
-              None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
-        hit = self._hip_linears.get(name)
-        if hit is None or hit[1] != fp:
-            if hit is not None:
-                hit[0].close()
-            hit = self._hip_linears[name] = (HipLinear.from_module(lin), fp)
-        return hit[0]
-
-    def _hl_qkv(self, name: str, att: ChaosAttention) -> HipLinear:
-        """q_proj | k_proj | v_proj as ONE [3D, D] layer: x is read once and the three projections are a single launch."""
-        mods = (att.q_proj, att.k_proj, att.v_proj)
-        fp = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
-        hit = self._hip_linears.get(name)
-        if hit is None or hit[1] != fp:
-            if hit is not None:
-                hit[0].close()
-            hit = self._hip_linears[name] = (HipLinear(torch.cat([m.weight for m in mods]), torch.cat([m.bias for m in mods])), fp)
-        return hit[0]
-
+    # ---- transformer body on libsmokehip (eval only; per-layer code: hip_body.py) ----------------------------------
     def hip_weights_fingerprint(self):
         """Identity + version of every tensor libsmokehip keeps a re-laid-out copy of (GraphedSmokePhysNet re-captures
         when this changes)."""
-        fp = [self._encoder_fingerprint(), (self.pos_embedding.data_ptr(), self.pos_embedding._version)]
-        for name in self._hip_linears:
-            if name.endswith(".qkv"):
-                mods = [self.get_submodule(name[:-3] + p) for p in ("q_proj", "k_proj", "v_proj")]
-            else:
-                mods = [self.get_submodule(name)]
-            for lin in mods:
-                fp.append((lin.weight.data_ptr(), lin.weight._version,
-                           None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version)))
-        return tuple(fp)
+        return (self._encoder_fingerprint(), (self.pos_embedding.data_ptr(), self.pos_embedding._version),
+                self._hip_body.fingerprint())
 
     def _body_hip(self, tokens: torch.Tensor, chaos_noise: Optional[torch.Tensor], pool_size: int):
         """feature_proj + pos-embed, the pre-LN chaos transformer layers and output_decoder (smokephys_net.py:95-114,
         136-168; chaos_attention.py:68-114) with every token-wise nn.Linear as one fused libsmokehip launch:
-        bias, the pos-embedding / chaos-term addend, GELU / ReLU and the residual add ride in the GEMM epilogue.
-        softmax attention runs on libsmokehip's flash kernel (smk_attention, chaos term folded into Q) and the
-        per-layer Lorenz / chaos-gate chain on smk_chaos_addend, LayerNorm on smk_layernorm.  Returns (features [B,L,D], decoded [B,L,C])."""
+        bias, the pos-embedding / chaos-term addend, GELU / ReLU and the residual add ride in the GEMM epilogue;
+        softmax attention on the flash kernel (smk_attention, chaos term folded into Q), the per-layer Lorenz /
+        chaos-gate chain on smk_chaos_addend, LayerNorm on smk_layernorm.  Returns (features [B,L,D], decoded [B,L,C])."""
         B, L, _ = tokens.shape
-        D = self.hidden_dim
-        x = self._hl("feature_proj", self.feature_proj)(tokens, periodic_add=self._pos_embed(pool_size),
-                                                        rows_per_group=B * L)
+        body = self._hip_body
+        x = body.linear("feature_proj", self.feature_proj)(tokens, periodic_add=self._pos_embed(pool_size),
+                                                           rows_per_group=B * L)
         for li, layer in enumerate(self.chaos_layers):
-            att, pre = layer.chaos_attention, f"chaos_layers.{li}."
-            H, d = att.num_heads, att.head_dim
-            h = self._ln(x, layer.norm1)
-            # fused q|k|v projection; the chaos addend only touches the q columns
-            key = (li, B)
-            add15 = self._addend_bufs.get(key)
-            if add15 is None or add15.device != x.device:   # [B,5,3D]; the k|v columns stay zero, the q columns are rewritten per call
-                add15 = self._addend_bufs[key] = torch.zeros(B, 5, 3 * D, device=x.device)
-            att.chaos_addend_hip(B, x.device, None if chaos_noise is None else chaos_noise[li], out=add15)
-            qkv = self._hl_qkv(pre + "chaos_attention.qkv", att)(h, periodic_add=add15, rows_per_group=L)
-            q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
-            scale = 1.0 / (math.sqrt(d) * att.temperature)
-            if hip_attention_supported(L, d):
-                o = hip_attention(q, k, v, H, scale)                       # [B, L, D]: heads already merged
-            else:
-                o = F.scaled_dot_product_attention(q.view(B, L, H, d).transpose(1, 2), k.view(B, L, H, d).transpose(1, 2),
-                                                   v.view(B, L, H, d).transpose(1, 2), scale=scale)
-                o = o.transpose(1, 2).reshape(B, L, D)
-            self._hl(pre + "chaos_attention.out_proj", att.out_proj)(o, residual=x, out=x)          # x += attn
-            h = self._ln(x, layer.norm2)
-            f = self._hl(pre + "ffn.0", layer.ffn[0])(h, activation="gelu")
-            self._hl(pre + "ffn.3", layer.ffn[3])(f, residual=x, out=x)                             # x += ffn
-        dec = self._hl("output_decoder.0", self.output_decoder[0])(x, activation="relu")
-        dec = self._hl("output_decoder.2", self.output_decoder[2])(dec)
+            body.layer(f"chaos_layers.{li}.", layer, x, None if chaos_noise is None else chaos_noise[li])
+        dec = body.linear("output_decoder.0", self.output_decoder[0])(x, activation="relu")
+        dec = body.linear("output_decoder.2", self.output_decoder[2])(dec)
         return x, dec
-
-    @staticmethod
-    def _ln(x: torch.Tensor, ln: nn.LayerNorm) -> torch.Tensor:
-        if hip_layernorm_supported(x.shape[-1]) and ln.elementwise_affine and ln.bias is not None:
-            return hip_layernorm(x, ln)
-        return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
 
     def _hip_body_ok(self, tokens: torch.Tensor) -> bool:
         if self.linear_dtype != "bf16x3" or self.training or torch.is_grad_enabled():
@@ -191,12 +132,8 @@ class SmokePhysNet(nn.Module):
         if not tokens.is_cuda or tokens.dtype != torch.float32:
             return False
         lins = [self.feature_proj, self.output_decoder[0], self.output_decoder[2]]
-        for layer in self.chaos_layers:
-            a = layer.chaos_attention
-            if a.q_proj.bias is None or a.k_proj.bias is None or a.v_proj.bias is None:
-                return False
-            lins += [a.q_proj, a.k_proj, a.v_proj, a.out_proj, layer.ffn[0], layer.ffn[3]]
-        return all(hip_linear_supported(m.in_features, m.out_features) for m in lins) and tokens.shape[1] % 32 == 0
+        return (all(hip_linear_supported(m.in_features, m.out_features) for m in lins)
+                and all(HipBody.layer_supported(layer, tokens.shape[1]) for layer in self.chaos_layers))
 
     def forward(self, x: torch.Tensor, return_features: bool = False, chaos_noise: Optional[torch.Tensor] = None,
                 encoder_dtype: Optional[str] = None) -> dict:

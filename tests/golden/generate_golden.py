@@ -17,6 +17,8 @@ What is recorded:
   encoder_*.npz           input_encoder weights (+ BN running stats), frames, features
   model_small.npz         small-config SmokePhysNet weights + explicit chaos noise + outputs
   train_batch.npz         one seeded batch -> the four train.py loss scalars + grad norm
+  transformer_layer.npz   one ChaosTransformerLayer (dim 128, 2 heads of 64, L=128): weights, input, the three noise draws,
+                          the ChaosAttention output and the layer output
 """
 import os
 import sys
@@ -33,7 +35,7 @@ import torch.nn.functional as F
 from src.physics.navier_stokes import NavierStokesSimulator
 from src.physics.smoke_simulator import SmokeSimulator
 from src.physics.fractal_generator import FractalGenerator
-from src.models.smokephys_net import SmokePhysNet
+from src.models.smokephys_net import SmokePhysNet, ChaosTransformerLayer
 from src.models.physics_regularizer import PhysicsRegularizer
 from src.utils.data_loader import SyntheticSmokeDataset
 
@@ -409,11 +411,35 @@ def gen_model_full_checksums():
          nparams=np.array(sum(p.numel() for p in model.parameters())))
 
 
+def gen_transformer_layer():
+    """One reference ChaosTransformerLayer in eval mode (smokephys_net.py:136-168, chaos_attention.py:68-114): pins the
+    build's body kernels (linear, chaos addend, attention, LayerNorm) to the reference's own arithmetic."""
+    torch.manual_seed(21)
+    layer = ChaosTransformerLayer(128, 2, chaos_strength=0.1).eval()
+    gen = torch.Generator().manual_seed(22)
+    B, L = 2, 128
+    with torch.no_grad():
+        for prm in layer.parameters():          # non-trivial LayerNorm affine, larger logits than the default init gives
+            if prm.dim() == 1:
+                prm.add_(torch.randn(prm.shape, generator=gen) * 0.1)
+        layer.chaos_attention.q_proj.weight.mul_(3.0)
+        layer.chaos_attention.k_proj.weight.mul_(3.0)
+        x = torch.randn(B, L, 128, generator=gen)
+        noise = chaos_noise(23, 1, B)[0]                      # [3,B,1]
+        torch.manual_seed(23)
+        attn = layer.chaos_attention(layer.norm1(x))
+        torch.manual_seed(23)
+        out = layer(x)
+    rec = {f"w::{k}": v.numpy() for k, v in layer.state_dict().items()}
+    rec.update(x=x.numpy(), noise=noise.numpy(), attention_out=attn.numpy(), layer_out=out.numpy())
+    save("transformer_layer.npz", **rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stages", "backtrace", "traj", "fractal", "dataset", "chaos", "encoder", "model", "full"]
+    which = sys.argv[1:] or ["stages", "backtrace", "traj", "fractal", "dataset", "chaos", "encoder", "model", "full", "layer"]
     fns = dict(stages=gen_stages, backtrace=gen_backtrace, traj=gen_traj, fractal=gen_fractal,
                dataset=gen_dataset, chaos=gen_chaos_stats, encoder=gen_encoder, model=gen_model_small,
-               full=gen_model_full_checksums)
+               full=gen_model_full_checksums, layer=gen_transformer_layer)
     with torch.no_grad():
         for w in which:
             if w in ("model",):

@@ -222,7 +222,7 @@ def test_hip_body_matches_fp32_torch_body(golden):
     with torch.no_grad():
         assert model._hip_body_ok(torch.empty(2, 1024, 128, device="cuda"))
         hip = model(x, return_features=True, chaos_noise=noise)
-        assert len(model._hip_linears) == 3 + 4 * len(model.chaos_layers)       # q|k|v fused into one layer
+        assert len(model._hip_body.linears) == 3 + 4 * len(model.chaos_layers)       # q|k|v fused into one layer
         model.linear_dtype = "f32"
         ref = model(x, return_features=True, chaos_noise=noise)
         model.linear_dtype = "bf16x3"

@@ -90,3 +90,32 @@ def test_layernorm_matches_torch(rows, D):
         ref = torch.nn.functional.layer_norm(x.double(), (D,), ln.weight.double(), ln.bias.double(), ln.eps)
         out = hip_layernorm(x, ln)
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+
+
+def test_hip_transformer_layer_matches_reference_golden(golden):
+    """One ChaosTransformerLayer through libsmokehip (LayerNorm, chaos addend, fused q|k|v, flash attention, out_proj +
+    residual, FFN with GELU + residual) against the REFERENCE's captured output for the same weights, input and noise
+    draws (tests/golden/transformer_layer.npz; dim 128, 2 heads of 64, L = 128) -- and the attention sub-block alone."""
+    from smokephysai_amd.models import ChaosTransformerLayer
+    from smokephysai_amd.models.hip_body import HipBody
+    g = golden("transformer_layer.npz")
+    layer = ChaosTransformerLayer(128, 2, chaos_strength=0.1)
+    layer.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w::")})
+    layer = layer.cuda().eval()
+    x = torch.from_numpy(g["x"]).cuda()
+    noise = torch.from_numpy(g["noise"]).cuda()
+    body = HipBody()
+    assert HipBody.layer_supported(layer, x.shape[1])
+    with torch.no_grad():
+        out = body.layer("t.", layer, x.clone(), noise)
+        assert rel_err(out.cpu().numpy(), g["layer_out"]) < 1e-4
+        # attention sub-block: LN1 -> q|k|v (+ chaos term) -> attention -> out_proj (no residual)
+        from smokephysai_amd.models.attention import hip_attention
+        h = body.layernorm(x, layer.norm1)
+        att = layer.chaos_attention
+        add15 = torch.zeros(2, 5, 3 * 128, device="cuda")
+        att.chaos_addend_hip(2, x.device, noise, out=add15)
+        qkv = body.qkv("t.chaos_attention.qkv", att)(h, periodic_add=add15, rows_per_group=128)
+        o = hip_attention(qkv[..., :128], qkv[..., 128:256], qkv[..., 256:], 2, 0.125)
+        attn = body.linear("t.chaos_attention.out_proj", att.out_proj)(o)
+        assert rel_err(attn.cpu().numpy(), g["attention_out"]) < 1e-4

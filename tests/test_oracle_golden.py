@@ -212,3 +212,18 @@ def test_encoder_features(golden, N):
         assert rel_err(feats, g["features"][-1:]) < 1e-5
         fast = oracle.encoder_features_fast(frames[-1:], w)     # the timing-grade port bench.py uses as CPU baseline
         assert rel_err(fast, g["features"][-1:]) < 1e-5
+
+
+def test_transformer_layer_oracle_matches_reference(golden):
+    """oracle.chaos_attention / chaos_transformer_layer (numpy, the reference's own formulation with the separate chaos-score
+    term) against the reference ChaosTransformerLayer's captured outputs (dim 128, 2 heads of 64, L = 128)."""
+    g = golden("transformer_layer.npz")
+    w = {k[3:]: v for k, v in g.items() if k.startswith("w::")}
+    attn = oracle.chaos_attention(oracle.layernorm(g["x"], w["norm1.weight"], w["norm1.bias"]), w, g["noise"], 2,
+                                  prefix="chaos_attention.")
+    assert rel_err(attn, g["attention_out"]) < 2e-6
+    out = oracle.chaos_transformer_layer(g["x"], w, g["noise"], 2)
+    assert rel_err(out, g["layer_out"]) < 2e-6
+    # the Q-fold identity the HIP path relies on (SURVEY 8a row 13): (Q + strength * gate * C_h) K^T == scores + strength * gate * chaos_scores
+    states = oracle.lorenz_states(g["noise"])
+    assert states.shape == (2, 5, 3) and states.dtype == np.float32
