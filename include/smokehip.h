@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 1
+#define SMK_ABI_VERSION 2
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -170,6 +170,13 @@ int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_strid
  * 1e-4 relative of the fp32 GEMM the reference runs; measured ~1e-6).
  * weight [out_features][in_features] fp32 (PyTorch layout), bias [out_features] or NULL; both are read once, on `stream`.
  * Requires in_features % 64 == 0 and out_features % 32 == 0 (else SMK_ERR_UNSUPPORTED). */
+/* Activation formats between the body kernels.  SMK_FMT_SPLIT_BF16 keeps an fp32-accurate activation as two bf16 per
+ * element (x = hi + lo) in the layout the MFMA kernels consume: per row, per group of 8 consecutive features, 8 hi then
+ * 8 lo ([rows][features/8][2][8] bf16 -- the same 4 bytes per element as fp32, rows dense).  A producer that writes it
+ * (LayerNorm, a linear layer's epilogue, the attention kernel) saves the consuming linear layer the split arithmetic in
+ * its K loop. */
+typedef enum smk_format { SMK_FMT_F32 = 0, SMK_FMT_SPLIT_BF16 = 1 } smk_format;
+
 typedef struct smk_linear smk_linear;
 typedef enum smk_activation { SMK_ACT_NONE = 0, SMK_ACT_GELU = 1 /* erf form, nn.GELU() */, SMK_ACT_RELU = 2 } smk_activation;
 
@@ -185,10 +192,12 @@ int smk_linear_destroy(smk_linear *lin);
  *   periodic_add[g][(i % rows_per_group) % period] before the activation -- the chaos term folded into Q
  *   (the 5-step Lorenz field tiled along the sequence, chaos_attention.py:61-65,85-100); rows_per_group % 32 == 0.
  *   residual and periodic_add are mutually exclusive (no layer of the path uses both).
+ *   x_format / y_format: smk_format of x and y (void pointers: fp32 or split-bf16 storage); a split tensor has dense rows
+ *   (ldx == in_features, ldy == out_features); a split y excludes residual.
  * Enqueued on `stream`, no synchronisation. */
-int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy,
+int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx, void *y, int64_t ldy,
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
-                       int32_t period, int32_t activation, void *stream);
+                       int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream);
 
 /* The chaos term of one ChaosAttention layer folded into Q (chaos_attention.py:39-66 lorenz_system + generate_chaos_field,
  * :85-100 chaos_proj / chaos_gate / chaos_strength): noise [3][B] = the three randn(B,1) draws (before the 0.1 scale),
@@ -205,14 +214,17 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
  * (softmax(((Q + addend) K^T) * scale) V, heads merged back): q, k, v [B][L][ld*] fp32 with head h in columns
  * head_dim*h .. of a token row (the layout q_proj / k_proj / v_proj write), out [B][L][ldo] in the same convention
  * (what out_proj reads -- no transpose copy).  Flash style (no L x L tensor), split-bf16 MFMA, fp32-class accuracy.
- * Requires head_dim == 64 and L % 128 == 0 (else SMK_ERR_UNSUPPORTED); scale = 1 / (sqrt(head_dim) * temperature). */
-int smk_attention(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t L, int32_t H,
-                  int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, void *stream);
+ * Requires head_dim == 64 and L % 128 == 0 (else SMK_ERR_UNSUPPORTED); scale = 1 / (sqrt(head_dim) * temperature).
+ * out_format: smk_format of out (split: dense rows, ldo == H * head_dim). */
+int smk_attention(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
+                  int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
+                  void *stream);
 
 /* nn.LayerNorm over the last dimension (smokephys_net.py:149-150, applied at :161,:165; biased variance, eps as given):
- * x [rows][ldx] -> y [rows][ldy], weight / bias [D].  D % 4 == 0, D <= 2048 (else SMK_ERR_UNSUPPORTED). */
+ * x [rows][ldx] -> y [rows][ldy], weight / bias [D].  D % 4 == 0, D <= 2048 (else SMK_ERR_UNSUPPORTED).
+ * y_format: smk_format of y (split: D % 8 == 0, dense rows, ldy == D). */
 int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const float *weight, const float *bias, double eps,
-                  float *y, int64_t ldy, void *stream);
+                  void *y, int64_t ldy, int32_t y_format, void *stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("SMOKEHIP_LIB") or os.path.join(_HERE, "libsmokehip.so
 
 SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
 SMK_ACT_NONE, SMK_ACT_GELU, SMK_ACT_RELU = 0, 1, 2
+SMK_FMT_F32, SMK_FMT_SPLIT_BF16 = 0, 1
 STAGE_BUOY_DIFFUSE, STAGE_PROJECT, STAGE_ADVECT_U, STAGE_ADVECT_V, STAGE_ADVECT_D = range(5)
 DTYPES = {"f32": SMK_F32, "fp32": SMK_F32, "float32": SMK_F32, "bf16x3": SMK_BF16X3, "bf16": SMK_BF16, "i8x3": SMK_I8X3}
 
@@ -61,13 +62,13 @@ _SIGNATURES = {
     "smk_chaos_addend": [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                          C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p],
     "smk_attention": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                      C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p],
+                      C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_void_p],
     "smk_layernorm": [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64,
-                      C.c_void_p],
+                      C.c_int32, C.c_void_p],
     "smk_linear_create": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
     "smk_linear_destroy": [C.c_void_p],
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
 EXPORTS = ["smk_abi_version", "smk_last_error"] + list(_SIGNATURES)
 

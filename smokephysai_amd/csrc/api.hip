@@ -515,9 +515,9 @@ int smk_linear_destroy(smk_linear *lin) {
     return SMK_OK;
 }
 
-int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy,
+int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx, void *y, int64_t ldy,
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
-                       int32_t period, int32_t activation, void *stream) {
+                       int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream) {
     SMK_REQUIRE(lin && x && y, "null lin/x/y");
     SMK_REQUIRE(rows >= 1 && rows < (1LL << 31) - 256, "1 <= rows < 2^31 - 256");
     SMK_REQUIRE(ldx >= lin->l.K && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "x rows: pitch >= in_features, 16-byte aligned");
@@ -528,14 +528,19 @@ int smk_linear_forward(smk_linear *lin, const float *x, int64_t rows, int64_t ld
     SMK_REQUIRE(!periodic_add || ((uintptr_t)periodic_add & 15) == 0, "periodic_add 16-byte aligned");
     SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_GELU || activation == SMK_ACT_RELU, "activation");
     SMK_REQUIRE(!(residual && periodic_add), "residual and periodic_add are exclusive (no layer of the path needs both)");
+    SMK_REQUIRE((x_format == SMK_FMT_F32 || x_format == SMK_FMT_SPLIT_BF16) && (y_format == SMK_FMT_F32 || y_format == SMK_FMT_SPLIT_BF16),
+                "x_format / y_format");
+    SMK_REQUIRE(x_format == SMK_FMT_F32 || ldx == lin->l.K, "split x: dense rows (ldx == in_features)");
+    SMK_REQUIRE(y_format == SMK_FMT_F32 || (ldy == lin->l.N && !residual), "split y: dense rows (ldy == out_features), no residual");
     if (periodic_add)
         SMK_REQUIRE(period >= 1 && rows_per_group >= 32 && rows_per_group % 32 == 0 && rows % rows_per_group == 0,
                     "periodic_add: period >= 1, rows_per_group a multiple of 32 that divides rows");
     int rc = set_device(lin->device);
     if (rc) return rc;
     LinearCall c;
-    c.x = x; c.ldx = ldx;
-    c.y = y; c.ldy = ldy;
+    c.x = (const float *)x; c.ldx = ldx;
+    c.y = (float *)y; c.ldy = ldy;
+    c.x_split = x_format == SMK_FMT_SPLIT_BF16; c.y_split = y_format == SMK_FMT_SPLIT_BF16;
     c.res = residual; c.ldr = ldr;
     c.padd = periodic_add; c.rows_per_group = periodic_add ? rows_per_group : 1; c.period = periodic_add ? period : 1;
     c.M = (int)rows;
@@ -557,8 +562,9 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
 }
 
 // ------------------------------------------------------------------ softmax attention (chaos term folded into Q)
-int smk_attention(const float *q, const float *k, const float *v, float *out, int32_t B, int32_t L, int32_t H,
-                  int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, void *stream) {
+int smk_attention(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
+                  int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
+                  void *stream) {
     SMK_REQUIRE(q && k && v && out, "null q/k/v/out");
     SMK_REQUIRE(B >= 1 && H >= 1 && L >= 128, "B >= 1, H >= 1, L >= 128");
     if (head_dim != 64 || L % 128 != 0) {
@@ -572,7 +578,8 @@ int smk_attention(const float *q, const float *k, const float *v, float *out, in
     SMK_REQUIRE((int64_t)B * L * ldk < (1LL << 29) && (int64_t)B * L * ldv < (1LL << 29) && (int64_t)B * H * (L / 128) < (1LL << 31),
                 "B * L * ld < 2^29 floats (32-bit buffer offsets)");
     AttnArgs a;
-    a.q = q; a.k = k; a.v = v; a.o = out;
+    SMK_REQUIRE(out_format == SMK_FMT_F32 || (out_format == SMK_FMT_SPLIT_BF16 && ldo == cols), "out_format (split: ldo == H * head_dim)");
+    a.q = q; a.k = k; a.v = v; a.o = (float *)out; a.o_split = out_format == SMK_FMT_SPLIT_BF16;
     a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo;
     a.B = B; a.L = L; a.H = H;
     a.scale_log2e = (float)(scale * 1.4426950408889634074);
@@ -581,7 +588,7 @@ int smk_attention(const float *q, const float *k, const float *v, float *out, in
 
 // ------------------------------------------------------------------ LayerNorm
 int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const float *weight, const float *bias, double eps,
-                  float *y, int64_t ldy, void *stream) {
+                  void *y, int64_t ldy, int32_t y_format, void *stream) {
     SMK_REQUIRE(x && y && weight && bias, "null x/y/weight/bias");
     SMK_REQUIRE(rows >= 1 && rows < (1LL << 31) - 4, "1 <= rows < 2^31");
     if (D < 4 || D % 4 != 0 || D > 2048) {
@@ -591,7 +598,9 @@ int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const fl
     SMK_REQUIRE(ldx >= D && ldy >= D && ldx % 4 == 0 && ldy % 4 == 0, "row pitches >= D, multiples of 4 floats");
     SMK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0, "16-byte aligned tensors");
     LayerNormArgs a;
-    a.x = x; a.y = y; a.w = weight; a.b = bias; a.ldx = ldx; a.ldy = ldy; a.rows = (int)rows; a.D = D; a.eps = (float)eps;
+    SMK_REQUIRE(y_format == SMK_FMT_F32 || (y_format == SMK_FMT_SPLIT_BF16 && D % 8 == 0 && ldy == D), "y_format (split: D % 8 == 0, ldy == D)");
+    a.x = x; a.y = (float *)y; a.w = weight; a.b = bias; a.ldx = ldx; a.ldy = ldy; a.rows = (int)rows; a.D = D; a.eps = (float)eps;
+    a.y_split = y_format == SMK_FMT_SPLIT_BF16;
     return check_launch(launch_layernorm(a, (hipStream_t)stream), "layernorm");
 }
 

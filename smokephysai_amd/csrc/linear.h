@@ -18,6 +18,7 @@ struct LinearCall {
     int rows_per_group, period;
     int M;
     int act;                              // 0 none, 1 GELU (erf form), 2 ReLU
+    int x_split, y_split;                 // SMK_FMT_SPLIT_BF16 on the input / output side (rows dense: ldx = K, ldy = N)
 };
 
 hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st);

@@ -30,7 +30,7 @@ constexpr int LN_PITCH = 144;      // bytes per staged row per plane: 64 bf16 + 
 #endif
 constexpr int LN_RING = 4;         // B fragments in flight: 3 k-steps ahead; 4 k-steps per chunk keep the ring indices static
 template <int MB> constexpr int ln_plane_bytes() { return MB * 32 * LN_PITCH; }
-template <int MB> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 1024; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
+template <int MB, int NW> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 1024; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
 
 __global__ __launch_bounds__(256) void k_split_linear_weights(const float *__restrict__ w, const float *__restrict__ bias, LinearDev l) {
     const long long total = (long long)l.N * l.K;
@@ -75,15 +75,17 @@ struct LinearArgs {
     LinearDev l;
     LinearCall c;
     int tiles_m, tiles_n;
-    int swz, stagger, num_cu;
+    int swz, stagger, stagger_unit, num_cu;
     unsigned long long *stamps;
     int dbg;              // timing ablations (SMK_LINEAR_DBG; results are wrong when non-zero): 1 A loads re-read tile 0,
                           // 2 B ring re-reads k-step 0, 4 no epilogue
 };
 
-template <int MB, int NW>
+// AS: the activations arrive already split (SMK_FMT_SPLIT_BF16: per row, per 8 k: 8 hi | 8 lo bf16 -- the same 4 bytes per
+// element as fp32, written by the producing kernel's epilogue): staging is then a 16-byte copy, no arithmetic in the K loop.
+template <int MB, int NW, bool AS>
 __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
-    constexpr int TN = NW * 32, RP = NW * 4;      // tile columns; rows staged per pass (NW*64 threads / 16 float4 columns)
+    constexpr int TN = NW * 32, RP = AS ? NW * 8 : NW * 4;   // tile columns; rows staged per pass (fp32: 16 float4 per row chunk; split: 8 x 32 B)
     constexpr bool sched = SMK_LINEAR_SCHED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TM = MB * 32, PLANE = ln_plane_bytes<MB>();
@@ -100,8 +102,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
     int tm = vid / a.tiles_n;
     // Two workgroups share a CU and run the same program with the same period: delay every other dispatch round by about
     // half a tile so that one's epilogue / staging stalls overlap the other's MFMA stretch (speed only).
-    if (a.stagger > 0 && ((blockIdx.x / a.num_cu) & 1))
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    // Tiles of equal length keep all workgroups of the chip in lock-step: every epilogue is then one chip-wide write burst
+    // that drains at HBM write bandwidth while the matrix pipes idle.  Starting the workgroups in `stagger` phase groups
+    // spreads the bursts (a one-time cost of up to (stagger-1)/stagger of a tile for the last group).
+    if (a.stagger > 1) {
+        const int ph = (blockIdx.x >> 3) % a.stagger;          // same XCD, consecutive CUs -> different phases
+        for (int i = 0; i < ph * a.stagger_unit; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int n = tn * TN + wave * 32 + r;                  // this lane's output column
     const bool n_ok = n < N;
 
@@ -121,27 +128,41 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
         bql[k] = load_b(k, 1);
     }
 
-    // ---- A staging: thread = float4 column sc of rows sr, sr+16, ... of the 32*MB x 64 chunk (a wave reads 4 full 256-B rows)
-    const int sc = tid & 15, sr = tid >> 4;
-    float4 stage[TM / RP];
+    // ---- A staging.  fp32: thread = float4 column sc of rows sr, sr+RP, ... of the 32*MB x 64 chunk (a wave reads 4 full 256-B
+    //      rows); split: thread = k-group sc (8 hi | 8 lo = 32 B) of rows sr, sr+RP, ...
+    const int sc = AS ? (tid & 7) : (tid & 15), sr = AS ? (tid >> 3) : (tid >> 4);
+    constexpr int NPC_ALL = TM / RP;                         // pieces per chunk per thread
+    float4 stage[AS ? 1 : NPC_ALL];
+    u32x4 sth[AS ? NPC_ALL : 1], stl[AS ? NPC_ALL : 1];
     // x through a buffer resource: a row past M (ragged last tile, or the chunk stream running past this workgroup's last
     // tile) is out of range and reads as zero in hardware -- no clamp, no predicate (either would cost VALU issue slots or
     // split the k-step into basic blocks and undo the MFMA / staging interleave below).  One v_add per load: the offset
     // must sit in the VGPR operand to be range-checked.
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.c.x), 0, (int)(((long long)(M - 1) * a.c.ldx + K) * 4), 0x00020000);
-    const int ldxb = (int)a.c.ldx * 4;
-    const int lane_x = sr * ldxb + sc * 16;
+    const int ldxb = (int)a.c.ldx * 4;                       // row bytes (split rows are dense: ldx = K)
+    const int lane_x = sr * ldxb + sc * (AS ? 32 : 16);
     auto stage_load = [&](int tmx, int cx, int j) {
         const unsigned row_u = (unsigned)((a.dbg & 1) ? 0 : tmx) * TM + RP * j;          // wave-uniform part (SALU); tmx <= tiles_m
         const unsigned off = row_u * (unsigned)ldxb + (unsigned)cx * 256u;                // < 2^32: api.hip bounds (rows + 256) * ldx
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
-        // (not __builtin_bit_cast(float, v[i]): hipcc 7.2 then emits a 1-dword load and leaves v[1..3] undefined)
-        stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        if (AS) {
+            sth[AS ? j : 0] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
+            stl[AS ? j : 0] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x + 16u), 0, 0);
+        } else {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
+            // (not __builtin_bit_cast(float, v[i]): hipcc 7.2 then emits a 1-dword load and leaves v[1..3] undefined)
+            stage[AS ? 0 : j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
     };
     auto stage_store = [&](int buf, int j) {
+        if (AS) {
+            unsigned char *ph = smem + buf * 2 * PLANE + (sr + RP * j) * LN_PITCH + sc * 16;
+            *reinterpret_cast<u32x4 *>(ph) = sth[AS ? j : 0];
+            *reinterpret_cast<u32x4 *>(ph + PLANE) = stl[AS ? j : 0];
+            return;
+        }
         unsigned char *ph = smem + buf * 2 * PLANE + (sr + RP * j) * LN_PITCH + sc * 8;
-        const float v[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
+        const float v[4] = {stage[AS ? 0 : j].x, stage[AS ? 0 : j].y, stage[AS ? 0 : j].z, stage[AS ? 0 : j].w};
         bf16x4 vh, vl;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
                     // per SIMD an MFMA gap hides about five other vector-issue slots (MI355X_MICROARCH.md, constants table), shared
                     // by the two resident waves: the split arithmetic is spread at ~12 VALU per piece over the k-step's gaps
                     constexpr int NMF = 3 * MB, NDS = 2 * MB, NPC = pend - pbeg;
-                    constexpr int VPER = NPC ? (14 * NPC + NMF - 1) / NMF : 0;
+                    constexpr int VPER = NPC ? ((AS ? 3 : 14) * NPC + NMF - 1) / NMF : 0;
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
@@ -270,7 +291,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
                         if (VPER) __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);             // split arithmetic
                         if (i >= NMF - NPC) {
                             __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                      // a finished piece: 2 DS writes
-                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      //   + its re-issued load
+                            __builtin_amdgcn_sched_group_barrier(0x020, AS ? 2 : 1, 0);             //   + its re-issued load(s)
                         }
                         if (i >= NMF - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // ring refill
                     }
@@ -315,27 +336,63 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
                     for (int q = 0; q < 4; ++q) e[q] = *reinterpret_cast<const float4 *>(rp + 8 * q);
                 }
             };
-            if (any_ex) fetch_extra(0, ex[0]);
+            // activation + store of 4 consecutive columns of one row (fp32 or split-bf16)
+            auto finish = [&](float (&v)[4], int row, int q) {
+                if (a.c.act == 1) {                       // wave-uniform
 #pragma unroll
-            for (int mi = 0; mi < MB; ++mi) {
-                if (any_ex && mi + 1 < MB) fetch_extra(mi + 1, ex[(mi + 1) & 1]);
-                const int row = row0 + mi * 32 + r;
-                float *yp = a.c.y + (long long)row * a.c.ldy + ncol;
+                    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+                } else if (a.c.act == 2) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bq = *reinterpret_cast<const float4 *>(bias_w + 8 * q);
-                    const float4 eq = ex[mi & 1][q];
-                    float v[4] = {acc[mi][4 * q] + bq.x, acc[mi][4 * q + 1] + bq.y, acc[mi][4 * q + 2] + bq.z, acc[mi][4 * q + 3] + bq.w};
-                    if (a.c.padd) { v[0] += eq.x; v[1] += eq.y; v[2] += eq.z; v[3] += eq.w; }
-                    if (a.c.act == 1) {                       // wave-uniform, epilogue only
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                }
+            };
+            auto store4 = [&](const float (&v)[4], int row, int q) {
+                if (row >= M) return;
+                if (a.c.y_split) {   // SMK_FMT_SPLIT_BF16: group (ncol + 8q) / 8 of the row, this lane's half (4 hi | 4 lo)
+                    bf16x4 vh, vl;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
-                    } else if (a.c.act == 2) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                    for (int i = 0; i < 4; ++i) {
+                        const __bf16 h = (__bf16)v[i];
+                        vh[i] = h;
+                        vl[i] = (__bf16)(v[i] - (float)h);
                     }
-                    if (a.c.res && !a.c.padd) { v[0] = eq.x + v[0]; v[1] = eq.y + v[1]; v[2] = eq.z + v[2]; v[3] = eq.w + v[3]; }
-                    if (row < M) *reinterpret_cast<float4 *>(yp + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                    __bf16 *ys = reinterpret_cast<__bf16 *>(a.c.y) + (size_t)row * (2 * N) + ((ncol >> 3) + q) * 16 + 4 * hi;
+                    *reinterpret_cast<bf16x4 *>(ys) = vh;
+                    *reinterpret_cast<bf16x4 *>(ys + 8) = vl;
+                } else {
+                    *reinterpret_cast<float4 *>(a.c.y + (long long)row * a.c.ldy + ncol + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            };
+            if (!any_ex) {
+                // plain path: no global loads at all, so nothing ever waits on vmcnt -- which on CDNA4 also counts the stores
+                // (a wait here would drain every store to memory before the next one is issued)
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi) {
+                    const int row = row0 + mi * 32 + r;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bq = *reinterpret_cast<const float4 *>(bias_w + 8 * q);
+                        float v[4] = {acc[mi][4 * q] + bq.x, acc[mi][4 * q + 1] + bq.y, acc[mi][4 * q + 2] + bq.z, acc[mi][4 * q + 3] + bq.w};
+                        finish(v, row, q);
+                        store4(v, row, q);
+                    }
+                }
+            } else {
+                fetch_extra(0, ex[0]);
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi) {
+                    if (mi + 1 < MB) fetch_extra(mi + 1, ex[(mi + 1) & 1]);
+                    const int row = row0 + mi * 32 + r;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bq = *reinterpret_cast<const float4 *>(bias_w + 8 * q);
+                        const float4 eq = ex[mi & 1][q];
+                        float v[4] = {acc[mi][4 * q] + bq.x, acc[mi][4 * q + 1] + bq.y, acc[mi][4 * q + 2] + bq.z, acc[mi][4 * q + 3] + bq.w};
+                        if (a.c.padd) { v[0] += eq.x; v[1] += eq.y; v[2] += eq.z; v[3] += eq.w; }
+                        finish(v, row, q);
+                        if (!a.c.padd) { v[0] = eq.x + v[0]; v[1] = eq.y + v[1]; v[2] = eq.z + v[2]; v[3] = eq.w + v[3]; }
+                        store4(v, row, q);
+                    }
                 }
             }
         }
@@ -354,12 +411,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
 #endif
 }
 
-template <int MB, int NW>
+template <int MB, int NW, bool AS>
 static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
-    constexpr int lds = ln_lds_bytes<MB>();
+    constexpr int lds = ln_lds_bytes<MB, NW>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     const int nwg_max = (NW == 8 ? 1 : 2) * a.num_cu;     // 8 waves per CU either way
@@ -372,8 +429,11 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     if (swz_env < 0) { const char *s = getenv("SMK_LINEAR_SWZ"); swz_env = s ? atoi(s) : 1; }
     if (stg_env < 0) { const char *s = getenv("SMK_LINEAR_STAGGER"); stg_env = s ? atoi(s) : 0; }
     b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
-    b.stagger = nwg > b.num_cu ? stg_env : 0;
-    hipLaunchKernelGGL((k_linear_x3<MB, NW>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
+    b.stagger = stg_env;
+    // one tile ~ (K/64) chunks x ~4.2 K cycles + ~9 K epilogue; s_sleep(127) ~ 8 K cycles
+    b.stagger_unit = stg_env > 1 ? (int)(((a.l.K / 64) * 4200 + 9000) / 8128 / stg_env) : 0;
+    if (b.stagger_unit < 1) b.stagger = 0;
+    hipLaunchKernelGGL((k_linear_x3<MB, NW, AS>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
     return hipGetLastError();
 }
 
@@ -420,10 +480,17 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     a.stamps = stamp_buf;
 #endif
     hipError_t e;
-    if (nw == 8) e = launch_mb<4, 8>(a, st);
-    else if (mb == 4) e = launch_mb<4, 4>(a, st);
-    else if (mb == 2) e = launch_mb<2, 4>(a, st);
-    else e = launch_mb<1, 4>(a, st);
+    if (c.x_split) {
+        if (nw == 8) e = launch_mb<4, 8, true>(a, st);
+        else if (mb == 4) e = launch_mb<4, 4, true>(a, st);
+        else if (mb == 2) e = launch_mb<2, 4, true>(a, st);
+        else e = launch_mb<1, 4, true>(a, st);
+    } else {
+        if (nw == 8) e = launch_mb<4, 8, false>(a, st);
+        else if (mb == 4) e = launch_mb<4, 4, false>(a, st);
+        else if (mb == 2) e = launch_mb<2, 4, false>(a, st);
+        else e = launch_mb<1, 4, false>(a, st);
+    }
 #ifdef SMK_LN_STAMPS
     if (getenv("SMK_LN_STAMPS_PRINT")) {   // diagnostic: wait, print the per-wave averages (cycles per tile; clock = core cycles / 100 MHz ticks)
         static unsigned long long h[8 * 4096];
@@ -434,8 +501,8 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
             us[0] += h[w*8+5] & 0xffffffffULL; us[1] += h[w*8+5] >> 32; us[2] += h[w*8+6] & 0xffffffffULL; us[3] += h[w*8+6] >> 32; us[4] += h[w*8+7]; }
         const double nch = nt * (l.K / 64);
         if (n) fprintf(stderr, "LN_KSTEPS per chunk: k0 %.0f k1 %.0f k2 %.0f k3(incl barrier) %.0f barrier %.0f\n", us[0] / nch, us[1] / nch, us[2] / nch, us[3] / nch, us[4] / nch);
-        if (n) fprintf(stderr, "LN_STAMPS M=%d K=%d N=%d mb=%d nw=%d waves=%d tiles/wave=%.1f | per tile: kloop %.0f epilogue %.0f | wave total %.0f cyc = %.1f us, clock %.0f MHz\n",
-                       c.M, l.K, l.N, mb, nw, n, nt / n, k / nt, ep / nt, tot / n, real / n / 100.0, tot / real * 100.0);
+        if (n) fprintf(stderr, "LN_STAMPS M=%d K=%d N=%d mb=%d nw=%d split=%d waves=%d tiles/wave=%.1f | per tile: kloop %.0f epilogue %.0f | wave total %.0f cyc = %.1f us, clock %.0f MHz\n",
+                       c.M, l.K, l.N, mb, nw, c.x_split, n, nt / n, k / nt, ep / nt, tot / n, real / n / 100.0, tot / real * 100.0);
     }
 #endif
     return e;

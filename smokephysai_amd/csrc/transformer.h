@@ -19,6 +19,7 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo;              // row pitches in floats
     int B, L, H;
     float scale_log2e;                   // softmax scale * log2(e), folded into Q
+    int o_split;                         // o in SMK_FMT_SPLIT_BF16 (dense rows)
 };
 hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st);
 
@@ -28,6 +29,7 @@ struct LayerNormArgs {
     long long ldx, ldy;
     int rows, D;
     float eps;
+    int y_split;                         // y in SMK_FMT_SPLIT_BF16 (dense rows)
 };
 hipError_t launch_layernorm(const LayerNormArgs &a, hipStream_t st);
 

@@ -248,7 +248,27 @@ __global__ __launch_bounds__(256, 2) void k_attention_x3(const AttnArgs a) {
     // ---- normalise and store: 4 consecutive d per register quad
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    float *op = a.o + ((size_t)b * a.L + qb * AT_QB + wave * 32 + r) * a.ldo + head * 64 + 4 * hh;
+    const size_t orow = (size_t)b * a.L + qb * AT_QB + wave * 32 + r;
+    if (a.o_split) {   // SMK_FMT_SPLIT_BF16: feature group (64 head + 32 db + 8 q4) / 8, this lane's half (4 hi | 4 lo)
+        __bf16 *os = reinterpret_cast<__bf16 *>(a.o) + orow * (2 * (size_t)a.ldo) + (head * 8) * 16 + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = oacc[db][4 * q4 + i] * inv;
+                    const __bf16 t16 = (__bf16)v;
+                    vh[i] = t16;
+                    vl[i] = (__bf16)(v - (float)t16);
+                }
+                *reinterpret_cast<bf16x4 *>(os + (4 * db + q4) * 16) = vh;
+                *reinterpret_cast<bf16x4 *>(os + (4 * db + q4) * 16 + 8) = vl;
+            }
+        return;
+    }
+    float *op = a.o + orow * a.ldo + head * 64 + 4 * hh;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -306,8 +326,22 @@ __global__ __launch_bounds__(256) void k_layernorm(const LayerNormArgs a) {
         const int c = (i * 64 + lane) * 4;
         if (c < a.D) {
             const float4 w = *reinterpret_cast<const float4 *>(a.w + c), b = *reinterpret_cast<const float4 *>(a.b + c);
-            *reinterpret_cast<float4 *>(yp + c) = make_float4((v[i].x - mean) * rstd * w.x + b.x, (v[i].y - mean) * rstd * w.y + b.y,
-                                                              (v[i].z - mean) * rstd * w.z + b.z, (v[i].w - mean) * rstd * w.w + b.w);
+            const float o[4] = {(v[i].x - mean) * rstd * w.x + b.x, (v[i].y - mean) * rstd * w.y + b.y,
+                                (v[i].z - mean) * rstd * w.z + b.z, (v[i].w - mean) * rstd * w.w + b.w};
+            if (a.y_split) {   // SMK_FMT_SPLIT_BF16: group c / 8, half (c / 4) & 1
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const __bf16 t16 = (__bf16)o[j];
+                    vh[j] = t16;
+                    vl[j] = (__bf16)(o[j] - (float)t16);
+                }
+                __bf16 *ys = reinterpret_cast<__bf16 *>(a.y) + (size_t)row * (2 * (size_t)a.D) + (c >> 3) * 16 + (c & 4);
+                *reinterpret_cast<bf16x4 *>(ys) = vh;
+                *reinterpret_cast<bf16x4 *>(ys + 8) = vl;
+            } else {
+                *reinterpret_cast<float4 *>(yp + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
         }
     }
 }

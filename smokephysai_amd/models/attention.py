@@ -4,6 +4,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
+from .linear import split_empty
 
 
 def hip_attention_supported(L: int, head_dim: int) -> bool:
@@ -11,7 +12,7 @@ def hip_attention_supported(L: int, head_dim: int) -> bool:
 
 
 def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, scale: float,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, out_split: bool = False) -> torch.Tensor:
     """q, k, v: [B, L, H*64] float32 on a ROCm device (row pitch may exceed H*64, e.g. slices of a fused qkv tensor);
     returns [B, L, H*64] -- the layout `out.transpose(1, 2).contiguous().view(B, L, D)` has in the reference
     (chaos_attention.py:111-112)."""
@@ -22,9 +23,10 @@ def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: 
         if t.dtype != torch.float32 or t.shape != q.shape or t.device != q.device or t.stride(2) != 1 or t.stride(0) != L * t.stride(1):
             raise ValueError("hip_attention: q, k, v must be float32 [B, L, H*d] with unit inner stride and dense batches")
     if out is None:
-        out = torch.empty(B, L, D, device=dev, dtype=torch.float32)
+        out = split_empty(B, L, D, device=dev) if out_split else torch.empty(B, L, D, device=dev, dtype=torch.float32)
+    ldo = D if out_split else out.stride(1)
     _lib.check(_lib.load().smk_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, L, num_heads, d,
-                                        q.stride(1), k.stride(1), v.stride(1), out.stride(1), float(scale),
+                                        q.stride(1), k.stride(1), v.stride(1), ldo, float(scale), int(out_split),
                                         _lib.stream_ptr(dev)))
     return out
 
@@ -33,7 +35,8 @@ def hip_layernorm_supported(D: int) -> bool:
     return D % 4 == 0 and 4 <= D <= 2048
 
 
-def hip_layernorm(x: torch.Tensor, ln: torch.nn.LayerNorm, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def hip_layernorm(x: torch.Tensor, ln: torch.nn.LayerNorm, out: Optional[torch.Tensor] = None,
+                  out_split: bool = False) -> torch.Tensor:
     """nn.LayerNorm over the last dimension as one libsmokehip launch (smk_layernorm); x [..., D] float32, dense rows."""
     dev = _lib.require_cuda(x.device, "hip_layernorm")
     D = x.shape[-1]
@@ -41,8 +44,8 @@ def hip_layernorm(x: torch.Tensor, ln: torch.nn.LayerNorm, out: Optional[torch.T
     if x2.stride(1) != 1 or x.dtype != torch.float32:
         raise ValueError("hip_layernorm: float32 rows with unit inner stride")
     if out is None:
-        out = torch.empty(x.shape, device=dev, dtype=torch.float32)
-    y2 = out.view(-1, D)
+        out = split_empty(*x.shape, device=dev) if out_split else torch.empty(x.shape, device=dev, dtype=torch.float32)
+    ldy = D if out_split else out.view(-1, D).stride(0)
     _lib.check(_lib.load().smk_layernorm(x2.data_ptr(), x2.shape[0], D, x2.stride(0), ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                        float(ln.eps), y2.data_ptr(), y2.stride(0), _lib.stream_ptr(dev)))
+                                        float(ln.eps), out.data_ptr(), ldy, int(out_split), _lib.stream_ptr(dev)))
     return out

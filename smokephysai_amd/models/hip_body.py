@@ -3,6 +3,7 @@ one pre-LN ChaosTransformerLayer (smokephys_net.py:136-168; chaos_attention.py:6
 LayerNorm, chaos addend, fused q|k|v projection (+ chaos term on the q columns), flash attention, out_proj (+ residual),
 LayerNorm, FFN up (+ GELU), FFN down (+ residual)."""
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -10,7 +11,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .attention import hip_attention, hip_attention_supported, hip_layernorm, hip_layernorm_supported
-from .linear import HipLinear, hip_linear_supported
+from .linear import HipLinear, hip_linear_supported, to_split
 
 
 def _fp(lin: nn.Linear):
@@ -22,6 +23,7 @@ class HipBody:
         self.linears: Dict[str, Tuple[HipLinear, tuple]] = {}      # name -> (handle, fingerprint of the source tensors)
         self.sources: Dict[str, tuple] = {}                        # name -> the nn.Linear modules the handle mirrors
         self.addend_bufs: Dict[tuple, torch.Tensor] = {}           # (name, batch) -> [B,5,3D] addend of the fused q|k|v layer
+        self.split_activations = os.environ.get("SMK_BODY_SPLIT", "0") == "1"
 
     # ---- weight mirrors ----------------------------------------------------------------------------------------
     def linear(self, name: str, lin: nn.Linear) -> HipLinear:
@@ -52,10 +54,11 @@ class HipBody:
 
     # ---- ops ------------------------------------------------------------------------------------------------------
     @staticmethod
-    def layernorm(x: torch.Tensor, ln: nn.LayerNorm) -> torch.Tensor:
+    def layernorm(x: torch.Tensor, ln: nn.LayerNorm, out_split: bool = False) -> torch.Tensor:
         if hip_layernorm_supported(x.shape[-1]) and ln.elementwise_affine and ln.bias is not None:
-            return hip_layernorm(x, ln)
-        return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
+            return hip_layernorm(x, ln, out_split=out_split)
+        y = F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
+        return to_split(y) if out_split else y
 
     @staticmethod
     def layer_supported(layer, L: int) -> bool:
@@ -71,22 +74,27 @@ class HipBody:
         B, L, D = x.shape
         att = layer.chaos_attention
         H, d = att.num_heads, att.head_dim
-        h = self.layernorm(x, layer.norm1)
+        # Optional (SMK_BODY_SPLIT=1): activations between the kernels travel as split-bf16 pairs (SMK_FMT_SPLIT_BF16, 4 bytes
+        # per element like fp32) written by the producers' epilogues, so no linear layer splits its input inside its K loop.
+        # Measured neutral on MI355X (the K loop is not bound by the split arithmetic: DESIGN.md 3.3), so it is off by default.
+        sp = self.split_activations and D % 8 == 0 and layer.ffn[0].out_features % 8 == 0
+        h = self.layernorm(x, layer.norm1, out_split=sp)
         add15 = self.addend_bufs.get((name, B))
         if add15 is None or add15.device != x.device:       # the k|v columns stay zero, the q columns are rewritten per call
             add15 = self.addend_bufs[(name, B)] = torch.zeros(B, 5, 3 * D, device=x.device)
         att.chaos_addend_hip(B, x.device, noise, out=add15)
-        qkv = self.qkv(name + "chaos_attention.qkv", att)(h, periodic_add=add15, rows_per_group=L)
+        qkv = self.qkv(name + "chaos_attention.qkv", att)(h, periodic_add=add15, rows_per_group=L, x_split=sp)
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         scale = 1.0 / (math.sqrt(d) * att.temperature)
         if hip_attention_supported(L, d):
-            o = hip_attention(q, k, v, H, scale)                           # [B, L, D]: heads already merged
+            o = hip_attention(q, k, v, H, scale, out_split=sp)             # [B, L, D]: heads already merged
         else:
             o = F.scaled_dot_product_attention(q.view(B, L, H, d).transpose(1, 2), k.view(B, L, H, d).transpose(1, 2),
                                                v.view(B, L, H, d).transpose(1, 2), scale=scale)
             o = o.transpose(1, 2).reshape(B, L, D)
-        self.linear(name + "chaos_attention.out_proj", att.out_proj)(o, residual=x, out=x)        # x += attn
-        h = self.layernorm(x, layer.norm2)
-        f = self.linear(name + "ffn.0", layer.ffn[0])(h, activation="gelu")
-        self.linear(name + "ffn.3", layer.ffn[3])(f, residual=x, out=x)                           # x += ffn
+            o = to_split(o) if sp else o
+        self.linear(name + "chaos_attention.out_proj", att.out_proj)(o, residual=x, out=x, x_split=sp)     # x += attn
+        h = self.layernorm(x, layer.norm2, out_split=sp)
+        f = self.linear(name + "ffn.0", layer.ffn[0])(h, activation="gelu", x_split=sp, out_split=sp)
+        self.linear(name + "ffn.3", layer.ffn[3])(f, residual=x, out=x, x_split=sp)                        # x += ffn
         return x

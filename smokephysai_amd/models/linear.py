@@ -10,6 +10,26 @@ from torch import nn
 from .. import _lib
 
 
+def split_empty(*shape, device) -> torch.Tensor:
+    """Storage of an activation [..., F] in SMK_FMT_SPLIT_BF16 (x = hi + lo): a bfloat16 tensor [..., F/8, 2, 8]."""
+    if shape[-1] % 8:
+        raise ValueError("split-bf16 activations need a feature count that is a multiple of 8")
+    return torch.empty(*shape[:-1], shape[-1] // 8, 2, 8, device=device, dtype=torch.bfloat16)
+
+
+def to_split(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., F] -> SMK_FMT_SPLIT_BF16 storage (host-side helper for tests / callers; the kernels emit it themselves)."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi.reshape(*x.shape[:-1], -1, 8), lo.reshape(*x.shape[:-1], -1, 8)], dim=-2).contiguous()
+
+
+def from_split(xs: torch.Tensor) -> torch.Tensor:
+    """SMK_FMT_SPLIT_BF16 storage [..., F/8, 2, 8] -> fp32 [..., F] (hi + lo)."""
+    v = xs.float()
+    return (v[..., 0, :] + v[..., 1, :]).reshape(*xs.shape[:-3], -1)
+
+
 def hip_linear_supported(in_features: int, out_features: int) -> bool:
     """Shapes the HIP kernel is built for (include/smokehip.h: smk_linear_create)."""
     return in_features % 64 == 0 and out_features % 32 == 0
@@ -48,21 +68,35 @@ class HipLinear:
 
     def __call__(self, x: torch.Tensor, activation: Optional[str] = None, residual: Optional[torch.Tensor] = None,
                  periodic_add: Optional[torch.Tensor] = None, rows_per_group: int = 0,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, x_split: bool = False, out_split: bool = False) -> torch.Tensor:
         """x [..., in_features] -> [..., out_features].  residual: same shape as the result, added after the activation.
         periodic_add [groups, period, out_features]: row i of group g gets periodic_add[g, i % period] before the
-        activation (rows_per_group rows per group, default = x.shape[-2])."""
-        if x.device != self._dev or x.dtype != torch.float32:
-            raise ValueError(f"HipLinear: x must be float32 on {self._dev}")
-        if x.shape[-1] != self.in_features:
-            raise ValueError(f"HipLinear: last dim {x.shape[-1]} != in_features {self.in_features}")
-        lead = x.shape[:-1]
-        x2 = x.reshape(-1, self.in_features)
-        if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
-            x2 = x2.contiguous()
-        rows = x2.shape[0]
-        y = out if out is not None else torch.empty(*lead, self.out_features, device=self._dev, dtype=torch.float32)
-        y2 = y.view(-1, self.out_features)
+        activation (rows_per_group rows per group, default = x.shape[-2]).
+        x_split: x is SMK_FMT_SPLIT_BF16 storage [..., in/8, 2, 8] (split_empty / to_split); out_split: return that format."""
+        if x_split:
+            if x.device != self._dev or x.dtype != torch.bfloat16 or x.shape[-3:] != (self.in_features // 8, 2, 8) or not x.is_contiguous():
+                raise ValueError("HipLinear: x_split wants contiguous bfloat16 [..., in_features/8, 2, 8]")
+            lead = x.shape[:-3]
+            rows = x.numel() // (2 * self.in_features)
+            x_ptr, ldx, seq = x.data_ptr(), self.in_features, (lead[-1] if lead else rows)
+        else:
+            if x.device != self._dev or x.dtype != torch.float32:
+                raise ValueError(f"HipLinear: x must be float32 on {self._dev}")
+            if x.shape[-1] != self.in_features:
+                raise ValueError(f"HipLinear: last dim {x.shape[-1]} != in_features {self.in_features}")
+            lead = x.shape[:-1]
+            x2 = x.reshape(-1, self.in_features)
+            if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+                x2 = x2.contiguous()
+            rows = x2.shape[0]
+            x_ptr, ldx, seq = x2.data_ptr(), x2.stride(0), (x.shape[-2] if x.dim() >= 2 else rows)
+        if out_split:
+            y = out if out is not None else split_empty(*lead, self.out_features, device=self._dev)
+            y_ptr, ldy = y.data_ptr(), self.out_features
+        else:
+            y = out if out is not None else torch.empty(*lead, self.out_features, device=self._dev, dtype=torch.float32)
+            y2 = y.view(-1, self.out_features)
+            y_ptr, ldy = y2.data_ptr(), y2.stride(0)
         res_ptr, ldr = 0, 0
         if residual is not None:
             r2 = residual.reshape(-1, self.out_features)
@@ -74,12 +108,11 @@ class HipLinear:
         pa_ptr, period, rpg = 0, 1, 1
         if periodic_add is not None:
             pa = periodic_add.to(torch.float32).contiguous()
-            rpg = rows_per_group or x.shape[-2]
+            rpg = rows_per_group or seq
             if pa.dim() != 3 or pa.shape[2] != self.out_features or pa.shape[0] * rpg != rows:
                 raise ValueError("HipLinear: periodic_add must be [rows / rows_per_group, period, out_features]")
             pa_ptr, period = pa.data_ptr(), pa.shape[1]
         act = {None: _lib.SMK_ACT_NONE, "none": _lib.SMK_ACT_NONE, "gelu": _lib.SMK_ACT_GELU, "relu": _lib.SMK_ACT_RELU}[activation]
-        _lib.check(self._L.smk_linear_forward(self._handle, x2.data_ptr(), rows, x2.stride(0), y2.data_ptr(),
-                                              y2.stride(0), res_ptr, ldr, pa_ptr, rpg, period, act,
-                                              _lib.stream_ptr(self._dev)))
+        _lib.check(self._L.smk_linear_forward(self._handle, x_ptr, rows, ldx, y_ptr, ldy, res_ptr, ldr, pa_ptr, rpg, period,
+                                              act, int(x_split), int(out_split), _lib.stream_ptr(self._dev)))
         return y

@@ -109,6 +109,10 @@ def test_hip_transformer_layer_matches_reference_golden(golden):
     with torch.no_grad():
         out = body.layer("t.", layer, x.clone(), noise)
         assert rel_err(out.cpu().numpy(), g["layer_out"]) < 1e-4
+        body.split_activations = True                         # same layer with split-bf16 activations between the kernels
+        out_s = body.layer("t.", layer, x.clone(), noise)
+        assert rel_err(out_s.cpu().numpy(), g["layer_out"]) < 1e-4
+        body.split_activations = False
         # attention sub-block: LN1 -> q|k|v (+ chaos term) -> attention -> out_proj (no residual)
         from smokephysai_amd.models.attention import hip_attention
         h = body.layernorm(x, layer.norm1)
@@ -119,3 +123,19 @@ def test_hip_transformer_layer_matches_reference_golden(golden):
         o = hip_attention(qkv[..., :128], qkv[..., 128:256], qkv[..., 256:], 2, 0.125)
         attn = body.linear("t.chaos_attention.out_proj", att.out_proj)(o)
         assert rel_err(attn.cpu().numpy(), g["attention_out"]) < 1e-4
+
+
+def test_layernorm_and_attention_split_bf16_outputs():
+    from smokephysai_amd.models.attention import hip_attention, hip_layernorm
+    from smokephysai_amd.models.linear import from_split
+    g = torch.Generator(device="cuda").manual_seed(17)
+    ln = torch.nn.LayerNorm(512).cuda()
+    x = torch.randn(3, 256, 512, device="cuda", generator=g) * 2 + 0.3
+    with torch.no_grad():
+        y = hip_layernorm(x, ln)
+        ys = hip_layernorm(x, ln, out_split=True)
+    assert ys.shape == (3, 256, 64, 2, 8) and rel_err(from_split(ys).cpu().numpy(), y.cpu().numpy()) < 2.0 ** -16
+    q, k, v = (torch.randn(2, 256, 512, device="cuda", generator=g) for _ in range(3))
+    o = hip_attention(q, k, v, 8, 0.125)
+    os_ = hip_attention(q, k, v, 8, 0.125, out_split=True)
+    assert os_.shape == (2, 256, 64, 2, 8) and rel_err(from_split(os_).cpu().numpy(), o.cpu().numpy()) < 2.0 ** -16

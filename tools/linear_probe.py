@@ -29,3 +29,16 @@ for M, K, N, act in shapes:
         t_ref = timeit(lambda: torch.nn.functional.linear(x, w, b))
     fl = 2.0 * M * K * N
     print(f"M={M:6d} K={K:5d} N={N:5d} act={act}: hip {t_hip*1e3:8.1f} us ({fl/t_hip/1e9:7.1f} TF/s counted)   torch fp32 {t_ref*1e3:8.1f} us ({fl/t_ref/1e9:6.1f} TF/s)", flush=True)
+
+# pre-split (SMK_FMT_SPLIT_BF16) activations: the same layers with the split done by the producer
+from smokephysai_amd.models.linear import to_split
+print("-- split-bf16 input / output")
+for M, K, N, act in shapes:
+    x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / math.sqrt(K); b = torch.randn(N, device="cuda")
+    lin = HipLinear(w, b); xs = to_split(x)
+    ys = lin(xs, activation=act, x_split=True, out_split=True)
+    y = torch.empty(M, N, device="cuda")
+    t_in = timeit(lambda: lin(xs, activation=act, x_split=True, out=y))
+    t_io = timeit(lambda: lin(xs, activation=act, x_split=True, out_split=True, out=ys))
+    fl = 2.0 * M * K * N
+    print(f"M={M:6d} K={K:5d} N={N:5d} act={act}: split-in {t_in*1e3:8.1f} us ({fl/t_in/1e9:6.1f} TF/s)   split-in+out {t_io*1e3:8.1f} us ({fl/t_io/1e9:6.1f} TF/s)", flush=True)
