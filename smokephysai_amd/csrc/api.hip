@@ -391,7 +391,7 @@ int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *st
     enc->e.t2 = p; p += 128;
     enc->e.sw2 = p; p += 128;
     enc->e.wsum = reinterpret_cast<int *>(p);
-    const size_t n16 = 2 * 64 * 64 + 36 * 2 * 128 * 16 + 18 * 2 * 128 * 32 / 2;   // + int8 limbs (bytes / 2)
+    const size_t n16 = 2 * 64 * 64 + 2 * (36 * 2 * 128 * 16) + 18 * 2 * 128 * 32 / 2;   // + int8 limbs (bytes / 2)
     e = hipMalloc((void **)&enc->blob16, n16 * sizeof(unsigned short));
     if (e != hipSuccess) {
         smk_encoder_destroy(enc);
@@ -399,8 +399,9 @@ int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *st
         return SMK_ERR_HIP;
     }
     enc->e.w2q = enc->blob16;                       // 16-byte aligned rows first
-    enc->e.w1p = enc->blob16 + 36 * 2 * 128 * 16;
-    enc->e.w2i = reinterpret_cast<signed char *>(enc->blob16 + 36 * 2 * 128 * 16 + 2 * 64 * 64);
+    enc->e.w2s = enc->blob16 + 36 * 2 * 128 * 16;
+    enc->e.w1p = enc->blob16 + 2 * (36 * 2 * 128 * 16);
+    enc->e.w2i = reinterpret_cast<signed char *>(enc->blob16 + 2 * (36 * 2 * 128 * 16) + 2 * 64 * 64);
     rc = check_launch(launch_fold_weights(*w, enc->e, (hipStream_t)stream), "fold_weights");
     if (rc) { smk_encoder_destroy(enc); return rc; }
     *out = enc;

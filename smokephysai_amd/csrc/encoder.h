@@ -15,6 +15,7 @@ struct EncoderDev {
     float *sw2;            // [128] per-output-channel weight scale of the int8 limbs
     int *wsum;             // [2][128] 128 * sum_k of the h / l weight limbs (offset correction of the unsigned activations)
     unsigned short *w2q;   // [36 k-steps = tap*4 + c/16][2 hi/lo][128 o][16 c]  (B fragments, 1 KiB per wave load)
+    unsigned short *w2s;   // [18 k-steps = tap*2 + c/32][2 hi/lo][128 o][32 c]  (16x16x32 B fragments: 16 o x 64 B = 1 KiB)
 };
 
 hipError_t launch_fold_weights(const smk_encoder_weights &w, const EncoderDev &e, hipStream_t st);
@@ -27,6 +28,9 @@ hipError_t launch_encoder_f32(const float *frames, int64_t fstride, int B, int H
 // tokens = true: features written token-major [B][32*32][128] (coalesced; the layout feature_proj consumes).
 hipError_t launch_encoder_bf16(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
                                float *features, bool x3, bool tokens, hipStream_t st);
+// split-bf16 on the 16x16x32 MFMA shape (same arithmetic and tiles; higher sustained clock under the power limit)
+hipError_t launch_encoder_b16(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
+                              float *features, bool tokens, hipStream_t st);
 
 // int8 two-limb fixed point (activations scaled per tile, weights per output channel), exact i32 accumulation.
 hipError_t launch_encoder_i8(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,

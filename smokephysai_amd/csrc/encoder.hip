@@ -61,6 +61,11 @@ __global__ void k_fold_weights(smk_encoder_weights w, EncoderDev e) {
         __bf16 hi = (__bf16)v;
         w2q[((size_t)(ks * 2 + 0) * 128 + o) * 16 + cc] = hi;
         w2q[((size_t)(ks * 2 + 1) * 128 + o) * 16 + cc] = (__bf16)(v - (float)hi);
+        // the same weights for the 16x16x32 shape: [k-step = tap*2 + c/32][hi|lo][o][32 c]
+        __bf16 *w2s = reinterpret_cast<__bf16 *>(e.w2s);
+        const int ks2 = tap * 2 + (c >> 5), c32 = c & 31;
+        w2s[((size_t)(ks2 * 2 + 0) * 128 + o) * 32 + c32] = hi;
+        w2s[((size_t)(ks2 * 2 + 1) * 128 + o) * 32 + c32] = (__bf16)(v - (float)hi);
     }
 }
 
@@ -625,6 +630,341 @@ __global__ __launch_bounds__(256, 2) void k_encoder_bf16(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_encoder_b16: the split-bf16 encoder on v_mfma_f32_16x16x32_bf16.  Same tiles, same arithmetic (x3), same conv1 as
+// k_encoder_bf16<true>; only conv2's MFMA shape changes.  Why: the K loop is power-limited (about 1.5 GHz); at equal cycles
+// per flop the 16x16x32 shape sustains a higher clock (MI355X_MICROARCH.md, "Shape": 1.12-1.14x in LDS-fed loops).
+//   conv2: D[pix][o], M tile = one tile row of 16 pixels (8 per workgroup tile), N tile = 16 channels (2 per wave), K = 32 c per
+//          k-step (18 = 9 taps x 2).  A lane reads pixel (lane & 15), channel group 4*half + (lane >> 4) (8 c = 16 B).
+//   a1 image: [180 halo pixels][8 groups of 8 c] without padding, group g of pixel p stored at unit g ^ (((p >> 1) & 3) << 1):
+//          no linear pitch is conflict-free for this operand (ds_read_b128 serves lanes {0-3,12-15,20-27} together: 8 pixels
+//          of one channel group with 8 of the next); the XOR keeps bit 0 of the group (so the two groups of a lane group use
+//          even / odd units) and spreads bits 1-2 over 4 consecutive pixel pairs -> every lane group hits 16 distinct units
+//          for every tap shift.
+//   loop:  unit = half a k-step (M tiles 4hm..4hm+3: 24 MFMAs = 384 cycles, the same unit as k_encoder_bf16's k-step), so the
+//          skeleton -- A fragments of the next unit read under this unit's MFMAs, B ring from L2 -- and the register budget
+//          (64 acc + 64 A + 48 B) carry over.
+constexpr int S16_A1_BYTES = B3_APIX * 128;                               // 23,040 per plane
+constexpr int S16_LDS = B3_XS_BYTES + 2 * S16_A1_BYTES + 2 * B3_W1_BYTES + B3_ST_BYTES;   // 66,736 -> 2 workgroups per CU
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int PS, bool TOKENS>
+__global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict__ frames, int64_t fstride, int H, int W,
+                                                     EncoderDev e, float *__restrict__ features, int lg_tiles_x,
+                                                     int lg_tiles_per_frame, int ntiles, int stagger) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    unsigned char *a1h = smem + B3_XS_BYTES, *a1l = a1h + S16_A1_BYTES;
+    unsigned char *w1s = a1l + S16_A1_BYTES;
+    float *st1 = reinterpret_cast<float *>(w1s + 2 * B3_W1_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (tid < 128) st1[tid] = tid < 64 ? e.s1[tid] : e.t1[tid - 64];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(e.w1p);
+        for (int c = tid; c < 2 * 64 * 8; c += 256) {
+            const int row = c >> 3, u = c & 7;
+            *reinterpret_cast<uint4 *>(w1s + row * B3_W1_PITCH + u * 16) = src[c];
+        }
+    }
+    // conv2 operand lanes: pixel / channel px = lane & 15, channel group kg = lane >> 4
+    const int px = lane & 15, kg = lane >> 4;
+    const int o0 = wave * 32 + px;                                            // N tile 0; tile 1 = + 16
+    const float s2a = e.s2[o0], t2a = e.t2[o0], s2b = e.s2[o0 + 16], t2b = e.t2[o0 + 16];
+    // w2s: [k-step 18][hi|lo][o 128][32 c]: 8 KiB per (k-step, part); lane offset = (o * 32 + kg * 8) * 2 B
+    const int lane_b = o0 * 64 + kg * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(e.w2s), 0, 18 * 2 * 8192, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto load_b = [&](int ks, int part, int nt) -> uint4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (ks * 2 + part) * 8192 + nt * 1024, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    // B ring in k-steps: slot = [nt][part]; 3 slots = two k-steps ahead
+    constexpr int RING = 3;
+    uint4 bq[RING][2][2];
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            bq[k][nt][0] = load_b(k, 0, nt);
+            bq[k][nt][1] = load_b(k, 1, nt);
+        }
+    // A addressing: pixel p = (mt + ki) * 18 + px + kj; unit = g ^ (((p >> 1) & 3) << 1), g = 4 half + kg.  (p >> 1) & 3 =
+    // (((px + kj) >> 1) + (mt + ki)) & 3 because 18 / 2 = 9 = 1 (mod 4): tq[kj] is the lane part, the row part is added per read.
+    int tq[3], abase[3];
+#pragma unroll
+    for (int kj = 0; kj < 3; ++kj) {
+        tq[kj] = ((px + kj) >> 1) & 3;
+        abase[kj] = (px + kj) * 128 + (kg & 1) * 16;
+    }
+    const int kgh = kg >> 1;
+
+    auto x_fetch = [&](int t, int k) -> float {
+        if (k >= B3_XH * B3_XW) return 0.f;
+        const int bb = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);
+        const int rr0 = (rem >> lg_tiles_x) * B3_TH, cc0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
+        const int row = k / B3_XW, col = k - row * B3_XW;
+        const int ii = rr0 - 4 + row, jj = cc0 - 4 + col;
+        const bool ok = row < B3_XH - 1 && col < B3_XW - 1 && ii >= 0 && ii < H && jj >= 0 && jj < W;
+        return ok ? frames[(size_t)bb * fstride + (size_t)ii * W + jj] : 0.f;
+    };
+    int t = blockIdx.x;
+    if (stagger > 0 && ((blockIdx.x / 256) & 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    if (t < ntiles) {
+        xs[tid] = x_fetch(t, tid);
+        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = x_fetch(t, tid + 256);
+    }
+    __syncthreads();
+
+    for (; t < ntiles; t += gridDim.x) {
+        const int b = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);
+        const int r0 = (rem >> lg_tiles_x) * B3_TH, c0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
+
+        __builtin_amdgcn_s_setprio(0);
+        // ---- conv1 on MFMA (32x32x16, as k_encoder_bf16): results stored into the swizzled a1 image
+        auto x_frags = [&](int pb, bf16x8 (&xh)[4], bf16x8 (&xl)[4], int &pix, bool &valid, bool &inimg) {
+            const int pp = pb * 32 + r;
+            valid = pp < B3_APIX;
+            pix = valid ? pp : B3_APIX - 1;
+            const int ar = pix / B3_AW, ac = pix - ar * B3_AW;
+            const int ii = r0 - 1 + ar, jj = c0 - 1 + ac;
+            inimg = valid && ii >= 0 && ii < H && jj >= 0 && jj < W;
+            const float *xp = xs + (ar + hi) * B3_XW + ac;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 vh, vl;
+                    split_bf16(xp[s * 2 * B3_XW + j], vh, vl);
+                    xh[s][j] = vh; xl[s][j] = vl;
+                }
+        };
+        auto conv1_store = [&](const f32x16 &acc, int cb, int pix, bool valid, bool inimg) {
+            const int sw = ((pix >> 1) & 3) << 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch0 = cb * 32 + 8 * q + 4 * hi;                      // 4 consecutive channels: half of group cb*4 + q
+                const float4 sc = *reinterpret_cast<const float4 *>(st1 + ch0);
+                const float4 sh = *reinterpret_cast<const float4 *>(st1 + 64 + ch0);
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float y = inimg ? bn_relu(acc[4 * q + i], scv[i], shv[i]) : 0.f;
+                    __bf16 a, bb;
+                    split_bf16(y, a, bb);
+                    vh[i] = a; vl[i] = bb;
+                }
+                if (valid) {
+                    const int off = pix * 128 + (((cb * 4 + q) ^ sw) * 16) + 8 * hi;
+                    *reinterpret_cast<bf16x4 *>(a1h + off) = vh;
+                    *reinterpret_cast<bf16x4 *>(a1l + off) = vl;
+                }
+            }
+        };
+        {
+            bf16x8 xh[4], xl[4];
+            int pix; bool valid, inimg;
+            x_frags(wave, xh, xl, pix, valid, inimg);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { acc0[g] = 0.f; acc1[g] = 0.f; }
+            const unsigned char *wrow = w1s + r * B3_W1_PITCH + 8 * hi * 2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(wrow + s * 32);
+                const bf16x8 a1hh = *reinterpret_cast<const bf16x8 *>(wrow + 32 * B3_W1_PITCH + s * 32);
+                const bf16x8 a0l = *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + s * 32);
+                const bf16x8 a1l_ = *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + 32 * B3_W1_PITCH + s * 32);
+                mma3<true>(acc0, a0h, a0l, xh[s], xl[s]);
+                mma3<true>(acc1, a1hh, a1l_, xh[s], xl[s]);
+            }
+            conv1_store(acc0, 0, pix, valid, inimg);
+            conv1_store(acc1, 1, pix, valid, inimg);
+        }
+        {
+            bf16x8 xh[4], xl[4];
+            int pix; bool valid, inimg;
+            const int cb = wave & 1;
+            x_frags(4 + (wave >> 1), xh, xl, pix, valid, inimg);
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            const unsigned char *wrow = w1s + (cb * 32 + r) * B3_W1_PITCH + 8 * hi * 2;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(wrow + s * 32);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(wrow + B3_W1_BYTES + s * 32);
+                mma3<true>(acc, ah, al, xh[s], xl[s]);
+            }
+            conv1_store(acc, cb, pix, valid, inimg);
+        }
+        __syncthreads();                                      // a1 complete; xs is free again
+        __builtin_amdgcn_s_setprio(1);
+
+        const int tn = t + gridDim.x;
+        float xr0 = 0.f, xr1 = 0.f;
+        if (tn < ntiles) {
+            xr0 = x_fetch(tn, tid);
+            xr1 = x_fetch(tn, tid + 256);
+        }
+
+        // ---- conv2: acc[mt][nt][reg] = D(pixel row mt, column 4 kg + reg; channel 16 nt + px of the wave's 32)
+        f32x4v acc[8][2];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[mt][nt][g] = 0.f;
+        // unit k (0..35) = tap * 4 + half * 2 + hm: M tiles 4hm .. 4hm+3 of k-step ks = k >> 1 = tap * 2 + half
+        auto load_a = [&](int k, bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
+            const int tap = k >> 2, half = (k >> 1) & 1, hm = k & 1, ki = tap / 3, kj = tap - 3 * ki;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int R = 4 * hm + m + ki;                                  // a1 halo row
+                const int un = ((half << 1) | kgh) ^ ((tq[kj] + R) & 3);         // bits 2:1 of the swizzled unit
+                const int off = abase[kj] + R * (B3_AW * 128) + un * 32;
+                ah[m] = *reinterpret_cast<const bf16x8 *>(a1h + off);
+                al[m] = *reinterpret_cast<const bf16x8 *>(a1l + off);
+            }
+        };
+        bf16x8 ahA[4], alA[4], ahB[4], alB[4];
+        load_a(0, ahA, alA);
+        constexpr int UNR = 6;                                // 3 k-steps per iteration: ring slot = (k >> 1) % 3 is static
+#pragma unroll 1
+        for (int k0 = 0; k0 < 36; k0 += UNR) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int k = k0 + u, slot = (u >> 1) % RING, hm = u & 1;
+                {   // refill: k-step ks + 2 into the slot consumed one k-step ago; this unit loads N tile hm (hi and lo)
+                    int kn = (k >> 1) + RING - 1;
+                    kn = kn >= 18 ? kn - 18 : kn;
+                    kn = __builtin_amdgcn_readfirstlane(kn);
+                    bq[(slot + RING - 1) % RING][hm][0] = load_b(kn, 0, hm);
+                    bq[(slot + RING - 1) % RING][hm][1] = load_b(kn, 1, hm);
+                }
+                if (k + 1 < 36) {
+                    if (u & 1) load_a(k + 1, ahA, alA); else load_a(k + 1, ahB, alB);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[slot][nt][0]);
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[slot][nt][1]);
+                        f32x4v &c = acc[4 * hm + m][nt];
+                        const bf16x8 ah = (u & 1) ? ahB[m] : ahA[m], al = (u & 1) ? alB[m] : alA[m];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                    }
+                // 24 MFMAs of 16 cycles; 8 DS reads (next unit's fragments) and 2 ring loads issued inside their gaps
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if ((i & 1) == 0 && i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else if (i == 17 || i == 19) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue: BN2 + ReLU + block-mean pool.  Lane: channel o0 (nt 0) / o0 + 16 (nt 1), pixels (row mt, cols 4kg .. 4kg+3)
+        auto out_index = [&](int pi, int pj, int o) -> size_t {
+            return TOKENS ? ((size_t)b * 1024 + pi * 32 + pj) * 128 + o : ((size_t)b * 128 + o) * 1024 + pi * 32 + pj;
+        };
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float s2 = nt ? s2b : s2a, t2 = nt ? t2b : t2a;
+            const int o = o0 + 16 * nt;
+            if (PS == 2) {          // cells: rows (mt, mt+1), column pairs (reg 0,1), (reg 2,3)
+#pragma unroll
+                for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+                    for (int cg = 0; cg < 2; ++cg) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int mt = 2 * mp; mt < 2 * mp + 2; ++mt)
+#pragma unroll
+                            for (int i = 2 * cg; i < 2 * cg + 2; ++i) sum += bn_relu(acc[mt][nt][i], s2, t2);
+                        features[out_index((r0 + 2 * mp) / 2, (c0 + 4 * kg + 2 * cg) / 2, o)] = sum * 0.25f;
+                    }
+            } else if (PS == 4) {   // cells: rows 4mq .. 4mq+3, columns 4kg .. 4kg+3 (all four registers)
+#pragma unroll
+                for (int mq = 0; mq < 2; ++mq) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int mt = 4 * mq; mt < 4 * mq + 4; ++mt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum += bn_relu(acc[mt][nt][i], s2, t2);
+                    features[out_index((r0 + 4 * mq) / 4, (c0 + 4 * kg) / 4, o)] = sum * (1.0f / 16);
+                }
+            } else {                // PS == 8: all 8 rows; columns 0-7 = kg 0,1, columns 8-15 = kg 2,3 (lane ^ 16 holds the other half)
+                float sum = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum += bn_relu(acc[mt][nt][i], s2, t2);
+                const float other = __shfl_xor(sum, 16);
+                const float total = (kg & 1) == 0 ? sum + other : other + sum;   // a+b == b+a: both lanes agree bitwise
+                if ((kg & 1) == 0) features[out_index(r0 / 8, c0 / 8 + (kg >> 1), o)] = total * (1.0f / 64);
+            }
+        }
+
+        xs[tid] = xr0;
+        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = xr1;
+        __syncthreads();
+    }
+}
+
+template <bool TOKENS>
+static hipError_t launch_b16_t(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e, float *features,
+                               hipStream_t st) {
+    const int PS = H / 32;
+    const int tiles_x = W / B3_TW, tiles_per_frame = tiles_x * (H / B3_TH), ntiles = B * tiles_per_frame;
+    int lg_tx = 0, lg_tpf = 0;
+    while ((1 << lg_tx) < tiles_x) ++lg_tx;
+    while ((1 << lg_tpf) < tiles_per_frame) ++lg_tpf;
+    if ((1 << lg_tx) != tiles_x || (1 << lg_tpf) != tiles_per_frame) return hipErrorInvalidValue;
+    static int stagger = -1;
+    if (stagger < 0) { const char *sv = getenv("SMK_ENC_STAGGER"); stagger = sv ? atoi(sv) : 1; }
+    static int wgs_per_cu = 0, num_cu = 0;
+    if (!wgs_per_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        num_cu = prop.multiProcessorCount;
+        int n = 0;
+        (void)hipFuncSetAttribute((const void *)k_encoder_b16<8, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS);
+        (void)hipFuncSetAttribute((const void *)k_encoder_b16<4, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS);
+        (void)hipFuncSetAttribute((const void *)k_encoder_b16<2, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_encoder_b16<8, TOKENS>, 256, S16_LDS) != hipSuccess || n < 1) n = 2;
+        const char *ov = getenv("SMK_ENC_WGS_PER_CU");
+        if (ov && atoi(ov) > 0) n = atoi(ov);
+        wgs_per_cu = n;
+    }
+    int nwg = num_cu * wgs_per_cu;
+    if (nwg > ntiles) nwg = ntiles;
+    dim3 grid(nwg), block(256);
+    switch (PS) {
+        case 2: hipLaunchKernelGGL((k_encoder_b16<2, TOKENS>), grid, block, S16_LDS, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles, stagger); break;
+        case 4: hipLaunchKernelGGL((k_encoder_b16<4, TOKENS>), grid, block, S16_LDS, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles, stagger); break;
+        case 8: hipLaunchKernelGGL((k_encoder_b16<8, TOKENS>), grid, block, S16_LDS, st, frames, fstride, H, W, e, features, lg_tx, lg_tpf, ntiles, stagger); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_encoder_b16(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e, float *features,
+                              bool tokens, hipStream_t st) {
+    return tokens ? launch_b16_t<true>(frames, fstride, B, H, W, e, features, st)
+                  : launch_b16_t<false>(frames, fstride, B, H, W, e, features, st);
+}
+
 template <bool X3, bool TOKENS>
 static hipError_t launch_bf16_t(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
                                 float *features, hipStream_t st) {
@@ -666,6 +1006,11 @@ static hipError_t launch_bf16_t(const float *frames, int64_t fstride, int B, int
 
 hipError_t launch_encoder_bf16(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
                                float *features, bool x3, bool tokens, hipStream_t st) {
+    // split-bf16 runs on the 16x16x32 shape (k_encoder_b16: -7 % time, interleaved A/B); SMK_ENC_SHAPE=32 selects the
+    // 32x32x16 kernel (k_encoder_bf16<true>) for comparison
+    static int shape = 0;
+    if (!shape) { const char *sv = getenv("SMK_ENC_SHAPE"); shape = sv && atoi(sv) == 32 ? 32 : 16; }
+    if (x3 && shape == 16) return launch_encoder_b16(frames, fstride, B, H, W, e, features, tokens, st);
     if (x3) return tokens ? launch_bf16_t<true, true>(frames, fstride, B, H, W, e, features, st)
                           : launch_bf16_t<true, false>(frames, fstride, B, H, W, e, features, st);
     return tokens ? launch_bf16_t<false, true>(frames, fstride, B, H, W, e, features, st)
