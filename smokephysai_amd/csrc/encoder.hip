@@ -682,7 +682,10 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     // B ring in k-steps: slot = [nt][part]; 3 slots = two k-steps ahead
-    constexpr int RING = 3;
+#ifndef S16_RING
+#define S16_RING 2
+#endif
+    constexpr int RING = S16_RING;
     uint4 bq[RING][2][2];
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k)
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
         };
         bf16x8 ahA[4], alA[4], ahB[4], alB[4];
         load_a(0, ahA, alA);
-        constexpr int UNR = 6;                                // 3 k-steps per iteration: ring slot = (k >> 1) % 3 is static
+        constexpr int UNR = 2 * S16_RING == 4 ? 4 : 6;        // RING k-steps per iteration: ring slot = (k >> 1) % RING is static
 #pragma unroll 1
         for (int k0 = 0; k0 < 36; k0 += UNR) {
 #pragma unroll
