@@ -257,7 +257,9 @@ def main():
         if not args.no_encode:
             tf = enc_flops / (ms_enc * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.encoder_dtype]
-            roof_enc = {"bound": "mfma", "kernel": f"k_encoder_{args.encoder_dtype} (fused conv1+conv2+pool, B frames)",
+            kname = {"bf16x3": "k_encoder_b16 (split-bf16 on v_mfma_f32_16x16x32_bf16)", "bf16": "k_encoder_bf16<false>",
+                     "i8x3": "k_encoder_i8", "f32": "k_encoder_f32"}[args.encoder_dtype]
+            roof_enc = {"bound": "mfma", "kernel": f"{kname}: fused conv1+conv2+pool, B frames",
                         "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
                         "ms_per_launch": ms_enc,
                         "note": "achieved counts SURVEY 8(d)'s algorithmic flops; the x3 modes execute 3 MFMA products per "
