@@ -93,16 +93,21 @@ __device__ __forceinline__ void at_split4(const float4 &v, bf16x4 &h, bf16x4 &l)
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_attention_x3(const AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+// KS = 2 (small grids: at most one workgroup per CU): 512 threads; wave group wave >> 2 takes half of the key tiles for the
+// same 128 queries, with its own LDS double buffer; the two partial (m, l, O) are merged through LDS at the end.
+template <int KS>
+__global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    unsigned char *smem = smem_all + grp * AT_LDS;
+    const int tid = threadIdx.x & 255, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the L/128 query blocks of one (batch, head) read the same K/V: give them consecutive ids on ONE XCD (ids are dealt to the
     // 8 XCDs round-robin; needs gridDim.x % 8 == 0, else the plain order)
     const int vid = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int nqb = a.L / AT_QB;
     const int qb = vid % nqb, bh = vid / nqb, head = bh % a.H, b = bh / a.H;
-    const int NT = a.L / AT_KV;
+    const int NT = a.L / AT_KV / KS, T0 = grp * NT;          // this wave group's key tiles: T0 .. T0 + NT - 1
 
     // ---- Q fragments (B operand: column = query r, k = d 16s + 8hh + j), pre-scaled, split
     bf16x8 qh[4], ql[4];
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_x3(const AttnArgs a) {
     const int lane_v = (rq * 4 * a.ldv + head * 64 + c4 * 4) * 4;              // V: rows 4rq + i
     float4 kst[4], vst[4];
     auto stage_load = [&](int t) {
-        const int tt = t < NT ? t : NT - 1;                                    // past the end: a harmless re-read
+        const int tt = T0 + (t < NT ? t : NT - 1);                             // past the end: a harmless re-read
         const unsigned row0 = (unsigned)b * a.L + tt * AT_KV;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -245,6 +250,35 @@ __global__ __launch_bounds__(256, 2) void k_attention_x3(const AttnArgs a) {
         __syncthreads();                                       // tile t+1 visible; every read of tile t's buffer has returned
     }
 
+    if (KS == 2) {   // merge the two wave groups' partial softmax states (same lane layout in both)
+        float *xch = reinterpret_cast<float *>(smem_all + AT_LDS) + (size_t)tid * 36;   // group 1's buffers are free after the last barrier
+        if (grp == 1) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *reinterpret_cast<float4 *>(xch + 16 * db + 4 * q4) =
+                        make_float4(oacc[db][4 * q4], oacc[db][4 * q4 + 1], oacc[db][4 * q4 + 2], oacc[db][4 * q4 + 3]);
+            xch[32] = m_run;
+            xch[33] = l_run;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m2 = xch[32], l2 = xch[33];
+        const float m_new = fmaxf(m_run, m2);
+        const float a1 = __builtin_amdgcn_exp2f(m_run - m_new), a2 = __builtin_amdgcn_exp2f(m2 - m_new);
+        l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 o2 = *reinterpret_cast<const float4 *>(xch + 16 * db + 4 * q4);
+                oacc[db][4 * q4] = oacc[db][4 * q4] * a1 + o2.x * a2;
+                oacc[db][4 * q4 + 1] = oacc[db][4 * q4 + 1] * a1 + o2.y * a2;
+                oacc[db][4 * q4 + 2] = oacc[db][4 * q4 + 2] * a1 + o2.z * a2;
+                oacc[db][4 * q4 + 3] = oacc[db][4 * q4 + 3] * a1 + o2.w * a2;
+            }
+    }
     // ---- normalise and store: 4 consecutive d per register quad
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
@@ -278,13 +312,23 @@ __global__ __launch_bounds__(256, 2) void k_attention_x3(const AttnArgs a) {
 }
 
 hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_attention_x3, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
-        attr_done = true;
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        num_cu = prop.multiProcessorCount;
+        (void)hipFuncSetAttribute((const void *)k_attention_x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
+        (void)hipFuncSetAttribute((const void *)k_attention_x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS);
     }
     const int nwg = a.B * a.H * (a.L / AT_QB);
-    hipLaunchKernelGGL(k_attention_x3, dim3(nwg), dim3(256), AT_LDS, st, a);
+    static int force_ks = -1;
+    if (force_ks < 0) { const char *sv = getenv("SMK_ATTN_KS"); force_ks = sv ? atoi(sv) : 0; }
+    // a grid that leaves the second workgroup slot of every CU empty runs the split-KV form instead (8 waves per CU either way)
+    int ks = (nwg <= num_cu && (a.L / AT_KV) % 2 == 0) ? 2 : 1;
+    if ((force_ks == 1 || force_ks == 2) && (a.L / AT_KV) % force_ks == 0) ks = force_ks;
+    if (ks == 2) hipLaunchKernelGGL(k_attention_x3<2>, dim3(nwg), dim3(512), 2 * AT_LDS, st, a);
+    else hipLaunchKernelGGL(k_attention_x3<1>, dim3(nwg), dim3(256), AT_LDS, st, a);
     return hipGetLastError();
 }
 
