@@ -134,7 +134,7 @@ def inference_ms(dev, N, frames, encoder_dtype):
     if gflop:
         res["counted_TFLOPs_at_sim_batch"] = gflop / res[f"batch{frames.shape[0]}"]
     res["body"] = ("libsmokehip split-bf16 kernels: fused encoder, token linears (bias/pos-embed/chaos-term/GELU/residual epilogues), "
-                   "flash attention, chaos addend, LayerNorm; conv decoder head on PyTorch-ROCm (MIOpen)")
+                   "flash attention, chaos addend, LayerNorm, conv reconstruction head")
     res["note"] = f"{N}x{N} frames; hipGraph replay (eager launch beside it); reference README: 610.92 ms/frame (hardware unstated)"
     return res
 

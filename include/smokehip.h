@@ -226,6 +226,25 @@ int smk_attention(const float *q, const float *k, const float *v, void *out, int
 int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const float *weight, const float *bias, double eps,
                   void *y, int64_t ldy, int32_t y_format, void *stream);
 
+/* ------------------------------------------------------------------ reconstruction head */
+/* Eval-mode SmokePhysNet.reconstruction_head (smokephys_net.py:57-66): ConvTranspose2d(64,32,4,2,1) + BN + ReLU ->
+ * ConvTranspose2d(32,16,4,2,1) + BN + ReLU -> Conv2d(16,1,3,padding 1) -> Sigmoid.  Device pointers, PyTorch layouts:
+ * ct*_w [in][out][4][4], conv_w [1][16][3][3]; BN as (weight, bias, running_mean, running_var), eps 1e-5. */
+typedef struct smk_decoder_weights {
+    const float *ct1_w, *ct1_b, *bn1_w, *bn1_b, *bn1_mean, *bn1_var;
+    const float *ct2_w, *ct2_b, *bn2_w, *bn2_b, *bn2_mean, *bn2_var;
+    const float *conv_w, *conv_b;
+} smk_decoder_weights;
+typedef struct smk_decoder smk_decoder; /* opaque: BN-folded weights on the device */
+
+int smk_decoder_create(const smk_decoder_weights *w, int32_t device_id, void *stream, smk_decoder **out);
+int smk_decoder_destroy(smk_decoder *dec);
+
+/* tokens [B][S*S][64] fp32 -- output_decoder's result, read as `transpose(1,2).view(B,64,S,S)` (smokephys_net.py:117) --
+ * -> recon [B][1][4S][4S].  tmp1 [B][32][2S][2S] and tmp2 [B][16][4S][4S] are caller-owned scratch.  S % 16 == 0. */
+int smk_decoder_forward(smk_decoder *dec, const float *tokens, int32_t B, int32_t S, float *tmp1, float *tmp2,
+                        float *recon, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,12 @@ class SmkEncoderWeights(C.Structure):
                  "conv2_w", "conv2_b", "bn2_w", "bn2_b", "bn2_mean", "bn2_var")]
 
 
+class SmkDecoderWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("ct1_w", "ct1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
+                 "ct2_w", "ct2_b", "bn2_w", "bn2_b", "bn2_mean", "bn2_var", "conv_w", "conv_b")]
+
+
 # name -> (argtypes); every function returns int status except the two noted below
 _SIGNATURES = {
     "smk_sim_create": [C.POINTER(SmkSimDesc), C.POINTER(C.c_void_p)],
@@ -65,6 +71,9 @@ _SIGNATURES = {
                       C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_void_p],
     "smk_layernorm": [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64,
                       C.c_int32, C.c_void_p],
+    "smk_decoder_create": [C.POINTER(SmkDecoderWeights), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
+    "smk_decoder_destroy": [C.c_void_p],
+    "smk_decoder_forward": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_linear_create": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
     "smk_linear_destroy": [C.c_void_p],
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "chaos.h"
+#include "decoder.h"
 #include "encoder.h"
 #include "linear.h"
 #include "stencil.h"
@@ -27,6 +28,12 @@ struct smk_sim {
     int *dev_first = nullptr;
     int src_cap = 0;
     int jacobi_iters = 20;
+    int device = 0;
+};
+
+struct smk_decoder {
+    DecoderDev d;
+    float *blob = nullptr;
     int device = 0;
 };
 
@@ -603,6 +610,57 @@ int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const fl
     a.x = x; a.y = (float *)y; a.w = weight; a.b = bias; a.ldx = ldx; a.ldy = ldy; a.rows = (int)rows; a.D = D; a.eps = (float)eps;
     a.y_split = y_format == SMK_FMT_SPLIT_BF16;
     return check_launch(launch_layernorm(a, (hipStream_t)stream), "layernorm");
+}
+
+// ------------------------------------------------------------------ reconstruction head
+int smk_decoder_create(const smk_decoder_weights *w, int32_t device_id, void *stream, smk_decoder **out) {
+    SMK_REQUIRE(w && out, "null weights/out");
+    const float *const *pp = (const float *const *)w;
+    for (size_t k = 0; k < sizeof(*w) / sizeof(float *); ++k) SMK_REQUIRE(pp[k], "null weight pointer");
+    int rc = set_device(device_id);
+    if (rc) return rc;
+    smk_decoder *dec = new smk_decoder();
+    dec->device = device_id;
+    const size_t n = 64 * 32 * 16 + 32 * 16 * 16 + 16 * 9 + 32 + 16 + 16;
+    hipError_t e = hipMalloc((void **)&dec->blob, n * sizeof(float));
+    if (e != hipSuccess) {
+        delete dec;
+        set_error(std::string("smk_decoder_create: ") + hipGetErrorString(e));
+        return SMK_ERR_HIP;
+    }
+    float *p = dec->blob;
+    dec->d.w1 = p; p += 64 * 32 * 16;
+    dec->d.w2 = p; p += 32 * 16 * 16;
+    dec->d.w3 = p; p += 16 * 9;
+    dec->d.t1 = p; p += 32;
+    dec->d.t2 = p; p += 16;
+    dec->d.b3 = p;
+    rc = check_launch(launch_fold_decoder(*w, dec->d, (hipStream_t)stream), "fold_decoder");
+    if (rc) { smk_decoder_destroy(dec); return rc; }
+    *out = dec;
+    return SMK_OK;
+}
+
+int smk_decoder_destroy(smk_decoder *dec) {
+    if (!dec) return SMK_OK;
+    (void)hipSetDevice(dec->device);
+    if (dec->blob) (void)hipFree(dec->blob);
+    delete dec;
+    return SMK_OK;
+}
+
+int smk_decoder_forward(smk_decoder *dec, const float *tokens, int32_t B, int32_t S, float *tmp1, float *tmp2,
+                        float *recon, void *stream) {
+    SMK_REQUIRE(dec && tokens && tmp1 && tmp2 && recon, "null dec/tokens/tmp/recon");
+    SMK_REQUIRE(B >= 1 && B <= 65535, "1 <= B <= 65535");
+    if (S < 16 || S % 16 != 0) {
+        set_error("decoder: HIP path is built for token grids whose side is a multiple of 16");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    SMK_REQUIRE(((uintptr_t)tokens & 15) == 0 && ((uintptr_t)tmp1 & 7) == 0 && ((uintptr_t)tmp2 & 7) == 0, "alignment");
+    int rc = set_device(dec->device);
+    if (rc) return rc;
+    return check_launch(launch_decoder(dec->d, tokens, B, S, tmp1, tmp2, recon, (hipStream_t)stream), "decoder");
 }
 
 }  // extern "C"

@@ -5,8 +5,9 @@ Inference (eval mode): frames go through the fused HIP encoder (csrc/encoder.hip
 on MFMA, both adaptive pools as one block mean) -- there is no CPU fallback for it.  The token-wise linear layers of the
 transformer body (feature_proj, q/k/v/out projections, FFN, output_decoder) run on libsmokehip's split-bf16 MFMA kernel
 (csrc/linear.hip) with bias / pos-embedding / chaos-term / GELU / residual fused into the GEMM epilogue, the softmax
-attention on its split-bf16 flash kernel (csrc/transformer.hip, chaos term folded into Q); LayerNorm and the conv heads
-are PyTorch-ROCm ops.
+attention on its split-bf16 flash kernel (csrc/transformer.hip, chaos term folded into Q), LayerNorm and the conv
+reconstruction head (csrc/decoder.hip, BatchNorms folded) on their own kernels; only the 3-element physics head and the
+token mean are PyTorch-ROCm ops.
 Training (train mode): the encoder runs as autograd-tracked PyTorch ops with batch-statistics BatchNorm, exactly the
 reference's op sequence (smokephys_net.py:87-91).
 """
@@ -17,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .chaos_attention import ChaosAttention
+from .decoder import HipDecoder, decoder_weight_dict, hip_decoder_supported
 from .encoder import HipEncoder, encoder_weight_dict
 from .hip_body import HipBody
 from .linear import hip_linear_supported
@@ -65,6 +67,7 @@ class SmokePhysNet(nn.Module):
         self._hip = None          # (HipEncoder, weight fingerprint)
         self._pos_cache = None    # (fingerprint, tensor)
         self._hip_body = HipBody()   # libsmokehip mirrors of the token-wise linear layers + per-layer scratch
+        self._hip_dec = None         # (HipDecoder, weight fingerprint)
 
     # ---- HIP encoder plumbing -------------------------------------------------------------------------------
     def _encoder_fingerprint(self):
@@ -104,11 +107,24 @@ class SmokePhysNet(nn.Module):
         return pe
 
     # ---- transformer body on libsmokehip (eval only; per-layer code: hip_body.py) ----------------------------------
+    def _decoder_fingerprint(self):
+        return tuple((t.data_ptr(), t._version) for t in decoder_weight_dict(self.reconstruction_head).values())
+
+    def hip_decoder(self) -> HipDecoder:
+        """BN-folded HIP reconstruction head for the current reconstruction_head tensors (rebuilt when they change)."""
+        fp = self._decoder_fingerprint()
+        if self._hip_dec is None or self._hip_dec[1] != fp:
+            if self._hip_dec is not None:
+                self._hip_dec[0].close()
+            self._hip_dec = (HipDecoder(decoder_weight_dict(self.reconstruction_head), device=self.pos_embedding.device), fp)
+        return self._hip_dec[0]
+
     def hip_weights_fingerprint(self):
         """Identity + version of every tensor libsmokehip keeps a re-laid-out copy of (GraphedSmokePhysNet re-captures
         when this changes)."""
+        dec = self._decoder_fingerprint() if self._hip_dec is not None else None
         return (self._encoder_fingerprint(), (self.pos_embedding.data_ptr(), self.pos_embedding._version),
-                self._hip_body.fingerprint())
+                self._hip_body.fingerprint(), dec)
 
     def _body_hip(self, tokens: torch.Tensor, chaos_noise: Optional[torch.Tensor], pool_size: int):
         """feature_proj + pos-embed, the pre-LN chaos transformer layers and output_decoder (smokephys_net.py:95-114,
@@ -155,8 +171,13 @@ class SmokePhysNet(nn.Module):
             for li, layer in enumerate(self.chaos_layers):
                 features = layer(features, noise=None if chaos_noise is None else chaos_noise[li])
             output_features = self.output_decoder(features)
-        output_reshaped = output_features.transpose(1, 2).reshape(B, -1, pool_size, pool_size)
-        reconstructed = self.reconstruction_head(output_reshaped)
+        if (not self.training and not torch.is_grad_enabled() and self.linear_dtype == "bf16x3" and output_features.is_cuda
+                and output_features.dtype == torch.float32 and output_features.shape[2] == 64
+                and hip_decoder_supported(self.reconstruction_head, pool_size)):
+            reconstructed = self.hip_decoder()(output_features)           # 3 fused launches, BN folded
+        else:
+            output_reshaped = output_features.transpose(1, 2).reshape(B, -1, pool_size, pool_size)
+            reconstructed = self.reconstruction_head(output_reshaped)
         pooled_features = features.mean(dim=1)
         physics_pred = self.physics_head(pooled_features)
         results = {"reconstructed": reconstructed, "physics_features": physics_pred, "latent_features": pooled_features}

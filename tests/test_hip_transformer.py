@@ -139,3 +139,30 @@ def test_layernorm_and_attention_split_bf16_outputs():
     o = hip_attention(q, k, v, 8, 0.125)
     os_ = hip_attention(q, k, v, 8, 0.125, out_split=True)
     assert os_.shape == (2, 256, 64, 2, 8) and rel_err(from_split(os_).cpu().numpy(), o.cpu().numpy()) < 2.0 ** -16
+
+
+@pytest.mark.parametrize("B,S", [(1, 32), (3, 32), (2, 16)])
+def test_decoder_head_matches_torch(B, S):
+    """smk_decoder_forward (BN-folded direct fp32 kernels) against the PyTorch reconstruction_head in eval mode
+    (smokephys_net.py:57-66,117-118), including the tokens -> [B,64,S,S] re-view."""
+    from smokephysai_amd.models import SmokePhysNet
+    from smokephysai_amd.models.decoder import HipDecoder, decoder_weight_dict, hip_decoder_supported
+    torch.manual_seed(B * 10 + S)
+    head = SmokePhysNet().reconstruction_head.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(S)
+    with torch.no_grad():
+        for m in head:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.num_features, device="cuda", generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(m.num_features, device="cuda", generator=g) + 0.5)
+                m.weight.copy_(torch.randn(m.num_features, device="cuda", generator=g) * 0.3 + 1.0)
+                m.bias.copy_(torch.randn(m.num_features, device="cuda", generator=g) * 0.1)
+        assert hip_decoder_supported(head, S)
+        tokens = torch.randn(B, S * S, 64, device="cuda", generator=g)
+        ref = head(tokens.transpose(1, 2).reshape(B, 64, S, S).double().float())
+        ref64 = head.double()(tokens.double().transpose(1, 2).reshape(B, 64, S, S))
+        head.float()
+        out = HipDecoder(decoder_weight_dict(head))(tokens)
+    assert out.shape == (B, 1, 4 * S, 4 * S)
+    assert rel_err(out.cpu().numpy(), ref64.cpu().numpy()) < 5e-6
+    assert rel_err(ref.cpu().numpy(), ref64.cpu().numpy()) < 1e-4
