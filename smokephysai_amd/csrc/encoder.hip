@@ -636,11 +636,11 @@ __global__ __launch_bounds__(256, 2) void k_encoder_bf16(const float *__restrict
 // per flop the 16x16x32 shape sustains a higher clock (MI355X_MICROARCH.md, "Shape": 1.12-1.14x in LDS-fed loops).
 //   conv2: D[pix][o], M tile = one tile row of 16 pixels (8 per workgroup tile), N tile = 16 channels (2 per wave), K = 32 c per
 //          k-step (18 = 9 taps x 2).  A lane reads pixel (lane & 15), channel group 4*half + (lane >> 4) (8 c = 16 B).
-//   a1 image: [180 halo pixels][8 groups of 8 c] without padding, group g of pixel p stored at unit g ^ (((p >> 1) & 3) << 1):
-//          no linear pitch is conflict-free for this operand (ds_read_b128 serves lanes {0-3,12-15,20-27} together: 8 pixels
-//          of one channel group with 8 of the next); the XOR keeps bit 0 of the group (so the two groups of a lane group use
-//          even / odd units) and spreads bits 1-2 over 4 consecutive pixel pairs -> every lane group hits 16 distinct units
-//          for every tap shift.
+//   a1 image: [180 halo pixels][8 groups of 8 c] without padding, group g of pixel p stored at unit g ^ (p & 7).
+//          No linear pitch is conflict-free for this operand (ds_read_b128 serves lanes {0-3,12-15,20-27} together: 8 pixels
+//          of one channel group with 8 of the next); with the XOR every lane group hits 16 distinct 16-byte units for every tap
+//          shift, and conv1's 8-byte stores stay at their inherent 2-way (an exhaustive search over pitches 8..16 units and
+//          shift/mask swizzles: DESIGN.md 3.2; the first swizzle tried, (p >> 1 & 3) << 1, read conflict-free but stored 4-way).
 //   loop:  unit = half a k-step (M tiles 4hm..4hm+3: 24 MFMAs = 384 cycles, the same unit as k_encoder_bf16's k-step), so the
 //          skeleton -- A fragments of the next unit read under this unit's MFMAs, B ring from L2 -- and the register budget
 //          (64 acc + 64 A + 48 B) carry over.
@@ -694,15 +694,14 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
             bq[k][nt][0] = load_b(k, 0, nt);
             bq[k][nt][1] = load_b(k, 1, nt);
         }
-    // A addressing: pixel p = (mt + ki) * 18 + px + kj; unit = g ^ (((p >> 1) & 3) << 1), g = 4 half + kg.  (p >> 1) & 3 =
-    // (((px + kj) >> 1) + (mt + ki)) & 3 because 18 / 2 = 9 = 1 (mod 4): tq[kj] is the lane part, the row part is added per read.
+    // A addressing: pixel p = (mt + ki) * 18 + px + kj; unit = g ^ (p & 7), g = 4 half + kg.  p & 7 = (px + kj + 2 (mt + ki)) & 7
+    // because 18 = 2 (mod 8): tq[kj] is the lane part, the row part is added per read.
     int tq[3], abase[3];
 #pragma unroll
     for (int kj = 0; kj < 3; ++kj) {
-        tq[kj] = ((px + kj) >> 1) & 3;
-        abase[kj] = (px + kj) * 128 + (kg & 1) * 16;
+        tq[kj] = (px + kj) ^ 0;
+        abase[kj] = (px + kj) * 128;
     }
-    const int kgh = kg >> 1;
 
     auto x_fetch = [&](int t, int k) -> float {
         if (k >= B3_XH * B3_XW) return 0.f;
@@ -746,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
                 }
         };
         auto conv1_store = [&](const f32x16 &acc, int cb, int pix, bool valid, bool inimg) {
-            const int sw = ((pix >> 1) & 3) << 1;
+            const int sw = pix & 7;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ch0 = cb * 32 + 8 * q + 4 * hi;                      // 4 consecutive channels: half of group cb*4 + q
@@ -829,8 +828,8 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int R = 4 * hm + m + ki;                                  // a1 halo row
-                const int un = ((half << 1) | kgh) ^ ((tq[kj] + R) & 3);         // bits 2:1 of the swizzled unit
-                const int off = abase[kj] + R * (B3_AW * 128) + un * 32;
+                const int un = (4 * half + kg) ^ ((tq[kj] + 2 * R) & 7);         // swizzled 16-byte unit of the channel group
+                const int off = abase[kj] + R * (B3_AW * 128) + un * 16;
                 ah[m] = *reinterpret_cast<const bf16x8 *>(a1h + off);
                 al[m] = *reinterpret_cast<const bf16x8 *>(a1l + off);
             }
