@@ -682,10 +682,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     // B ring in k-steps: slot = [nt][part]; 3 slots = two k-steps ahead
-#ifndef S16_RING
-#define S16_RING 2
-#endif
-    constexpr int RING = S16_RING;
+    constexpr int RING = 2;                                   // two k-steps = one tap: the slot of k-step (tap, half) is `half`
     uint4 bq[RING][2][2];
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k)
@@ -696,12 +693,6 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
         }
     // A addressing: pixel p = (mt + ki) * 18 + px + kj; unit = g ^ (p & 7), g = 4 half + kg.  p & 7 = (px + kj + 2 (mt + ki)) & 7
     // because 18 = 2 (mod 8): tq[kj] is the lane part, the row part is added per read.
-    int tq[3], abase[3];
-#pragma unroll
-    for (int kj = 0; kj < 3; ++kj) {
-        tq[kj] = (px + kj) ^ 0;
-        abase[kj] = (px + kj) * 128;
-    }
 
     auto x_fetch = [&](int t, int k) -> float {
         if (k >= B3_XH * B3_XW) return 0.f;
@@ -822,35 +813,49 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[mt][nt][g] = 0.f;
-        // unit k (0..35) = tap * 4 + half * 2 + hm: M tiles 4hm .. 4hm+3 of k-step ks = k >> 1 = tap * 2 + half
-        auto load_a = [&](int k, bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
-            const int tap = k >> 2, half = (k >> 1) & 1, hm = k & 1, ki = tap / 3, kj = tap - 3 * ki;
+        // unit k (0..35) = tap * 4 + half * 2 + hm: M tiles 4hm .. 4hm+3 of k-step ks = k >> 1 = tap * 2 + half.  The loop runs over
+        // the 9 taps (runtime) x 4 unrolled units.  Per tap four lane registers om[m] = pixel base ^ swizzle term of row m + ki
+        // are formed once (the base is a multiple of 128 and the term < 128, so base + (c ^ t) = base ^ t ^ c): a fragment pair then
+        // costs ONE xor, and the row offsets ki * 2304 (scalar) and 4hm * 2304 + m * 2304 (ds_read immediate) are free.
+        const int c16[2] = {kg << 4, (4 + kg) << 4};
+        auto tap_consts = [&](int ki, int kj, int (&om)[4]) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) om[m] = ((px + kj) << 7) ^ (((px + kj + 2 * (m + ki)) & 7) << 4);
+        };
+        auto load_a = [&](int ki, int half, int hm, const int (&om)[4], bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
+            const unsigned char *ph = a1h + ki * (B3_AW * 128), *pl = a1l + ki * (B3_AW * 128);      // wave-uniform part
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int R = 4 * hm + m + ki;                                  // a1 halo row
-                const int un = (4 * half + kg) ^ ((tq[kj] + 2 * R) & 7);         // swizzled 16-byte unit of the channel group
-                const int off = abase[kj] + R * (B3_AW * 128) + un * 16;
-                ah[m] = *reinterpret_cast<const bf16x8 *>(a1h + off);
-                al[m] = *reinterpret_cast<const bf16x8 *>(a1l + off);
+                const int off = om[m] ^ c16[half];
+                ah[m] = *reinterpret_cast<const bf16x8 *>(ph + off + (4 * hm + m) * (B3_AW * 128));
+                al[m] = *reinterpret_cast<const bf16x8 *>(pl + off + (4 * hm + m) * (B3_AW * 128));
             }
         };
         bf16x8 ahA[4], alA[4], ahB[4], alB[4];
-        load_a(0, ahA, alA);
-        constexpr int UNR = 2 * S16_RING == 4 ? 4 : 6;        // RING k-steps per iteration: ring slot = (k >> 1) % RING is static
+        int om[4];
+        tap_consts(0, 0, om);
+        load_a(0, 0, 0, om, ahA, alA);
+        int ki = 0, kj = 0;
 #pragma unroll 1
-        for (int k0 = 0; k0 < 36; k0 += UNR) {
+        for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int k = k0 + u, slot = (u >> 1) % RING, hm = u & 1;
-                {   // refill: k-step ks + 2 into the slot consumed one k-step ago; this unit loads N tile hm (hi and lo)
-                    int kn = (k >> 1) + RING - 1;
+            for (int u = 0; u < 4; ++u) {
+                const int half = u >> 1, hm = u & 1, slot = half % RING;
+                {   // refill: k-step ks + RING - 1 into the slot consumed one k-step ago; this unit loads N tile hm (hi and lo)
+                    int kn = tap * 2 + half + RING - 1;
                     kn = kn >= 18 ? kn - 18 : kn;
                     kn = __builtin_amdgcn_readfirstlane(kn);
                     bq[(slot + RING - 1) % RING][hm][0] = load_b(kn, 0, hm);
                     bq[(slot + RING - 1) % RING][hm][1] = load_b(kn, 1, hm);
                 }
-                if (k + 1 < 36) {
-                    if (u & 1) load_a(k + 1, ahA, alA); else load_a(k + 1, ahB, alB);
+                if (u < 3) {                                   // next unit: same tap
+                    if (u & 1) load_a(ki, (u + 1) >> 1, (u + 1) & 1, om, ahA, alA);
+                    else load_a(ki, (u + 1) >> 1, (u + 1) & 1, om, ahB, alB);
+                } else if (tap < 8) {                          // first unit of the next tap (u = 3 is odd: set A)
+                    kj = kj == 2 ? 0 : kj + 1;
+                    ki = kj == 0 ? ki + 1 : ki;
+                    tap_consts(ki, kj, om);
+                    load_a(ki, 0, 0, om, ahA, alA);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
