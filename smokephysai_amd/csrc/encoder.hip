@@ -857,18 +857,22 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
                     tap_consts(ki, kj, om);
                     load_a(ki, 0, 0, om, ahA, alA);
                 }
+                // product-major emission: consecutive MFMAs go to different accumulators (dependency distance 8 instead of 1); each
+                // accumulator still sums lo*hi, hi*lo, hi*hi in that order, so results are bitwise those of the chain-major form
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[slot][nt][0]);
-                        const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[slot][nt][1]);
-                        f32x4v &c = acc[4 * hm + m][nt];
-                        const bf16x8 ah = (u & 1) ? ahB[m] : ahA[m], al = (u & 1) ? alB[m] : alA[m];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-                    }
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[slot][nt][0]);
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[slot][nt][1]);
+                            f32x4v &c = acc[4 * hm + m][nt];
+                            const bf16x8 ah = (u & 1) ? ahB[m] : ahA[m], al = (u & 1) ? alB[m] : alA[m];
+                            if (pr == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+                            else if (pr == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+                            else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                        }
                 // 24 MFMAs of 16 cycles; 8 DS reads (next unit's fragments) and 2 ring loads issued inside their gaps
 #pragma unroll
                 for (int i = 0; i < 24; ++i) {
