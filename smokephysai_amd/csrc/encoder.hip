@@ -653,7 +653,9 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
                                                      EncoderDev e, float *__restrict__ features, int lg_tiles_x,
                                                      int lg_tiles_per_frame, int ntiles, int stagger) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *xs = reinterpret_cast<float *>(smem);
+    // x tile kept already split: one word per pixel, hi bf16 in the low half, lo bf16 in the high half (split once by the staging
+    // thread; every wave's fragment builder then needs one v_perm_b32 per element pair instead of two 3-instruction splits)
+    unsigned int *xs = reinterpret_cast<unsigned int *>(smem);
     unsigned char *a1h = smem + B3_XS_BYTES, *a1l = a1h + S16_A1_BYTES;
     unsigned char *w1s = a1l + S16_A1_BYTES;
     float *st1 = reinterpret_cast<float *>(w1s + 2 * B3_W1_BYTES);
@@ -703,12 +705,17 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
         const bool ok = row < B3_XH - 1 && col < B3_XW - 1 && ii >= 0 && ii < H && jj >= 0 && jj < W;
         return ok ? frames[(size_t)bb * fstride + (size_t)ii * W + jj] : 0.f;
     };
+    auto pack_split = [](float v) -> unsigned int {
+        __bf16 vh, vl;
+        split_bf16(v, vh, vl);
+        return (unsigned int)__builtin_bit_cast(unsigned short, vh) | ((unsigned int)__builtin_bit_cast(unsigned short, vl) << 16);
+    };
     int t = blockIdx.x;
     if (stagger > 0 && ((blockIdx.x / 256) & 1))
         for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
     if (t < ntiles) {
-        xs[tid] = x_fetch(t, tid);
-        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = x_fetch(t, tid + 256);
+        xs[tid] = pack_split(x_fetch(t, tid));
+        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = pack_split(x_fetch(t, tid + 256));
     }
     __syncthreads();
 
@@ -725,15 +732,19 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
             const int ar = pix / B3_AW, ac = pix - ar * B3_AW;
             const int ii = r0 - 1 + ar, jj = c0 - 1 + ac;
             inimg = valid && ii >= 0 && ii < H && jj >= 0 && jj < W;
-            const float *xp = xs + (ar + hi) * B3_XW + ac;
+            const unsigned int *xp = xs + (ar + hi) * B3_XW + ac;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
+                unsigned int wh[4], wl[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    __bf16 vh, vl;
-                    split_bf16(xp[s * 2 * B3_XW + j], vh, vl);
-                    xh[s][j] = vh; xl[s][j] = vl;
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned int e0 = xp[s * 2 * B3_XW + 2 * jj], e1 = xp[s * 2 * B3_XW + 2 * jj + 1];
+                    wh[jj] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);          // low halves: the two hi parts
+                    wl[jj] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);          // high halves: the two lo parts
                 }
+                xh[s] = __builtin_bit_cast(bf16x8, make_uint4(wh[0], wh[1], wh[2], wh[3]));
+                xl[s] = __builtin_bit_cast(bf16x8, make_uint4(wl[0], wl[1], wl[2], wl[3]));
+            }
         };
         auto conv1_store = [&](const f32x16 &acc, int cb, int pix, bool valid, bool inimg) {
             const int sw = pix & 7;
@@ -926,8 +937,8 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
             }
         }
 
-        xs[tid] = xr0;
-        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = xr1;
+        xs[tid] = pack_split(xr0);
+        if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = pack_split(xr1);
         __syncthreads();
     }
 }
