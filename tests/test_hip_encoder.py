@@ -111,3 +111,39 @@ def test_unsupported_shapes_fail_loudly(enc):
         enc(torch.zeros(1, 1, 96, 96, device="cuda"))
     with pytest.raises(SmokeHipError):
         enc(torch.zeros(1, 1, 64, 64, device="cuda"), input_dim=48)
+
+
+def test_bf16x3_on_the_32x32x16_shape_still_matches():
+    """SMK_ENC_SHAPE=32 selects k_encoder_bf16<true> (the 32x32x16 MFMA form kept for A/B against the default 16x16x32
+    kernel).  The switch is read once per process, so this runs in a child process: same fixtures, same 1e-4 bar, both output
+    layouts, and the two kernels agree with each other to 1e-5."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+from conftest import rel_err
+from smokephysai_amd.models.encoder import HipEncoder
+w = {k: torch.from_numpy(v) for k, v in np.load("tests/golden/encoder_weights.npz").items()}
+enc = HipEncoder(w)
+for N in (64, 128, 256):
+    g = np.load(f"tests/golden/encoder_io_{N}.npz")
+    x = torch.from_numpy(g["frames"]).cuda()
+    f = enc(x[:, None], input_dim=128, dtype="bf16x3")
+    t = enc.tokens(x[:, None], input_dim=128, dtype="bf16x3")
+    assert rel_err(f.cpu().numpy(), g["features"]) < 1e-4, N
+    assert torch.equal(t, f.flatten(2).transpose(1, 2)), N
+    np.save(f"/tmp/smk_feat32_{N}.npy", f.cpu().numpy())
+print("ok32")
+'''
+    env = dict(os.environ, SMK_ENC_SHAPE="32")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok32" in out.stdout, out.stderr[-2000:]
+    w = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(root, "tests/golden/encoder_weights.npz")).items()}
+    enc16 = HipEncoder(w)
+    for N in (64, 128, 256):
+        g = np.load(os.path.join(root, f"tests/golden/encoder_io_{N}.npz"))
+        f16 = enc16(torch.from_numpy(g["frames"]).cuda()[:, None], input_dim=128, dtype="bf16x3").cpu().numpy()
+        assert rel_err(f16, np.load(f"/tmp/smk_feat32_{N}.npy")) < 1e-5, N
