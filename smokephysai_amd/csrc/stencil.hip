@@ -185,13 +185,13 @@ __global__ void k_copy_cells(Geom g, const float *src, float *dst) {
 // across waves through a double-buffered LDS edge exchange (one barrier per sweep).  Each band carries (TR-BR)/2
 // redundant halo rows on every non-physical side, so `iters` <= that many sweeps are exact on the BR owned rows
 // (the garbage front moves one row per sweep).  Per cell the arithmetic is exactly k_jacobi_sweep's.
-__device__ __forceinline__ float wave_shr1(float x) {   // lane i <- lane i-1 (lane 0: unchanged, unused)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
-                                                                  0x138, 0xf, 0xf, false));
+// bound_ctrl zero-fills the lane without a source (lane 0 / lane 63: grid-edge cells, whose neighbour value is never used), so no
+// copy of `x` into the destination is needed before the DPP move: one instruction per shift instead of two.
+__device__ __forceinline__ float wave_shr1(float x) {   // lane i <- lane i-1 (lane 0: 0, unused)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_shl1(float x) {   // lane i <- lane i+1 (lane 63: unchanged, unused)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
-                                                                  0x130, 0xf, 0xf, false));
+__device__ __forceinline__ float wave_shl1(float x) {   // lane i <- lane i+1 (lane 63: 0, unused)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
 
 constexpr int JB_NW = 16;
@@ -284,13 +284,12 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
             dst[k][0] = first_col ? 0.f : dst[k][0];          // column ring: only the two edge cells need a select
             dst[k][VEC - 1] = last_col ? 0.f : dst[k][VEC - 1];
         }
-        if (ring_k == 0) {                                    // row ring: scalar branches, taken by 2 waves of a grid
+        // row ring (grid row 0 / H-1: 2 waves of a grid): wave-uniform selects -- as scalar branches they cost more in register
+        // copies at the control-flow merges (16 v_mov per sweep) than the 2 * VEC v_cndmask they save
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) dst[0][c] = 0.f;
-        }
-        if (ring_k == RPW - 1) {
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) dst[RPW - 1][c] = 0.f;
+        for (int c = 0; c < VEC; ++c) {
+            dst[0][c] = ring_k == 0 ? 0.f : dst[0][c];
+            dst[RPW - 1][c] = ring_k == RPW - 1 ? 0.f : dst[RPW - 1][c];
         }
     };
     float pw[RPW][VEC];
