@@ -257,6 +257,28 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
             edge[par][wave][0][j0 + c] = src[0][c];
             edge[par][wave][1][j0 + c] = src[RPW - 1][c];
         }
+        __builtin_amdgcn_sched_barrier(0);                    // publish first: the neighbours' edge rows wait on these stores
+        // one row of the sweep; up / dn: the rows above and below (registers, or the neighbour wave's edge row)
+        auto row = [&](int k, const float (&up)[VEC], const float (&dn)[VEC]) {
+            const float lin = wave_shr1(src[k][VEC - 1]), rin = wave_shl1(src[k][0]);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const float l = c > 0 ? src[k][c - 1] : lin;
+                const float r = c < VEC - 1 ? src[k][c + 1] : rin;
+                float sm = up[c] + dn[c];
+                sm = sm + l;
+                sm = sm + r;
+                sm = sm - dv[k][c];
+                dst[k][c] = 0.25f * sm;
+            }
+            dst[k][0] = first_col ? 0.f : dst[k][0];          // column ring: only the two edge cells need a select
+            dst[k][VEC - 1] = last_col ? 0.f : dst[k][VEC - 1];
+        };
+        // The sweep is bound by publish -> barrier -> read -> compute, not by VALU throughput: the rows that need nothing from
+        // the neighbour waves (1 .. RPW-2) are computed BEFORE the barrier, under the wait; only the two edge rows follow it.
+#pragma unroll
+        for (int k = 1; k < RPW - 1; ++k) row(k, src[k - 1], src[k + 1]);
+        __builtin_amdgcn_sched_barrier(0);                    // (hipcc otherwise sinks these rows below the barrier)
         __syncthreads();
         const float *eu = &edge[par][wave > 0 ? wave - 1 : 0][1][j0];            // top wave: value unused (ring or halo row)
         const float *ed = &edge[par][wave < JB_NW - 1 ? wave + 1 : JB_NW - 1][0][j0];
@@ -266,23 +288,11 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
             above[c] = eu[c];
             below[c] = ed[c];
         }
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            const float lin = wave_shr1(src[k][VEC - 1]), rin = wave_shl1(src[k][0]);
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                const float up = k > 0 ? src[k - 1][c] : above[c];
-                const float dn = k < RPW - 1 ? src[k + 1][c] : below[c];
-                const float l = c > 0 ? src[k][c - 1] : lin;
-                const float r = c < VEC - 1 ? src[k][c + 1] : rin;
-                float s = up + dn;
-                s = s + l;
-                s = s + r;
-                s = s - dv[k][c];
-                dst[k][c] = 0.25f * s;
-            }
-            dst[k][0] = first_col ? 0.f : dst[k][0];          // column ring: only the two edge cells need a select
-            dst[k][VEC - 1] = last_col ? 0.f : dst[k][VEC - 1];
+        if (RPW == 1) {
+            row(0, above, below);
+        } else {
+            row(0, above, src[1]);
+            row(RPW - 1, src[RPW - 2], below);
         }
         // row ring (grid row 0 / H-1: 2 waves of a grid): wave-uniform selects -- as scalar branches they cost more in register
         // copies at the control-flow merges (16 v_mov per sweep) than the 2 * VEC v_cndmask they save
