@@ -264,18 +264,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
                 else load_a(buf, u + 1, ahB, alB);
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, bqh[u]);
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, bql[u]);
+                // product-major emission: consecutive MFMAs go to different accumulators; each still sums lo*hi, hi*lo, hi*hi in order
 #pragma unroll
-                for (int mi = 0; mi < MB; ++mi) {
-                    if (u & 1) {
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, alB[mi], acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ahB[mi], acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ahB[mi], acc[mi], 0, 0, 0);
-                    } else {
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, alA[mi], acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ahA[mi], acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ahA[mi], acc[mi], 0, 0, 0);
-                    }
-                }
+                for (int mi = 0; mi < MB; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, (u & 1) ? alB[mi] : alA[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, (u & 1) ? ahB[mi] : ahA[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, (u & 1) ? ahB[mi] : ahA[mi], acc[mi], 0, 0, 0);
                 // Schedule of one k-step: next k-step's fragment reads, the ring refill and (k-steps 0,1) the staging work are
                 // issued INSIDE the gaps of this k-step's MFMAs (left alone, hipcc sinks every ds_read to just before its
                 // consumer and waits on it there).

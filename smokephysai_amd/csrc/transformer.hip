@@ -188,17 +188,24 @@ __global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) 
         // ---- S^T = K Q^T (log2 units): sacc[kb][g] = score(query r, key 32kb + (g&3) + 8(g>>2) + 4hh)
         f32x16 sacc[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int g = 0; g < 16; ++g) sacc[kb][g] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(kb_h + kb * 32 * AT_KPITCH + s * 32);
-                const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(kb_h + AT_KPLANE + kb * 32 * AT_KPITCH + s * 32);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], sacc[kb], 0, 0, 0);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], sacc[kb], 0, 0, 0);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], sacc[kb], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 kh[2], kl[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                kh[kb] = *reinterpret_cast<const bf16x8 *>(kb_h + kb * 32 * AT_KPITCH + s * 32);
+                kl[kb] = *reinterpret_cast<const bf16x8 *>(kb_h + AT_KPLANE + kb * 32 * AT_KPITCH + s * 32);
             }
+            // product-major: consecutive MFMAs alternate between the two accumulators (each still sums lo*hi, hi*lo, hi*hi in order)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[kb], qh[s], sacc[kb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kb], ql[s], sacc[kb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kb], qh[s], sacc[kb], 0, 0, 0);
         }
         // the staged registers hold tile t+1: split + write it to the other buffer (its last reads ended before the barrier
         // that closed tile t-1), then re-issue the loads for tile t+2
@@ -235,18 +242,23 @@ __global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) 
 
         // ---- O^T += V^T P: oacc[db][g] = O(query r, d 32db + (g&3) + 8(g>>2) + 4hh)
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int s4 = 0; s4 < 4; ++s4) {
+            bf16x8 vh[2], vl[2];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
+            for (int db = 0; db < 2; ++db) {
                 const unsigned char *p0 = vt_h + db * 32 * AT_VPITCH + s4 * 32;          // keys 16 s4 + 4hh .. +3 | +8
                 const bf16x4 h0 = *reinterpret_cast<const bf16x4 *>(p0), h1 = *reinterpret_cast<const bf16x4 *>(p0 + 16);
                 const bf16x4 l0 = *reinterpret_cast<const bf16x4 *>(p0 + AT_VPLANE), l1 = *reinterpret_cast<const bf16x4 *>(p0 + AT_VPLANE + 16);
-                const bf16x8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s4], oacc[db], 0, 0, 0);
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s4], oacc[db], 0, 0, 0);
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s4], oacc[db], 0, 0, 0);
+                vh[db] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                vl[db] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[db], ph[s4], oacc[db], 0, 0, 0);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[db], pl[s4], oacc[db], 0, 0, 0);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[db], ph[s4], oacc[db], 0, 0, 0);
+        }
         __syncthreads();                                       // tile t+1 visible; every read of tile t's buffer has returned
     }
 
