@@ -5,7 +5,7 @@
 # Summaries land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 set -u
 TAG=${1:-prof}
-STEPS=${2:-20}
+STEPS=${2:-150}   # >= 100: the first ~20 launches of a fresh process run 10-25 % slower (clock ramp); a short profile overstates the average
 DTYPE=${3:-bf16x3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
