@@ -7,6 +7,9 @@ from .. import _lib
 from .linear import split_empty
 
 
+MAX_QKV_ELEMS = 1 << 29      # smk_attention: B * L * ld < 2^29 floats per tensor and launch (32-bit buffer offsets)
+
+
 def hip_attention_supported(L: int, head_dim: int) -> bool:
     return head_dim == 64 and L % 128 == 0 and L >= 128
 
@@ -25,9 +28,17 @@ def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: 
     if out is None:
         out = split_empty(B, L, D, device=dev) if out_split else torch.empty(B, L, D, device=dev, dtype=torch.float32)
     ldo = D if out_split else out.stride(1)
-    _lib.check(_lib.load().smk_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, L, num_heads, d,
-                                        q.stride(1), k.stride(1), v.stride(1), ldo, float(scale), int(out_split),
-                                        _lib.stream_ptr(dev)))
+    ld_max = max(q.stride(1), k.stride(1), v.stride(1), ldo)
+    bmax = max(1, (MAX_QKV_ELEMS - 1) // (L * ld_max))       # larger batches go in batch chunks (independent problems)
+    o_batch_bytes = L * D * 4 if out_split else out.stride(0) * 4
+    b0 = 0
+    while b0 < B:
+        nb = min(bmax, B - b0)
+        _lib.check(_lib.load().smk_attention(q.data_ptr() + b0 * q.stride(0) * 4, k.data_ptr() + b0 * k.stride(0) * 4,
+                                            v.data_ptr() + b0 * v.stride(0) * 4, out.data_ptr() + b0 * o_batch_bytes, nb, L,
+                                            num_heads, d, q.stride(1), k.stride(1), v.stride(1), ldo, float(scale),
+                                            int(out_split), _lib.stream_ptr(dev)))
+        b0 += nb
     return out
 
 

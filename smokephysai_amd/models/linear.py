@@ -35,6 +35,9 @@ def hip_linear_supported(in_features: int, out_features: int) -> bool:
     return in_features % 64 == 0 and out_features % 32 == 0
 
 
+MAX_X_ELEMS = 1 << 30        # smk_linear_forward: (rows + 256) * ldx < 2^30 floats per launch (32-bit buffer offsets)
+
+
 class HipLinear:
     """Device-resident, re-laid-out copy of one nn.Linear's weights + the launch wrapper."""
 
@@ -113,6 +116,18 @@ class HipLinear:
                 raise ValueError("HipLinear: periodic_add must be [rows / rows_per_group, period, out_features]")
             pa_ptr, period = pa.data_ptr(), pa.shape[1]
         act = {None: _lib.SMK_ACT_NONE, "none": _lib.SMK_ACT_NONE, "gelu": _lib.SMK_ACT_GELU, "relu": _lib.SMK_ACT_RELU}[activation]
-        _lib.check(self._L.smk_linear_forward(self._handle, x_ptr, rows, ldx, y_ptr, ldy, res_ptr, ldr, pa_ptr, rpg, period,
-                                              act, int(x_split), int(out_split), _lib.stream_ptr(self._dev)))
+        # one launch addresses x with 32-bit offsets: larger inputs go in row chunks (whole groups when a periodic addend is set)
+        unit = rpg if pa_ptr else 128
+        max_rows = max(unit, ((MAX_X_ELEMS // max(ldx, 1) - 256) // unit) * unit)
+        x_row_bytes = (2 * self.in_features * 2) if x_split else ldx * 4
+        y_row_bytes = (2 * self.out_features * 2) if out_split else ldy * 4
+        r0 = 0
+        while r0 < rows:
+            n = min(max_rows, rows - r0)
+            _lib.check(self._L.smk_linear_forward(
+                self._handle, x_ptr + r0 * x_row_bytes, n, ldx, y_ptr + r0 * y_row_bytes, ldy,
+                res_ptr + r0 * ldr * 4 if res_ptr else 0, ldr,
+                pa_ptr + (r0 // rpg) * period * self.out_features * 4 if pa_ptr else 0, rpg, period,
+                act, int(x_split), int(out_split), _lib.stream_ptr(self._dev)))
+            r0 += n
         return y

@@ -166,3 +166,25 @@ def test_decoder_head_matches_torch(B, S):
     assert out.shape == (B, 1, 4 * S, 4 * S)
     assert rel_err(out.cpu().numpy(), ref64.cpu().numpy()) < 5e-6
     assert rel_err(ref.cpu().numpy(), ref64.cpu().numpy()) < 1e-4
+
+
+def test_large_inputs_are_chunked_transparently(monkeypatch):
+    """One launch addresses its inputs with 32-bit offsets; the wrappers split larger problems into row / batch chunks.
+    With the thresholds lowered, chunked results must equal the single-launch results bit for bit."""
+    import math
+    from smokephysai_amd.models import attention as A, linear as Lm
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(6, 256, 512, device="cuda", generator=g)
+    w = torch.randn(1536, 512, device="cuda", generator=g) / math.sqrt(512)
+    b = torch.randn(1536, device="cuda", generator=g)
+    padd = torch.randn(6, 5, 1536, device="cuda", generator=g)
+    res = torch.randn(6, 256, 1536, device="cuda", generator=g)
+    lin = Lm.HipLinear(w, b)
+    y_p, y_r = lin(x, periodic_add=padd), lin(x, residual=res, activation=None)
+    qkv = y_p
+    o = A.hip_attention(qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:], 8, 0.125)
+    monkeypatch.setattr(Lm, "MAX_X_ELEMS", (512 + 256) * 512 + 1)          # -> chunks of 512 rows (2 groups of 256)
+    monkeypatch.setattr(A, "MAX_QKV_ELEMS", 2 * 256 * 1536 + 1)            # -> chunks of 2 batch elements
+    assert torch.equal(lin(x, periodic_add=padd), y_p)
+    assert torch.equal(lin(x, residual=res), y_r)
+    assert torch.equal(A.hip_attention(qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:], 8, 0.125), o)
