@@ -45,3 +45,9 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "smoke_oracle" in txt:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_graft_entry_build_passes():
+    """The driver's "does it build" hook (make is a no-op when the library is current; includes the ABI-version check)."""
+    import __graft_entry__ as g
+    g.build()
