@@ -685,6 +685,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
     };
     // B ring in k-steps: slot = [nt][part]; 3 slots = two k-steps ahead
     constexpr int RING = 2;                                   // two k-steps = one tap: the slot of k-step (tap, half) is `half`
+                                                              // (3-deep with a 3-tap body: 43 spilled registers, +12 % time)
     uint4 bq[RING][2][2];
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k)
@@ -852,12 +853,18 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int half = u >> 1, hm = u & 1, slot = half % RING;
-                {   // refill: k-step ks + RING - 1 into the slot consumed one k-step ago; this unit loads N tile hm (hi and lo)
+                if (hm == 0) {
+                    // refill: k-step ks + 1 into the slot consumed one k-step ago.  All four fragments (both N tiles, hi and lo) are
+                    // requested in the FIRST unit of the k-step, right at its start: two units (768 cycles) before their first use.
+                    // Measured placements of the ring loads within a unit: early 1.06 ms, middle 1.075, late 1.11.
                     int kn = tap * 2 + half + RING - 1;
                     kn = kn >= 18 ? kn - 18 : kn;
                     kn = __builtin_amdgcn_readfirstlane(kn);
-                    bq[(slot + RING - 1) % RING][hm][0] = load_b(kn, 0, hm);
-                    bq[(slot + RING - 1) % RING][hm][1] = load_b(kn, 1, hm);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        bq[(slot + RING - 1) % RING][nt][0] = load_b(kn, 0, nt);
+                        bq[(slot + RING - 1) % RING][nt][1] = load_b(kn, 1, nt);
+                    }
                 }
                 if (u < 3) {                                   // next unit: same tap
                     if (u & 1) load_a(ki, (u + 1) >> 1, (u + 1) & 1, om, ahA, alA);
@@ -884,12 +891,14 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
                             else if (pr == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
                             else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
                         }
-                // 24 MFMAs of 16 cycles; 8 DS reads (next unit's fragments) and 2 ring loads issued inside their gaps
+                // 24 MFMAs of 16 cycles.  The next unit's 8 fragment reads are spread evenly, one after every third MFMA; the ring loads
+                // go right behind the first MFMAs.  (One read per second MFMA in the first 16 -- what hipcc also does unpinned -- is
+                // 4 % slower; see DESIGN.md 3.2 for the placements measured.)
 #pragma unroll
                 for (int i = 0; i < 24; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if ((i & 1) == 0 && i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    else if (i == 17 || i == 19) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else if (hm == 0 && (i == 1 || i == 2 || i == 4 || i == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
