@@ -28,6 +28,9 @@ constexpr int LN_PITCH = 144;      // bytes per staged row per plane: 64 bf16 + 
 #ifndef SMK_LINEAR_SCHED
 #define SMK_LINEAR_SCHED 1
 #endif
+#ifndef SMK_LN_RINGFIRST
+#define SMK_LN_RINGFIRST 1
+#endif
 constexpr int LN_RING = 4;         // B fragments in flight: 3 k-steps ahead; 4 k-steps per chunk keep the ring indices static
 template <int MB> constexpr int ln_plane_bytes() { return MB * 32 * LN_PITCH; }
 template <int MB, int NW> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 1024; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
@@ -282,13 +285,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
+#if SMK_LN_RINGFIRST
+                        if (i < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // ring refill first (L2 latency)
                         if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // 1 DS read (next k-step's fragment)
+#else
+                        if (i < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // 1 DS read (next k-step's fragment)
+#endif
                         if (VPER) __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);             // split arithmetic
                         if (i >= NMF - NPC) {
                             __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                      // a finished piece: 2 DS writes
                             __builtin_amdgcn_sched_group_barrier(0x020, AS ? 2 : 1, 0);             //   + its re-issued load(s)
                         }
+#if !SMK_LN_RINGFIRST
                         if (i >= NMF - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // ring refill
+#endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
