@@ -644,6 +644,10 @@ __global__ __launch_bounds__(256, 2) void k_encoder_bf16(const float *__restrict
 //   loop:  unit = half a k-step (M tiles 4hm..4hm+3: 24 MFMAs = 384 cycles, the same unit as k_encoder_bf16's k-step), so the
 //          skeleton -- A fragments of the next unit read under this unit's MFMAs, B ring from L2 -- and the register budget
 //          (64 acc + 64 A + 48 B) carry over.
+#ifndef S16_PRIO_CONV1
+#define S16_PRIO_CONV1 0
+#define S16_PRIO_KLOOP 1
+#endif
 constexpr int S16_A1_BYTES = B3_APIX * 128;                               // 23,040 per plane
 constexpr int S16_LDS = B3_XS_BYTES + 2 * S16_A1_BYTES + 2 * B3_W1_BYTES + B3_ST_BYTES;   // 66,736 -> 2 workgroups per CU
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
         const int b = t >> lg_tiles_per_frame, rem = t & ((1 << lg_tiles_per_frame) - 1);
         const int r0 = (rem >> lg_tiles_x) * B3_TH, c0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
 
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(S16_PRIO_CONV1);
         // ---- conv1 on MFMA (32x32x16, as k_encoder_bf16): results stored into the swizzled a1 image
         auto x_frags = [&](int pb, bf16x8 (&xh)[4], bf16x8 (&xl)[4], int &pix, bool &valid, bool &inimg) {
             const int pp = pb * 32 + r;
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
             conv1_store(acc, cb, pix, valid, inimg);
         }
         __syncthreads();                                      // a1 complete; xs is free again
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(S16_PRIO_KLOOP);
 
         const int tn = t + gridDim.x;
         float xr0 = 0.f, xr1 = 0.f;
