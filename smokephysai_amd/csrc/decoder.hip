@@ -140,8 +140,14 @@ __global__ __launch_bounds__(256) void k_conv3_sigmoid(const float *__restrict__
 hipError_t launch_decoder(const DecoderDev &d, const float *tokens, int B, int S, float *tmp1, float *tmp2, float *recon,
                           hipStream_t st) {
     const int t1 = (S / DC_T) * (S / DC_T), t2 = (2 * S / DC_T) * (2 * S / DC_T), t3 = (4 * S / DC_T) * (4 * S / DC_T);
-    hipLaunchKernelGGL((k_convt4s2<64, 32, 8, true>), dim3(t1, 4, B), dim3(256), 0, st, tokens, d.w1, d.t1, tmp1, S, S);
-    hipLaunchKernelGGL((k_convt4s2<32, 16, 8, false>), dim3(t2, 2, B), dim3(256), 0, st, tmp1, d.w2, d.t2, tmp2, 2 * S, 2 * S);
+    // small batches: narrower output-channel groups -> 4x the workgroups (B = 1: 16 and 32 workgroups otherwise)
+    if ((long long)t1 * 4 * B < 256) {
+        hipLaunchKernelGGL((k_convt4s2<64, 32, 2, true>), dim3(t1, 16, B), dim3(256), 0, st, tokens, d.w1, d.t1, tmp1, S, S);
+        hipLaunchKernelGGL((k_convt4s2<32, 16, 2, false>), dim3(t2, 8, B), dim3(256), 0, st, tmp1, d.w2, d.t2, tmp2, 2 * S, 2 * S);
+    } else {
+        hipLaunchKernelGGL((k_convt4s2<64, 32, 8, true>), dim3(t1, 4, B), dim3(256), 0, st, tokens, d.w1, d.t1, tmp1, S, S);
+        hipLaunchKernelGGL((k_convt4s2<32, 16, 8, false>), dim3(t2, 2, B), dim3(256), 0, st, tmp1, d.w2, d.t2, tmp2, 2 * S, 2 * S);
+    }
     hipLaunchKernelGGL(k_conv3_sigmoid, dim3(t3, 1, B), dim3(256), 0, st, tmp2, d.w3, d.b3, recon, 4 * S, 4 * S);
     return hipGetLastError();
 }

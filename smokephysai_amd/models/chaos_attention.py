@@ -76,7 +76,11 @@ class ChaosAttention(nn.Module):
         from .. import _lib
         dev = _lib.require_cuda(device, "ChaosAttention.chaos_addend_hip")
         if noise is None:
-            noise = torch.stack([torch.randn(batch_size, 1, device=dev) for _ in range(3)])
+            # the reference's three randn(B,1) generator calls, in its order, written straight into one [3,B,1] buffer
+            # (torch.stack of three tiny tensors costs three device memcpys per layer)
+            noise = torch.empty(3, batch_size, 1, device=dev, dtype=torch.float32)
+            for i in range(3):
+                torch.randn(batch_size, 1, device=dev, out=noise[i])
         n3 = noise.to(dev, torch.float32).reshape(3, batch_size).contiguous()
         if out is None:                      # out: [B, 5, >= dim] float32, columns 0..dim-1 are written
             out = torch.empty(batch_size, 5, self.dim, device=dev, dtype=torch.float32)
