@@ -86,16 +86,22 @@ struct LinearArgs {
 
 // AS: the activations arrive already split (SMK_FMT_SPLIT_BF16: per row, per 8 k: 8 hi | 8 lo bf16 -- the same 4 bytes per
 // element as fp32, written by the producing kernel's epilogue): staging is then a 16-byte copy, no arithmetic in the K loop.
-template <int MB, int NW, bool AS>
-__global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
+// KS > 1 (small problems only: fewer tiles than the chip has workgroup slots): KS wave groups of NW waves share one output tile, each
+// walking 1/KS of the K range with its own LDS chunk stream; the partial sums are merged through LDS in fixed group order
+// (deterministic, no atomics) and group 0 runs the epilogue.
+template <int MB, int NW, bool AS, int KS = 1>
+__global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(const LinearArgs a) {
     constexpr int TN = NW * 32, RP = AS ? NW * 8 : NW * 4;   // tile columns; rows staged per pass (fp32: 16 float4 per row chunk; split: 8 x 32 B)
     constexpr bool sched = SMK_LINEAR_SCHED;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     constexpr int TM = MB * 32, PLANE = ln_plane_bytes<MB>();
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hi = lane >> 5;
+    const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / (NW * 64));
+    unsigned char *smem = smem_all + grp * ln_lds_bytes<MB, NW>();
+    const int tid = KS == 1 ? (int)threadIdx.x : (int)threadIdx.x % (NW * 64), lane = tid & 63, r = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.l.K, N = a.l.N, M = a.c.M;
-    const int nchunks = K >> 6, nks = K >> 4;
+    const int nchunks = (K >> 6) / KS, nks = nchunks * 4;      // this wave group's share of the K range
+    const int c_off = grp * nchunks, k_off = c_off * 4;
     // Workgroups are dealt to the 8 XCDs round-robin (id % 8).  vid renumbers them so that one XCD holds a contiguous id range:
     // the tiles_n workgroups that share a row block (the same A rows) then run on ONE XCD at the same time and A is fetched
     // from HBM once (L2 hits for the others) instead of once per XCD.  (gridDim.x % (8 * tiles_n) == 0 or swz == 0.)
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.l.wq), 0, K * N * 4, 0x00020000);
     const int frag_bytes = N * 32;                           // one (k-step, part) plane
     auto load_b = [&](int kn, int part) -> uint4 {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (((a.dbg & 2) ? 0 : kn) * 2 + part) * frag_bytes, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (((a.dbg & 2) ? 0 : kn + k_off) * 2 + part) * frag_bytes, 0);
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
     uint4 bqh[LN_RING], bql[LN_RING];
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
     const int lane_x = sr * ldxb + sc * (AS ? 32 : 16);
     auto stage_load = [&](int tmx, int cx, int j) {
         const unsigned row_u = (unsigned)((a.dbg & 1) ? 0 : tmx) * TM + RP * j;          // wave-uniform part (SALU); tmx <= tiles_m
-        const unsigned off = row_u * (unsigned)ldxb + (unsigned)cx * 256u;                // < 2^32: api.hip bounds (rows + 256) * ldx
+        const unsigned off = row_u * (unsigned)ldxb + (unsigned)(cx + c_off) * 256u;      // < 2^32: api.hip bounds (rows + 256) * ldx
         if (AS) {
             sth[AS ? j : 0] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
             stl[AS ? j : 0] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x + 16u), 0, 0);
@@ -313,9 +319,37 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
 #ifdef SMK_LN_STAMPS
         LN_STAMP(t_k1);
 #endif
+        if (KS > 1) {   // merge the wave groups' partial sums: groups 1.. park theirs in LDS, group 0 adds them in group order
+            float *xch = reinterpret_cast<float *>(smem_all + KS * ln_lds_bytes<MB, NW>());
+            if (grp > 0) {
+                float *dstp = xch + ((size_t)(grp - 1) * (NW * 64) + tid) * (MB * 16);
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4 *>(dstp + mi * 16 + 4 * q) =
+                            make_float4(acc[mi][4 * q], acc[mi][4 * q + 1], acc[mi][4 * q + 2], acc[mi][4 * q + 3]);
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int gsrc = 1; gsrc < KS; ++gsrc) {
+                    const float *srcp = xch + ((size_t)(gsrc - 1) * (NW * 64) + tid) * (MB * 16);
+#pragma unroll
+                    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 o = *reinterpret_cast<const float4 *>(srcp + mi * 16 + 4 * q);
+                            acc[mi][4 * q] += o.x; acc[mi][4 * q + 1] += o.y; acc[mi][4 * q + 2] += o.z; acc[mi][4 * q + 3] += o.w;
+                        }
+                }
+            }
+            // (the next write to xch by groups 1.. lies behind at least one more workgroup barrier -- the next tile's first chunk --
+            //  which group 0 reaches only after these reads)
+        }
         // ---- epilogue.  The weights are the MFMA's row operand, so acc[mi][4q + i] = output row mi*32 + r (this lane's token),
         //      column 8q + 4hi + i of the wave's 32: four consecutive columns per lane -> 16-byte loads and stores.
-        if (nw_ok && !(a.dbg & 4)) {
+        if (grp == 0 && nw_ok && !(a.dbg & 4)) {
             const int row0 = tm * TM, ncol = tn * TN + wave * 32 + 4 * hi;
             const float *bias_w = bias_s + wave * 32 + 4 * hi;
             // Global loads (residual, periodic addend) of row block mi+1 are issued BEFORE the stores of block mi: vmcnt retires in
@@ -416,15 +450,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_x3(const LinearArgs a) {
 #endif
 }
 
-template <int MB, int NW, bool AS>
+template <int MB, int NW, bool AS, int KS = 1>
 static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
-    constexpr int lds = ln_lds_bytes<MB, NW>();
+    constexpr int lds = KS * ln_lds_bytes<MB, NW>() + (KS - 1) * NW * 64 * MB * 16 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    const int nwg_max = (NW == 8 ? 1 : 2) * a.num_cu;     // 8 waves per CU either way
+    const int nwg_max = (NW == 8 || KS > 1 ? 1 : 2) * a.num_cu;     // 8 waves per CU either way (split-K: one workgroup per CU)
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
     long long nwg = tiles < nwg_max ? tiles : nwg_max;
     nwg -= nwg % a.tiles_n;                               // every workgroup keeps one column tile
@@ -438,7 +472,7 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     // one tile ~ (K/64) chunks x ~4.2 K cycles + ~9 K epilogue; s_sleep(127) ~ 8 K cycles
     b.stagger_unit = stg_env > 1 ? (int)(((a.l.K / 64) * 4200 + 9000) / 8128 / stg_env) : 0;
     if (b.stagger_unit < 1) b.stagger = 0;
-    hipLaunchKernelGGL((k_linear_x3<MB, NW, AS>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
+    hipLaunchKernelGGL((k_linear_x3<MB, NW, AS, KS>), dim3((unsigned)nwg), dim3(NW * 64 * KS), lds, st, b);
     return hipGetLastError();
 }
 
@@ -494,7 +528,21 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
         if (nw == 8) e = launch_mb<4, 8, false>(a, st);
         else if (mb == 4) e = launch_mb<4, 4, false>(a, st);
         else if (mb == 2) e = launch_mb<2, 4, false>(a, st);
-        else e = launch_mb<1, 4, false>(a, st);
+        else {
+            // few 32 x 128 tiles (batch 1: 128 for the 2048 -> 512 layer): split K over 2 or 4 wave groups per workgroup
+            static int force_ks = -1;
+            if (force_ks < 0) { const char *sv = getenv("SMK_LINEAR_KS"); force_ks = sv ? atoi(sv) : 0; }
+            const long long tiles = (long long)a.tiles_m * a.tiles_n;
+            const int nch = l.K / 64;
+            int ks = 1;
+            // measured at M = 1024: 2048 -> 512 (128 tiles, 32 chunks) 24.4 -> 19.3 us with 4 groups; neutral at 8 chunks; with
+            // 512 tiles already on the chip a split only adds the merge (+15 %)
+            if (tiles <= num_cu / 2 && nch % 4 == 0 && nch >= 16) ks = 4;
+            if (force_ks == 1 || ((force_ks == 2 || force_ks == 4) && nch % force_ks == 0 && nch / force_ks >= 1)) ks = force_ks;
+            if (ks == 4) e = launch_mb<1, 4, false, 4>(a, st);
+            else if (ks == 2) e = launch_mb<1, 4, false, 2>(a, st);
+            else e = launch_mb<1, 4, false>(a, st);
+        }
     }
 #ifdef SMK_LN_STAMPS
     if (getenv("SMK_LN_STAMPS_PRINT")) {   // diagnostic: wait, print the per-wave averages (cycles per tile; clock = core cycles / 100 MHz ticks)

@@ -85,7 +85,8 @@ def test_linear_strided_rows_and_unsupported_shapes():
 
 def test_linear_split_bf16_input_and_output_formats():
     """SMK_FMT_SPLIT_BF16 on either side of a layer: a pre-split x gives the same result as fp32 x (the kernel splits fp32
-    the same way), a split y decodes (hi + lo) to the fp32 y within the format's resolution (2^-17 relative)."""
+    the same way; 1e-6: only the K summation order may differ), a split y decodes (hi + lo) to the fp32 y within the
+    format's resolution (2^-17 relative)."""
     from smokephysai_amd.models.linear import to_split, from_split
     g = torch.Generator(device="cuda").manual_seed(3)
     for (B, L, K, N, act) in [(2, 1024, 512, 2048, "gelu"), (1, 256, 2048, 512, None), (3, 128, 128, 384, None), (1, 40, 64, 32, "relu")]:
@@ -98,11 +99,12 @@ def test_linear_split_bf16_input_and_output_formats():
         assert xs.shape == (B, L, K // 8, 2, 8) and xs.dtype == torch.bfloat16
         assert (from_split(xs) - x).abs().max().item() <= x.abs().max().item() * 2.0 ** -16
         y_from_split = lin(xs, activation=act, x_split=True)
-        assert torch.equal(y_from_split, y)
+        # same operand values; the summation order over K can differ (the fp32-input form may split K across wave groups)
+        assert rel_err(y_from_split.cpu().numpy(), y.cpu().numpy()) < 1e-6
         ys = lin(x, activation=act, out_split=True)
         assert ys.shape == (B, L, N // 8, 2, 8)
         assert rel_err(from_split(ys).cpu().numpy(), y.cpu().numpy()) < 2.0 ** -16
         both = lin(xs, activation=act, x_split=True, out_split=True)
-        assert torch.equal(both, ys)
+        assert rel_err(from_split(both).cpu().numpy(), from_split(ys).cpu().numpy()) < 2.0 ** -15      # two decodes of the format
         res = torch.randn(B, L, N, device="cuda", generator=g)
-        assert torch.equal(lin(xs, residual=res, x_split=True), lin(x, residual=res))
+        assert rel_err(lin(xs, residual=res, x_split=True).cpu().numpy(), lin(x, residual=res).cpu().numpy()) < 1e-6
