@@ -74,13 +74,19 @@ __device__ __forceinline__ float gelu_erf(float v) {
 #define LN_STAMP(v) unsigned long long v; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0)
 #define LN_RSTAMP(v) unsigned long long v; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0)
 #endif
+// timing ablations (SMK_LINEAR_DBG) exist only in diagnostic builds; the product library ignores the variable
+#ifdef SMK_LN_DIAG
+#define LN_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define LN_DBG(a, bit) 0
+#endif
 struct LinearArgs {
     LinearDev l;
     LinearCall c;
     int tiles_m, tiles_n;
     int swz, stagger, stagger_unit, num_cu;
     unsigned long long *stamps;
-    int dbg;              // timing ablations (SMK_LINEAR_DBG; results are wrong when non-zero): 1 A loads re-read tile 0,
+    int dbg;              // timing ablations, honoured only by -DSMK_LN_DIAG builds (results are wrong when non-zero): 1 A loads re-read tile 0,
                           // 2 B ring re-reads k-step 0, 4 no epilogue
 };
 
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.l.wq), 0, K * N * 4, 0x00020000);
     const int frag_bytes = N * 32;                           // one (k-step, part) plane
     auto load_b = [&](int kn, int part) -> uint4 {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (((a.dbg & 2) ? 0 : kn + k_off) * 2 + part) * frag_bytes, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, ((LN_DBG(a, 2) ? 0 : kn + k_off) * 2 + part) * frag_bytes, 0);
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
     uint4 bqh[LN_RING], bql[LN_RING];
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     const int ldxb = (int)a.c.ldx * 4;                       // row bytes (split rows are dense: ldx = K)
     const int lane_x = sr * ldxb + sc * (AS ? 32 : 16);
     auto stage_load = [&](int tmx, int cx, int j) {
-        const unsigned row_u = (unsigned)((a.dbg & 1) ? 0 : tmx) * TM + RP * j;          // wave-uniform part (SALU); tmx <= tiles_m
+        const unsigned row_u = (unsigned)(LN_DBG(a, 1) ? 0 : tmx) * TM + RP * j;          // wave-uniform part (SALU); tmx <= tiles_m
         const unsigned off = row_u * (unsigned)ldxb + (unsigned)(cx + c_off) * 256u;      // < 2^32: api.hip bounds (rows + 256) * ldx
         if (AS) {
             sth[AS ? j : 0] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
         }
         // ---- epilogue.  The weights are the MFMA's row operand, so acc[mi][4q + i] = output row mi*32 + r (this lane's token),
         //      column 8q + 4hi + i of the wave's 32: four consecutive columns per lane -> 16-byte loads and stores.
-        if (grp == 0 && nw_ok && !(a.dbg & 4)) {
+        if (grp == 0 && nw_ok && !LN_DBG(a, 4)) {
             const int row0 = tm * TM, ncol = tn * TN + wave * 32 + 4 * hi;
             const float *bias_w = bias_s + wave * 32 + 4 * hi;
             // Global loads (residual, periodic addend) of row block mi+1 are issued BEFORE the stores of block mi: vmcnt retires in
@@ -493,7 +499,11 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     if (force_mb < 0) { const char *s = getenv("SMK_LINEAR_MB"); force_mb = s ? atoi(s) : 0; }
     if (force_nw < 0) { const char *s = getenv("SMK_LINEAR_NW"); force_nw = s ? atoi(s) : 0; }
     static int dbg = -1;
+#ifdef SMK_LN_DIAG
     if (dbg < 0) { const char *s = getenv("SMK_LINEAR_DBG"); dbg = s ? atoi(s) : 0; }
+#else
+    dbg = 0;
+#endif
     a.dbg = dbg;
     a.num_cu = num_cu;
     a.swz = 0;
