@@ -8,12 +8,16 @@
 // Nothing but the frame is read from HBM and nothing but the pooled features is written: the conv1 activations of a
 // tile (+1 halo) live only in LDS, conv2 is an implicit GEMM  D[pixel][o] = sum_k A[pixel][k] B[k][o]  with
 // k = (tap, channel) whose A fragments are shifted reads of that LDS tile (no im2col), BN2 + ReLU + the block-mean pool
-// run in the epilogue.  Three kernels, one per arithmetic:
+// run in the epilogue.  One kernel per arithmetic (SMK_BF16X3, the default, runs k_encoder_b16):
 //   k_encoder_f32   tile 8x32, 512 threads; conv1 on VALU, conv2 on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain),
 //                   weights [tap][c][o] double-buffered through LDS.
 //   k_encoder_bf16  persistent, tile 8x16, 256 threads; both convs on v_mfma_f32_32x32x16_bf16; X3 = split-bf16
 //                   (hi*hi + hi*lo + lo*hi: fp32-class accuracy), weights as register fragments straight from L2.
-//   k_encoder_i8    same structure; conv2 on v_mfma_i32_32x32x32_i8 with 16-bit fixed-point operands as two int8 limbs.
+//   k_encoder_b16   the headline kernel: split-bf16 as k_encoder_bf16<X3>, conv2 on v_mfma_f32_16x16x32_bf16 (same cycles per
+//                   flop, higher sustained clock under the power limit), XOR-swizzled a1 image, one-xor fragment addressing,
+//                   product-major MFMA emission, pinned read / ring-load placement (-22 % time vs k_encoder_bf16<X3>).
+//   k_encoder_i8    same structure as k_encoder_bf16; conv2 on v_mfma_i32_32x32x32_i8 with 16-bit fixed-point operands as two
+//                   int8 limbs.
 #include "encoder.h"
 
 #include <stdlib.h>
