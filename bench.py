@@ -278,6 +278,9 @@ def main():
             for key, kname in (("roofline_stencil", "stencil"), ("roofline_encoder", "encoder")):
                 if key in out and kname in tr:
                     out[key]["traffic"] = tr[kname]
+        sq = os.path.join(ROOT, "profiles", "pmc_mfma.json")     # tools/pmc_encoder.sh: matrix-pipe busy cycles of the headline kernel
+        if os.path.exists(sq) and "roofline_encoder" in out and args.encoder_dtype == "bf16x3":
+            out["roofline_encoder"]["pmc"] = json.load(open(sq))
         if world == 1:
             out["hbm_copy_measured_GBs"] = hbm_copy_gbs(dev)
         if world == 1 and not args.no_encode and not args.no_inference:
