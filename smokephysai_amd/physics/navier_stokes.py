@@ -54,10 +54,10 @@ class NavierStokesSimulator(nn.Module):
         self._handle = handle
 
     def __del__(self):
-        h = getattr(self, "_handle", None)
+        h = self.__dict__.get("_handle")
         if h:
+            self.__dict__["_handle"] = None       # not nn.Module.__setattr__: torch's globals may be gone at interpreter exit
             self._L.smk_sim_destroy(h)
-            self._handle = None
 
     # ---- state views with the reference's shapes (navier_stokes.py:27-32) ---------------------------------
     def _view(self, store, cols):
