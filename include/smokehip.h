@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 2
+#define SMK_ABI_VERSION 3
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -183,6 +183,13 @@ typedef enum smk_activation { SMK_ACT_NONE = 0, SMK_ACT_GELU = 1 /* erf form, nn
 int smk_linear_create(const float *weight, const float *bias, int32_t out_features, int32_t in_features,
                       int32_t device_id, void *stream, smk_linear **out);
 int smk_linear_destroy(smk_linear *lin);
+
+/* Re-split new weights into an existing handle (training: the parameters change at every optimizer step, train.py:88-93; no
+ * allocation).  transposed = 0: weight is [out_features][in_features] as in smk_linear_create.  transposed = 1: weight is
+ * [in_features][out_features] row-major, i.e. the handle computes x W for a PyTorch weight W whose shape is
+ * [in_features][out_features] -- the input-gradient GEMM dX = dY W of nn.Linear's backward (autograd's LinearBackward0) on the
+ * same kernel.  bias NULL = zeros.  Read once, on `stream`. */
+int smk_linear_update(smk_linear *lin, const float *weight, int32_t transposed, const float *bias, void *stream);
 
 /* y = act(x W^T + b + addend) + residual over `rows` token rows:
  *   x [rows][in_features], row pitch ldx floats; y [rows][out_features], row pitch ldy (all row starts 16-byte aligned);

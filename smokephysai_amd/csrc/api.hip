@@ -523,6 +523,14 @@ int smk_linear_destroy(smk_linear *lin) {
     return SMK_OK;
 }
 
+int smk_linear_update(smk_linear *lin, const float *weight, int32_t transposed, const float *bias, void *stream) {
+    SMK_REQUIRE(lin && weight, "null lin/weight");
+    SMK_REQUIRE(transposed == 0 || transposed == 1, "transposed is 0 or 1");
+    int rc = set_device(lin->device);
+    if (rc) return rc;
+    return check_launch(launch_split_linear_weights(weight, bias, lin->l, (hipStream_t)stream, transposed), "split_linear_weights");
+}
+
 int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx, void *y, int64_t ldy,
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream) {

@@ -21,7 +21,7 @@ struct LinearCall {
     int x_split, y_split;                 // SMK_FMT_SPLIT_BF16 on the input / output side (rows dense: ldx = K, ldy = N)
 };
 
-hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st);
+hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed = 0);
 hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t st);
 
 }  // namespace smk

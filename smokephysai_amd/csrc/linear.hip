@@ -35,10 +35,14 @@ constexpr int LN_RING = 4;         // B fragments in flight: 3 k-steps ahead; 4 
 template <int MB> constexpr int ln_plane_bytes() { return MB * 32 * LN_PITCH; }
 template <int MB, int NW> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 1024; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
 
-__global__ __launch_bounds__(256) void k_split_linear_weights(const float *__restrict__ w, const float *__restrict__ bias, LinearDev l) {
+// transposed: `w` is [K][N] row-major (the handle then computes x W for a layer whose weight is W [K][N]: its input-gradient GEMM)
+__global__ __launch_bounds__(256) void k_split_linear_weights(const float *__restrict__ w, const float *__restrict__ bias, LinearDev l,
+                                                              int transposed) {
     const long long total = (long long)l.N * l.K;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int n = (int)(i / l.K), k = (int)(i - (long long)n * l.K);
+        int n, k;
+        if (transposed) { k = (int)(i / l.N); n = (int)(i - (long long)k * l.N); }     // i walks the source in memory order either way
+        else { n = (int)(i / l.K); k = (int)(i - (long long)n * l.K); }
         const float v = w[i];
         const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
         const size_t base = ((size_t)(k >> 4) * 2 * l.N + n) * 16 + (k & 15);
@@ -48,10 +52,10 @@ __global__ __launch_bounds__(256) void k_split_linear_weights(const float *__res
     for (int n = blockIdx.x * 256 + threadIdx.x; n < l.N; n += gridDim.x * 256) l.bias[n] = bias ? bias[n] : 0.f;
 }
 
-hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st) {
+hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed) {
     const long long total = (long long)l.N * l.K;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_split_linear_weights, dim3(blocks), dim3(256), 0, st, w, bias, l);
+    hipLaunchKernelGGL(k_split_linear_weights, dim3(blocks), dim3(256), 0, st, w, bias, l, transposed);
     return hipGetLastError();
 }
 

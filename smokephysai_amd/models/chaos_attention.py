@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .linear import TrainableHipLinear
+
 
 class ChaosAttention(nn.Module):
     def __init__(self, dim: int, num_heads: int = 8, chaos_strength: float = 0.1, temperature: float = 1.0):
@@ -23,10 +25,10 @@ class ChaosAttention(nn.Module):
         self.chaos_strength = chaos_strength
         self.temperature = temperature
         assert dim % num_heads == 0
-        self.q_proj = nn.Linear(dim, dim)
-        self.k_proj = nn.Linear(dim, dim)
-        self.v_proj = nn.Linear(dim, dim)
-        self.out_proj = nn.Linear(dim, dim)
+        self.q_proj = TrainableHipLinear(dim, dim)
+        self.k_proj = TrainableHipLinear(dim, dim)
+        self.v_proj = TrainableHipLinear(dim, dim)
+        self.out_proj = TrainableHipLinear(dim, dim)
         self.chaos_proj = nn.Linear(3, dim)
         self.chaos_gate = nn.Linear(dim, 1)
         self.register_buffer("lorenz_sigma", torch.tensor(10.0))

@@ -62,6 +62,18 @@ class HipLinear:
     def from_module(cls, lin: nn.Linear) -> "HipLinear":
         return cls(lin.weight, lin.bias)
 
+    def update(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, transposed: bool = False):
+        """Re-split new parameter values into this handle (smk_linear_update; no allocation).  transposed: `weight` is
+        [in_features, out_features] -- the handle then computes ``x @ weight``."""
+        want = (self.in_features, self.out_features) if transposed else (self.out_features, self.in_features)
+        w = weight.detach()
+        if tuple(w.shape) != want or w.dtype != torch.float32 or w.device != self._dev or not w.is_contiguous():
+            raise ValueError(f"HipLinear.update: weight must be contiguous float32 {want} on {self._dev}")
+        b = None if bias is None else bias.detach().to(self._dev, torch.float32).contiguous()
+        _lib.check(self._L.smk_linear_update(self._handle, w.data_ptr(), int(transposed), 0 if b is None else b.data_ptr(),
+                                             _lib.stream_ptr(self._dev)))
+        self._keep = (w, b)                                     # alive until the enqueued split kernel has read them
+
     def close(self):
         if getattr(self, "_handle", None):
             self._L.smk_linear_destroy(self._handle)
@@ -131,3 +143,80 @@ class HipLinear:
                 act, int(x_split), int(out_split), _lib.stream_ptr(self._dev)))
             r0 += n
         return y
+
+
+class _HipLinearFn(torch.autograd.Function):
+    """y = x W^T + b with the forward GEMM and the input-gradient GEMM (dX = dY W) on libsmokehip's split-bf16 kernel; the
+    weight gradient dW = dY^T X is a reduction over the token rows and stays a PyTorch-ROCm fp32 GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod):
+        ctx.mod = mod
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return mod._hip_forward_handle()(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        mod = ctx.mod
+        dx = dw = db = None
+        dy2 = dy.reshape(-1, mod.out_features)
+        if dy2.stride(1) != 1:
+            dy2 = dy2.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = mod._hip_backward_handle()(dy2).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = dy2.t().mm(x.reshape(-1, mod.in_features))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db, None
+
+
+class TrainableHipLinear(nn.Linear):
+    """nn.Linear (same parameters, init and state_dict keys) whose training forward and input gradient run on libsmokehip when
+    `hip_train` is set, the tensors live on a ROCm device and the shape is one the kernel is built for; otherwise F.linear.
+    The two device mirrors of the weight (W for the forward, W^T for dX) are re-split when the parameter changes."""
+
+    hip_train = False
+
+    def __getstate__(self):            # deepcopy / pickling: the device mirrors are per instance, rebuilt on first use
+        d = self.__dict__.copy()
+        for k in ("_hip_fwd", "_hip_bwd", "_hip_fwd_fp", "_hip_bwd_fp"):
+            d.pop(k, None)
+        return d
+
+    def _hip_ok(self, x: torch.Tensor) -> bool:
+        return (self.hip_train and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and (x.requires_grad or self.weight.requires_grad)
+                and hip_linear_supported(self.in_features, self.out_features)
+                and hip_linear_supported(self.out_features, self.in_features))
+
+    def _fingerprint(self):
+        b = self.bias
+        return (self.weight.data_ptr(), self.weight._version, None if b is None else (b.data_ptr(), b._version))
+
+    def _hip_forward_handle(self) -> HipLinear:
+        fp = self._fingerprint()
+        h = self.__dict__.get("_hip_fwd")
+        if h is None:
+            h = self.__dict__["_hip_fwd"] = HipLinear(self.weight, self.bias)
+        elif self.__dict__.get("_hip_fwd_fp") != fp:
+            h.update(self.weight, self.bias)
+        self.__dict__["_hip_fwd_fp"] = fp
+        return h
+
+    def _hip_backward_handle(self) -> HipLinear:
+        fp = (self.weight.data_ptr(), self.weight._version)
+        h = self.__dict__.get("_hip_bwd")
+        if h is None:       # a handle with out = in_features, in = out_features, filled from W read as [in' = out][out' = in]
+            h = self.__dict__["_hip_bwd"] = HipLinear(self.weight.detach().t().contiguous(), None)
+        elif self.__dict__.get("_hip_bwd_fp") != fp:
+            h.update(self.weight, None, transposed=True)
+        self.__dict__["_hip_bwd_fp"] = fp
+        return h
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._hip_ok(x):
+            return _HipLinearFn.apply(x, self.weight, self.bias, self)
+        return nn.functional.linear(x, self.weight, self.bias)

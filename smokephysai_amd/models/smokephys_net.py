@@ -21,7 +21,7 @@ from .chaos_attention import ChaosAttention
 from .decoder import HipDecoder, decoder_weight_dict, hip_decoder_supported
 from .encoder import HipEncoder, encoder_weight_dict
 from .hip_body import HipBody
-from .linear import hip_linear_supported
+from .linear import TrainableHipLinear, hip_linear_supported
 from .physics_regularizer import PhysicsRegularizer
 
 
@@ -35,8 +35,8 @@ def _upsample_block(cin: int, cout: int):
     return [nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
 
 
-def _mlp(din: int, dhid: int, dout: int) -> nn.Sequential:
-    return nn.Sequential(nn.Linear(din, dhid), nn.ReLU(inplace=True), nn.Linear(dhid, dout))
+def _mlp(din: int, dhid: int, dout: int, linear=nn.Linear) -> nn.Sequential:
+    return nn.Sequential(linear(din, dhid), nn.ReLU(inplace=True), linear(dhid, dout))
 
 
 class SmokePhysNet(nn.Module):
@@ -56,10 +56,10 @@ class SmokePhysNet(nn.Module):
         self.input_encoder = nn.Sequential(*_conv_block(1, 64, 7), *_conv_block(64, 128, 3),
                                            nn.AdaptiveAvgPool2d((input_dim, input_dim)))
         self.pos_embedding = nn.Parameter(torch.randn(1, input_dim * input_dim, hidden_dim))
-        self.feature_proj = nn.Linear(128, hidden_dim)
+        self.feature_proj = TrainableHipLinear(128, hidden_dim)
         self.chaos_layers = nn.ModuleList(
             ChaosTransformerLayer(hidden_dim, num_heads, chaos_strength=chaos_strength) for _ in range(num_layers))
-        self.output_decoder = _mlp(hidden_dim, 256, output_channels)
+        self.output_decoder = _mlp(hidden_dim, 256, output_channels, linear=TrainableHipLinear)
         self.reconstruction_head = nn.Sequential(*_upsample_block(output_channels, 32), *_upsample_block(32, 16),
                                                  nn.Conv2d(16, 1, 3, padding=1), nn.Sigmoid())
         self.physics_head = _mlp(hidden_dim, 256, 3)
@@ -68,6 +68,21 @@ class SmokePhysNet(nn.Module):
         self._pos_cache = None    # (fingerprint, tensor)
         self._hip_body = HipBody()   # libsmokehip mirrors of the token-wise linear layers + per-layer scratch
         self._hip_dec = None         # (HipDecoder, weight fingerprint)
+        # training: the token-wise linear layers run their forward and input-gradient GEMMs on libsmokehip as well (models/linear.py)
+        for m in self.modules():
+            if isinstance(m, TrainableHipLinear):
+                m.hip_train = linear_dtype == "bf16x3"
+
+    # copy.deepcopy / pickling of the module: the libsmokehip handles are per-instance device mirrors, rebuilt on first use
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.update(_hip=None, _pos_cache=None, _hip_body=None, _hip_dec=None)
+        return d
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if self.__dict__.get("_hip_body") is None:
+            self._hip_body = HipBody()
 
     # ---- HIP encoder plumbing -------------------------------------------------------------------------------
     def _encoder_fingerprint(self):
@@ -194,7 +209,7 @@ class ChaosTransformerLayer(nn.Module):
         self.chaos_attention = ChaosAttention(dim, num_heads, chaos_strength)
         self.norm1 = nn.LayerNorm(dim)
         self.norm2 = nn.LayerNorm(dim)
-        self.ffn = nn.Sequential(nn.Linear(dim, 4 * dim), nn.GELU(), nn.Dropout(dropout), nn.Linear(4 * dim, dim),
+        self.ffn = nn.Sequential(TrainableHipLinear(dim, 4 * dim), nn.GELU(), nn.Dropout(dropout), TrainableHipLinear(4 * dim, dim),
                                  nn.Dropout(dropout))
 
     def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:

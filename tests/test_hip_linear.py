@@ -108,3 +108,49 @@ def test_linear_split_bf16_input_and_output_formats():
         assert rel_err(from_split(both).cpu().numpy(), from_split(ys).cpu().numpy()) < 2.0 ** -15      # two decodes of the format
         res = torch.randn(B, L, N, device="cuda", generator=g)
         assert rel_err(lin(xs, residual=res, x_split=True).cpu().numpy(), lin(x, residual=res).cpu().numpy()) < 1e-6
+
+
+# ---------------------------------------------------------------- training: forward + input gradient on the HIP kernel
+@pytest.mark.parametrize("M,K,N", [(4096, 512, 512), (2048, 512, 2048), (2048, 2048, 512), (1024, 128, 512), (512, 256, 64)])
+def test_trainable_linear_forward_and_gradients_match_fp64(M, K, N):
+    """nn.Linear's autograd contract (y, dX = dY W, dW = dY^T X, db = sum dY) with y and dX on smk_linear_forward; after an
+    in-place parameter update (an optimizer step) both device mirrors are re-split (smk_linear_update)."""
+    from smokephysai_amd.models.linear import TrainableHipLinear
+    torch.manual_seed(M + K + N)
+    lin = TrainableHipLinear(K, N).cuda()
+    lin.hip_train = True
+    for rnd in range(2):
+        x = torch.randn(2, M // 2, K, device="cuda", requires_grad=True)
+        dy = torch.randn(2, M // 2, N, device="cuda")
+        y = lin(x)
+        assert y.grad_fn is not None and "HipLinearFn" in type(y.grad_fn).__name__
+        y.backward(dy)
+        xd = x.detach().double().requires_grad_(True)
+        wd = lin.weight.detach().double().requires_grad_(True)
+        bd = lin.bias.detach().double().requires_grad_(True)
+        yd = torch.nn.functional.linear(xd, wd, bd)
+        yd.backward(dy.double())
+        def err(a, b):
+            return rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+        assert err(y, yd) < TOL and err(x.grad, xd.grad) < TOL
+        assert err(lin.weight.grad, wd.grad) < TOL and err(lin.bias.grad, bd.grad) < TOL
+        assert err(y, yd) < 2e-5 and err(x.grad, xd.grad) < 2e-5        # measured ~1e-6
+        with torch.no_grad():                                                     # "optimizer step": bumps the parameter versions
+            lin.weight.add_(0.05 * torch.randn_like(lin.weight))
+            lin.bias.mul_(0.5)
+        lin.zero_grad()
+
+
+def test_trainable_linear_falls_back_to_f_linear_when_not_applicable():
+    from smokephysai_amd.models.linear import TrainableHipLinear
+    lin = TrainableHipLinear(3, 512).cuda()            # chaos_proj-like shape: not a kernel shape
+    lin.hip_train = True
+    x = torch.randn(8, 3, device="cuda", requires_grad=True)
+    assert "HipLinearFn" not in type(lin(x).grad_fn).__name__
+    lin2 = TrainableHipLinear(512, 512).cuda()
+    lin2.hip_train = True
+    with torch.no_grad():
+        y = lin2(torch.randn(64, 512, device="cuda"))
+    assert y.grad_fn is None
+    lin2.hip_train = False
+    assert "HipLinearFn" not in type(lin2(x.new_zeros(4, 512).requires_grad_()).grad_fn).__name__

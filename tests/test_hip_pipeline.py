@@ -146,6 +146,84 @@ def test_train_step_runs_and_updates(golden):
     assert abs(float(recon) - g["losses"][1]) / g["losses"][1] < 1e-2    # dropout active: loose
 
 
+def _grads(mod, loss_fn):
+    mod.zero_grad()
+    loss_fn(mod).backward()
+    return {k: p.grad.detach().double().cpu() for k, p in mod.named_parameters() if p.grad is not None}
+
+
+def _max_rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+def test_training_gradients_with_hip_linears(golden):
+    """Training with the token-wise linears on libsmokehip (forward + input-gradient GEMM), checked against fp64 autograd.
+
+    (1) Transformer body alone, a well-conditioned loss: every parameter gradient within 1e-4 (max-norm) of fp64.
+    (2) train.py's full loss on the fixture batch (train-mode BatchNorm over a batch of 2 under a mass-conservation term of
+        ~1e6: the exact gradient is the small remainder of large cancelling terms, and PyTorch's own fp32 run is 1e-3..1e-2
+        away from fp64): the HIP route must stay inside that same band."""
+    import copy
+    import train
+    from smokephysai_amd.models.linear import TrainableHipLinear
+    g = golden("train_batch.npz")
+    model = SmokePhysNet(input_dim=32, hidden_dim=64, num_layers=2, num_heads=4, output_channels=16)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w::")})
+    model = model.cuda().train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    m64 = copy.deepcopy(model).double()
+
+    def set_hip(mod, on):
+        for m in mod.modules():
+            if isinstance(m, TrainableHipLinear):
+                m.hip_train = on
+    set_hip(m64, False)
+    gen = torch.Generator().manual_seed(5)
+    noise = torch.randn(2, 3, 2, 1, generator=gen).cuda()
+
+    # (1) body only
+    x = torch.randn(2, 1024, 64, generator=gen).cuda()
+    r = torch.randn(2, 1024, 64, generator=gen).cuda()
+
+    def body_loss(mod):
+        dt = next(mod.parameters()).dtype
+        h = x.to(dt)
+        for i, layer in enumerate(mod.chaos_layers):
+            h = layer(h, noise=noise[i].to(dt))
+        return (h * r.to(dt)).sum()
+    ref = _grads(m64, body_loss)
+    set_hip(model, True)
+    got = _grads(model, body_loss)
+    assert sum("_hip_fwd" in m.__dict__ for m in model.modules() if isinstance(m, TrainableHipLinear)) >= 12
+    assert got.keys() == ref.keys() and len(got) > 20
+    scale = max(float(v.abs().max()) for v in ref.values())
+    for k in ref:
+        if float(ref[k].abs().max()) > 1e-9 * scale:          # k_proj.bias: softmax is invariant to a key bias, gradient 0
+            assert _max_rel(got[k], ref[k]) < 1e-4, (k, _max_rel(got[k], ref[k]))
+        else:
+            assert float(got[k].abs().max()) < 1e-5 * scale, k
+
+    # (2) the full training loss
+    batch = {"input": torch.from_numpy(g["inputs"]), "target": torch.from_numpy(g["targets"]),
+             "chaos_features": torch.from_numpy(g["chaos_targets"]), "sequence": torch.zeros(2, 20, 128, 128)}
+    b64 = {k: v.double() for k, v in batch.items()}
+
+    def full_loss(b, nz):
+        return lambda mod: train.batch_losses(mod, mod.physics_regularizer, b, "cuda", chaos_noise=nz)[0]
+    ref = _grads(m64, full_loss(b64, noise.double()))
+    got = _grads(model, full_loss(batch, noise))
+    set_hip(model, False)
+    f32 = _grads(model, full_loss(batch, noise))
+    scale = max(float(v.abs().max()) for v in ref.values())
+    live = [k for k, v in ref.items() if float(v.abs().max()) > 1e-9 * scale]     # biases in front of a BatchNorm have gradient 0
+    worst_f32 = max(_max_rel(f32[k], ref[k]) for k in live)
+    worst_hip = max(_max_rel(got[k], ref[k]) for k in live)
+    assert 1e-4 < worst_f32 < 5e-2          # the conditioning claim above
+    assert worst_hip < max(2.0 * worst_f32, 1e-2), (worst_hip, worst_f32)
+
+
 def test_train_losses_at_256_pool_the_target():
     """BASELINE config 4 trains on 256^2 grids; the head emits 128^2 (the reference's loss raises there): the target is
     block-averaged to the head's resolution."""

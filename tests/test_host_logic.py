@@ -125,6 +125,23 @@ def test_full_model_init_matches_reference_checksums(golden):
         np.testing.assert_allclose(got, cs, rtol=1e-12, atol=1e-9, err_msg=k)
 
 
+def test_model_deepcopy_drops_the_device_mirrors():
+    """copy.deepcopy / pickling must not share (or try to pickle) libsmokehip handles: the copy rebuilds them on first use."""
+    import copy
+    import pickle
+    from smokephysai_amd.models.linear import TrainableHipLinear
+    model = SmokePhysNet(input_dim=32, hidden_dim=64, num_layers=1, num_heads=4)
+    clone = pickle.loads(pickle.dumps(copy.deepcopy(model)))
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), clone.state_dict().values()))
+    assert list(model.state_dict()) == list(clone.state_dict())
+    assert clone._hip is None and clone._hip_dec is None and clone._hip_body is not model._hip_body
+    lin = clone.chaos_layers[0].ffn[0]
+    assert isinstance(lin, TrainableHipLinear) and lin.hip_train and "_hip_fwd" not in lin.__dict__
+    # on CPU tensors the trainable linear is plain F.linear (the HIP route needs a ROCm device)
+    x = torch.randn(3, 64)
+    assert torch.equal(lin(x), torch.nn.functional.linear(x, lin.weight, lin.bias))
+
+
 # ---------------------------------------------------------------- N>1: DDP gradient step on 2 gloo ranks
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
