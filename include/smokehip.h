@@ -191,6 +191,16 @@ int smk_linear_destroy(smk_linear *lin);
  * same kernel.  bias NULL = zeros.  Read once, on `stream`. */
 int smk_linear_update(smk_linear *lin, const float *weight, int32_t transposed, const float *bias, void *stream);
 
+/* Weight gradient of nn.Linear, dW [out_features][in_features] = dY^T X (autograd's LinearBackward0; train.py:89 `total.backward()`),
+ * on the same split-bf16 kernel: dy [rows][out_features] (row pitch ld_dy floats), x [rows][in_features] (row pitch ldx), dw dense.
+ * The reduction runs over the token rows, cut into segments that share one launch; the partial sums are added in segment order
+ * (deterministic).  `workspace`: smk_linear_wgrad_workspace(rows, out, in) bytes of device memory, 16-byte aligned, owned by the
+ * caller and free for reuse once the enqueued work has run.  Requires in_features % 32 == 0, out_features % 4 == 0,
+ * (out_features + 256) * (rows + 4096) < 2^30 (longer inputs: call per row chunk and add).  Enqueued on `stream`. */
+int64_t smk_linear_wgrad_workspace(int64_t rows, int32_t out_features, int32_t in_features);
+int smk_linear_wgrad(const float *dy, int64_t ld_dy, const float *x, int64_t ldx, int64_t rows, int32_t out_features,
+                     int32_t in_features, float *dw, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* y = act(x W^T + b + addend) + residual over `rows` token rows:
  *   x [rows][in_features], row pitch ldx floats; y [rows][out_features], row pitch ldy (all row starts 16-byte aligned);
  *   residual (or NULL) [rows][out_features], row pitch ldr -- the `x + sublayer(x)` of the pre-LN block

@@ -77,10 +77,12 @@ _SIGNATURES = {
     "smk_linear_create": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
     "smk_linear_destroy": [C.c_void_p],
     "smk_linear_update": [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p],
+    "smk_linear_wgrad": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                         C.c_int64, C.c_void_p],
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
-EXPORTS = ["smk_abi_version", "smk_last_error"] + list(_SIGNATURES)
+EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace"] + list(_SIGNATURES)
 
 _lib = None
 
@@ -100,6 +102,8 @@ def load():
         L = C.CDLL(LIB_PATH)
         L.smk_abi_version.restype = C.c_int
         L.smk_last_error.restype = C.c_char_p
+        L.smk_linear_wgrad_workspace.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        L.smk_linear_wgrad_workspace.restype = C.c_int64          # a byte count, not a status
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -531,6 +531,27 @@ int smk_linear_update(smk_linear *lin, const float *weight, int32_t transposed, 
     return check_launch(launch_split_linear_weights(weight, bias, lin->l, (hipStream_t)stream, transposed), "split_linear_weights");
 }
 
+int64_t smk_linear_wgrad_workspace(int64_t rows, int32_t out_features, int32_t in_features) {
+    if (rows < 1 || out_features < 1 || in_features < 1) return 0;
+    return (int64_t)plan_linear_wgrad(rows, out_features, in_features).bytes;
+}
+
+int smk_linear_wgrad(const float *dy, int64_t ld_dy, const float *x, int64_t ldx, int64_t rows, int32_t out_features,
+                     int32_t in_features, float *dw, void *workspace, int64_t workspace_bytes, void *stream) {
+    SMK_REQUIRE(dy && x && dw && workspace, "null dy/x/dw/workspace");
+    SMK_REQUIRE(rows >= 1 && out_features >= 1 && in_features >= 1, "positive sizes");
+    if (in_features % 32 != 0 || out_features % 4 != 0) {
+        set_error("linear_wgrad: HIP path is built for in_features % 32 == 0, out_features % 4 == 0");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    SMK_REQUIRE(ld_dy >= out_features && ldx >= in_features, "row pitches >= feature counts");
+    SMK_REQUIRE((int64_t)(out_features + 256) * (rows + 4096) < (1LL << 30), "(out_features + 256) * (rows + 4096) < 2^30: chunk the rows");
+    SMK_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dw & 15) == 0, "workspace / dw 16-byte aligned");
+    SMK_REQUIRE(workspace_bytes >= smk_linear_wgrad_workspace(rows, out_features, in_features), "workspace too small");
+    return check_launch(launch_linear_wgrad(dy, ld_dy, x, ldx, rows, out_features, in_features, dw, workspace, (hipStream_t)stream),
+                        "linear_wgrad");
+}
+
 int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx, void *y, int64_t ldy,
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream) {

@@ -19,9 +19,20 @@ struct LinearCall {
     int M;
     int act;                              // 0 none, 1 GELU (erf form), 2 ReLU
     int x_split, y_split;                 // SMK_FMT_SPLIT_BF16 on the input / output side (rows dense: ldx = K, ldy = N)
+    // K-segmented form (weight gradients: a reduction over 65,536 token rows with only a handful of output tiles): nseg independent
+    // problems y[s] = x[:, s*K:(s+1)*K] w[:, s*K:(s+1)*K]^T share one launch; l.K is the SEGMENT length, the weights hold nseg*K
+    // k in one layout, y is nseg dense [M][N] slabs.  nseg = 1: the plain layer.
+    int nseg = 1;
 };
 
-hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed = 0);
+hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed = 0,
+                                       long long ld = 0, int k_valid = -1);
 hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t st);
+
+// dW = dY^T X (linear.hip): workspace layout and segment count for a problem size
+struct WgradPlan { int nseg; long long rows_pad; size_t off_wq, off_part, bytes; };
+WgradPlan plan_linear_wgrad(long long rows, int out_features, int in_features);
+hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x, long long ldx, long long rows, int out_features,
+                               int in_features, float *dw, void *workspace, hipStream_t st);
 
 }  // namespace smk

@@ -35,27 +35,64 @@ constexpr int LN_RING = 4;         // B fragments in flight: 3 k-steps ahead; 4 
 template <int MB> constexpr int ln_plane_bytes() { return MB * 32 * LN_PITCH; }
 template <int MB, int NW> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 1024; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
 
-// transposed: `w` is [K][N] row-major (the handle then computes x W for a layer whose weight is W [K][N]: its input-gradient GEMM)
+// transposed: `w` is [K][N] row-major (the handle then computes x W for a layer whose weight is W [K][N]: its input-gradient GEMM).
+// ld: source row pitch in floats; k_valid: k >= k_valid reads as zero (the weight-gradient form pads the token rows to whole segments).
 __global__ __launch_bounds__(256) void k_split_linear_weights(const float *__restrict__ w, const float *__restrict__ bias, LinearDev l,
-                                                              int transposed) {
+                                                              int transposed, long long ld, int k_valid) {
     const long long total = (long long)l.N * l.K;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         int n, k;
         if (transposed) { k = (int)(i / l.N); n = (int)(i - (long long)k * l.N); }     // i walks the source in memory order either way
         else { n = (int)(i / l.K); k = (int)(i - (long long)n * l.K); }
-        const float v = w[i];
+        const float v = k < k_valid ? (transposed ? w[(long long)k * ld + n] : w[(long long)n * ld + k]) : 0.f;
         const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
         const size_t base = ((size_t)(k >> 4) * 2 * l.N + n) * 16 + (k & 15);
         l.wq[base] = __builtin_bit_cast(unsigned short, hi);
         l.wq[base + (size_t)l.N * 16] = __builtin_bit_cast(unsigned short, lo);
     }
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < l.N; n += gridDim.x * 256) l.bias[n] = bias ? bias[n] : 0.f;
+    if (l.bias)
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < l.N; n += gridDim.x * 256) l.bias[n] = bias ? bias[n] : 0.f;
 }
 
-hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed) {
+// The transposed form at weight-gradient sizes (the "weights" are the 65,536 x in_features activations): thread = (16-k block, n);
+// 16 loads that are coalesced across the wave (consecutive n) and two 32-byte stores that tile the fragment planes contiguously.
+__global__ __launch_bounds__(256) void k_split_linear_weights_t16(const float *__restrict__ w, LinearDev l, long long ld, int k_valid) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= l.N) return;
+    for (int kb = blockIdx.x; kb < l.K / 16; kb += gridDim.x) {
+        unsigned short hi[16], lo[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = kb * 16 + j;
+            const float v = k < k_valid ? w[(long long)k * ld + n] : 0.f;
+            const __bf16 h = (__bf16)v;
+            hi[j] = __builtin_bit_cast(unsigned short, h);
+            lo[j] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+        }
+        uint4 *dh = reinterpret_cast<uint4 *>(l.wq + ((size_t)kb * 2 * l.N + n) * 16);
+        uint4 *dl = reinterpret_cast<uint4 *>(l.wq + ((size_t)kb * 2 * l.N + l.N + n) * 16);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            dh[q] = make_uint4(hi[8 * q] | (unsigned)hi[8 * q + 1] << 16, hi[8 * q + 2] | (unsigned)hi[8 * q + 3] << 16,
+                               hi[8 * q + 4] | (unsigned)hi[8 * q + 5] << 16, hi[8 * q + 6] | (unsigned)hi[8 * q + 7] << 16);
+            dl[q] = make_uint4(lo[8 * q] | (unsigned)lo[8 * q + 1] << 16, lo[8 * q + 2] | (unsigned)lo[8 * q + 3] << 16,
+                               lo[8 * q + 4] | (unsigned)lo[8 * q + 5] << 16, lo[8 * q + 6] | (unsigned)lo[8 * q + 7] << 16);
+        }
+    }
+}
+
+hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed,
+                                       long long ld, int k_valid) {
+    if (ld <= 0) ld = transposed ? l.N : l.K;
+    if (k_valid < 0) k_valid = l.K;
+    if (transposed && !l.bias && l.K % 16 == 0 && (long long)l.N * l.K >= (1 << 20)) {
+        const int kblocks = l.K / 16;
+        hipLaunchKernelGGL(k_split_linear_weights_t16, dim3(kblocks < 4096 ? kblocks : 4096, cdiv(l.N, 256)), dim3(256), 0, st, w, l, ld, k_valid);
+        return hipGetLastError();
+    }
     const long long total = (long long)l.N * l.K;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_split_linear_weights, dim3(blocks), dim3(256), 0, st, w, bias, l, transposed);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_split_linear_weights, dim3(blocks), dim3(256), 0, st, w, bias, l, transposed, ld, k_valid);
     return hipGetLastError();
 }
 
@@ -115,9 +152,13 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     // Workgroups are dealt to the 8 XCDs round-robin (id % 8).  vid renumbers them so that one XCD holds a contiguous id range:
     // the tiles_n workgroups that share a row block (the same A rows) then run on ONE XCD at the same time and A is fetched
     // from HBM once (L2 hits for the others) instead of once per XCD.  (gridDim.x % (8 * tiles_n) == 0 or swz == 0.)
-    const int vid = a.swz ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const int tn = vid % a.tiles_n;                          // fixed for the life of the workgroup (gridDim.x % tiles_n == 0)
-    const int tm_step = gridDim.x / a.tiles_n;
+    const int vid0 = a.swz ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    // K-segmented launches (LinearCall::nseg > 1): a contiguous id range per segment; the segment only offsets the three base pointers
+    const int wg_per_seg = (int)gridDim.x / a.c.nseg;
+    const int seg = a.c.nseg > 1 ? vid0 / wg_per_seg : 0;
+    const int vid = vid0 - seg * wg_per_seg;
+    const int tn = vid % a.tiles_n;                          // fixed for the life of the workgroup (wg_per_seg % tiles_n == 0)
+    const int tm_step = wg_per_seg / a.tiles_n;
     int tm = vid / a.tiles_n;
     // Two workgroups share a CU and run the same program with the same period: delay every other dispatch round by about
     // half a tile so that one's epilogue / staging stalls overlap the other's MFMA stretch (speed only).
@@ -128,13 +169,14 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
         const int ph = (blockIdx.x >> 3) % a.stagger;          // same XCD, consecutive CUs -> different phases
         for (int i = 0; i < ph * a.stagger_unit; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    float *const y_seg = a.c.y + (size_t)seg * M * a.c.ldy;   // segment s writes its own dense [M][N] slab
     const int n = tn * TN + wave * 32 + r;                  // this lane's output column
     const bool n_ok = n < N;
 
     // ---- B ring: 16 bytes per lane at a per-lane constant offset from a wave-uniform (scalar) fragment base
     const int lane_b = n_ok ? (n * 2 + hi) * 16 : 0;
     const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.l.wq), 0, K * N * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.l.wq) + (size_t)seg * K * N * 2, 0, K * N * 4, 0x00020000);
     const int frag_bytes = N * 32;                           // one (k-step, part) plane
     auto load_b = [&](int kn, int part) -> uint4 {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, ((LN_DBG(a, 2) ? 0 : kn + k_off) * 2 + part) * frag_bytes, 0);
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     // split the k-step into basic blocks and undo the MFMA / staging interleave below).  One v_add per load: the offset
     // must sit in the VGPR operand to be range-checked.
     const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.c.x), 0, (int)(((long long)(M - 1) * a.c.ldx + K) * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.c.x) + (size_t)seg * K, 0, (int)(((long long)(M - 1) * a.c.ldx + K) * 4), 0x00020000);
     const int ldxb = (int)a.c.ldx * 4;                       // row bytes (split rows are dense: ldx = K)
     const int lane_x = sr * ldxb + sc * (AS ? 32 : 16);
     auto stage_load = [&](int tmx, int cx, int j) {
@@ -227,7 +269,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     load_a(0, 0, ahA, alA);
     const bool nw_ok = tn * TN + wave * 32 < N;
     float *bias_s = reinterpret_cast<float *>(smem + 4 * PLANE);       // this workgroup's 128 bias values
-    if (tid < TN) bias_s[tid] = tn * TN + tid < N ? a.l.bias[tn * TN + tid] : 0.f;   // visible after the first barrier below             // N % 32 == 0: a wave's 32 columns are all inside or all outside
+    if (tid < TN) bias_s[tid] = (a.l.bias && tn * TN + tid < N) ? a.l.bias[tn * TN + tid] : 0.f;   // visible after the first barrier below             // N % 32 == 0: a wave's 32 columns are all inside or all outside
 
 #ifdef SMK_LN_STAMPS
     unsigned long long sum_k = 0, sum_e = 0, ntl = 0, sum_u[5] = {0, 0, 0, 0, 0}, t_prev = 0;
@@ -409,7 +451,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                     *reinterpret_cast<bf16x4 *>(ys) = vh;
                     *reinterpret_cast<bf16x4 *>(ys + 8) = vl;
                 } else {
-                    *reinterpret_cast<float4 *>(a.c.y + (long long)row * a.c.ldy + ncol + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4 *>(y_seg + (long long)row * a.c.ldy + ncol + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             };
             if (!any_ex) {
@@ -468,11 +510,13 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    const int nwg_max = (NW == 8 || KS > 1 ? 1 : 2) * a.num_cu;     // 8 waves per CU either way (split-K: one workgroup per CU)
+    const int nseg = a.c.nseg;
+    const int nwg_max = (NW == 8 || KS > 1 ? 1 : 2) * a.num_cu / nseg;     // 8 waves per CU either way (split-K: one workgroup per CU)
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
     long long nwg = tiles < nwg_max ? tiles : nwg_max;
     nwg -= nwg % a.tiles_n;                               // every workgroup keeps one column tile
     if (nwg < a.tiles_n) nwg = a.tiles_n;
+    nwg *= nseg;                                          // per segment: the same walk over its own [M][N] slab
     LinearArgs b = a;
     static int swz_env = -1, stg_env = -1;
     if (swz_env < 0) { const char *s = getenv("SMK_LINEAR_SWZ"); swz_env = s ? atoi(s) : 1; }
@@ -513,13 +557,13 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     a.swz = 0;
     a.stagger = 0;
     a.stamps = nullptr;
-    int nw = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) >= num_cu) ? 8 : 4;
+    int nw = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) * c.nseg >= num_cu) ? 8 : 4;
     if (force_nw == 4 || force_nw == 8) nw = force_nw;
     a.tiles_n = cdiv(l.N, nw * 32);
     // row-block count per tile: the largest that still gives every CU its share of workgroups (small M: finer tiles)
     const long long want = (nw == 8 ? 1LL : 2LL) * num_cu;
     int mb = 4;
-    while (mb > 1 && (long long)cdiv(c.M, 32 * mb) * a.tiles_n < want) mb >>= 1;
+    while (mb > 1 && (long long)cdiv(c.M, 32 * mb) * a.tiles_n * c.nseg < want) mb >>= 1;
     if (force_mb == 1 || force_mb == 2 || force_mb == 4) mb = force_mb;
     if (nw == 8) mb = 4;                                   // the 8-wave form is built for full 128-row tiles only
     while (c.padd && mb > 1 && c.rows_per_group % (32 * mb) != 0) mb >>= 1;
@@ -551,7 +595,7 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
             int ks = 1;
             // measured at M = 1024: 2048 -> 512 (128 tiles, 32 chunks) 24.4 -> 19.3 us with 4 groups; neutral at 8 chunks; with
             // 512 tiles already on the chip a split only adds the merge (+15 %)
-            if (tiles <= num_cu / 2 && nch % 4 == 0 && nch >= 16) ks = 4;
+            if (tiles * c.nseg <= num_cu / 2 && nch % 4 == 0 && nch >= 16) ks = 4;
             if (force_ks == 1 || ((force_ks == 2 || force_ks == 4) && nch % force_ks == 0 && nch / force_ks >= 1)) ks = force_ks;
             if (ks == 4) e = launch_mb<1, 4, false, 4>(a, st);
             else if (ks == 2) e = launch_mb<1, 4, false, 2>(a, st);
@@ -573,6 +617,84 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     }
 #endif
     return e;
+}
+
+// ---- weight gradient of a linear layer: dW [out][in] = dY^T X, a reduction over the token rows (autograd's LinearBackward0, third
+// GEMM).  On the layer kernel it is "x' = dY^T [out][rows], w' = X^T [in][rows]": dY is transposed (zero-padded to whole segments) and
+// X is split straight into the weight layout with its k index = the token row; the row range is cut into nseg K-segments that run as
+// one launch (LinearCall::nseg) and the nseg partial [out][in] slabs are added in segment order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void k_transpose_pad(const float *__restrict__ src, long long ld, int rows, int cols, float *__restrict__ dst,
+                                                       int rows_pad) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                 // 32 x 8
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        tile[ty + 8 * j][tx] = (r < rows && c < cols) ? src[(long long)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;
+        if (c < cols && r < rows_pad) dst[(long long)c * rows_pad + r] = tile[tx][ty + 8 * j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sum_segments(const float *__restrict__ part, int nseg, long long n4, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 acc = reinterpret_cast<const float4 *>(part)[i];
+        for (int s = 1; s < nseg; ++s) {
+            const float4 v = reinterpret_cast<const float4 *>(part)[(long long)s * n4 + i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = acc;
+    }
+}
+
+WgradPlan plan_linear_wgrad(long long rows, int out_f, int in_f) {
+    WgradPlan p;
+    const long long tiles = (long long)cdiv(out_f, 128) * cdiv(in_f, 128);
+    int nseg = 1;
+    while (nseg < 64 && tiles * nseg < 512 && rows / (2 * nseg) >= 1024) nseg *= 2;     // fill ~512 workgroup slots; segments of >= 1024 rows
+    p.nseg = nseg;
+    const long long unit = 64LL * nseg;
+    p.rows_pad = (rows + unit - 1) / unit * unit;
+    p.off_wq = (size_t)out_f * p.rows_pad * sizeof(float);                                // after dY^T
+    p.off_part = p.off_wq + (size_t)p.rows_pad * in_f * 2 * sizeof(unsigned short);
+    p.bytes = p.off_part + (nseg > 1 ? (size_t)nseg * out_f * in_f * sizeof(float) : 0);
+    return p;
+}
+
+hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x, long long ldx, long long rows, int out_f, int in_f,
+                               float *dw, void *workspace, hipStream_t st) {
+    const WgradPlan p = plan_linear_wgrad(rows, out_f, in_f);
+    float *dyt = reinterpret_cast<float *>(workspace);
+    LinearDev l;
+    l.wq = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(workspace) + p.off_wq);
+    l.bias = nullptr;
+    l.N = in_f;
+    l.K = (int)p.rows_pad;
+    float *part = p.nseg > 1 ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(workspace) + p.off_part) : dw;
+    hipLaunchKernelGGL(k_transpose_pad, dim3((unsigned)(p.rows_pad / 32), cdiv(out_f, 32)), dim3(256), 0, st, dy, ld_dy, (int)rows, out_f, dyt,
+                       (int)p.rows_pad);
+    hipError_t e = launch_split_linear_weights(x, nullptr, l, st, 1, ldx, (int)rows);
+    if (e != hipSuccess) return e;
+    l.K = (int)(p.rows_pad / p.nseg);                       // segment length
+    LinearCall c;
+    c.x = dyt; c.ldx = p.rows_pad;
+    c.y = part; c.ldy = in_f;
+    c.res = nullptr; c.ldr = 0; c.padd = nullptr; c.rows_per_group = 1; c.period = 1;
+    c.M = out_f; c.act = 0; c.x_split = 0; c.y_split = 0;
+    c.nseg = p.nseg;
+    e = launch_linear_x3(l, c, st);
+    if (e != hipSuccess) return e;
+    if (p.nseg > 1) {
+        const long long n4 = (long long)out_f * in_f / 4;
+        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_sum_segments, dim3(blocks), dim3(256), 0, st, part, p.nseg, n4, dw);
+    }
+    return hipGetLastError();
 }
 
 }  // namespace smk

@@ -145,9 +145,44 @@ class HipLinear:
         return y
 
 
+def hip_linear_wgrad_supported(in_features: int, out_features: int) -> bool:
+    return in_features % 32 == 0 and out_features % 4 == 0
+
+
+MAX_WGRAD_ROWS = 1 << 17     # rows per smk_linear_wgrad call ((out + 256) * (rows + 4096) < 2^30 holds up to out = 7,680); more: chunk + add
+
+
+def hip_linear_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW [out, in] = dy^T x over the token rows (dy [rows, out], x [rows, in], fp32 on one ROCm device) -- smk_linear_wgrad."""
+    dev = _lib.require_cuda(dy.device, "hip_linear_wgrad")
+    L = _lib.load()
+    if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0] or dy.dtype != torch.float32 or x.dtype != torch.float32 or x.device != dev:
+        raise ValueError("hip_linear_wgrad: dy [rows, out] and x [rows, in] float32 on the same device")
+    if dy.stride(1) != 1:
+        dy = dy.contiguous()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, out_f, in_f = dy.shape[0], dy.shape[1], x.shape[1]
+    dw = torch.empty(out_f, in_f, device=dev, dtype=torch.float32)
+    total = None
+    r0 = 0
+    while r0 < rows:
+        n = min(MAX_WGRAD_ROWS, rows - r0)
+        nbytes = int(L.smk_linear_wgrad_workspace(n, out_f, in_f))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)      # torch's caching allocator: stream-ordered reuse
+        tgt = dw if r0 == 0 else torch.empty_like(dw)
+        _lib.check(L.smk_linear_wgrad(dy[r0:].data_ptr(), dy.stride(0), x[r0:].data_ptr(), x.stride(0), n, out_f, in_f,
+                                      tgt.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr(dev)))
+        if r0:
+            dw += tgt
+        r0 += n
+    return dw
+
+
 class _HipLinearFn(torch.autograd.Function):
-    """y = x W^T + b with the forward GEMM and the input-gradient GEMM (dX = dY W) on libsmokehip's split-bf16 kernel; the
-    weight gradient dW = dY^T X is a reduction over the token rows and stays a PyTorch-ROCm fp32 GEMM."""
+    """y = x W^T + b with all three GEMMs of the layer on libsmokehip's split-bf16 kernel: the forward, the input gradient
+    dX = dY W (a handle filled from W read transposed) and the weight gradient dW = dY^T X (smk_linear_wgrad: the reduction over
+    the token rows as K-segments of one launch)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, mod):
@@ -167,7 +202,11 @@ class _HipLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = mod._hip_backward_handle()(dy2).view(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = dy2.t().mm(x.reshape(-1, mod.in_features))
+            x2 = x.reshape(-1, mod.in_features)
+            if mod.hip_wgrad and hip_linear_wgrad_supported(mod.in_features, mod.out_features):
+                dw = hip_linear_wgrad(dy2, x2)
+            else:
+                dw = dy2.t().mm(x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(0)
         return dx, dw, db, None
@@ -179,6 +218,7 @@ class TrainableHipLinear(nn.Linear):
     The two device mirrors of the weight (W for the forward, W^T for dX) are re-split when the parameter changes."""
 
     hip_train = False
+    hip_wgrad = True         # dW on libsmokehip too (False: PyTorch-ROCm fp32 GEMM for the weight gradient only)
 
     def __getstate__(self):            # deepcopy / pickling: the device mirrors are per instance, rebuilt on first use
         d = self.__dict__.copy()

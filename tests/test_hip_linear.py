@@ -154,3 +154,32 @@ def test_trainable_linear_falls_back_to_f_linear_when_not_applicable():
     assert y.grad_fn is None
     lin2.hip_train = False
     assert "HipLinearFn" not in type(lin2(x.new_zeros(4, 512).requires_grad_()).grad_fn).__name__
+
+
+@pytest.mark.parametrize("rows,out_f,in_f", [(65536, 512, 512), (8192, 2048, 512), (8192, 512, 2048), (1000, 64, 256),
+                                             (70001, 256, 128), (300, 36, 32)])
+def test_weight_gradient_matches_fp64(rows, out_f, in_f):
+    """smk_linear_wgrad: dW = dY^T X over the token rows (K-segmented launch + ordered partial sum), ragged row counts, row-strided
+    inputs; deterministic from run to run."""
+    from smokephysai_amd.models.linear import hip_linear_wgrad
+    g = torch.Generator(device="cuda").manual_seed(rows + out_f + in_f)
+    dy_full = torch.randn(rows, out_f + 8, device="cuda", generator=g)
+    x_full = torch.randn(rows, in_f + 4, device="cuda", generator=g)
+    dy, x = dy_full[:, :out_f], x_full[:, :in_f]                     # row pitch > feature count
+    dw = hip_linear_wgrad(dy, x)
+    ref = dy.double().t() @ x.double()
+    e_hip = rel_err(dw.cpu().numpy(), ref.cpu().numpy())
+    assert dw.shape == (out_f, in_f) and e_hip < TOL and e_hip < 2e-5, e_hip
+    assert torch.equal(dw, hip_linear_wgrad(dy, x))
+
+
+def test_weight_gradient_row_chunking(monkeypatch):
+    import smokephysai_amd.models.linear as hl
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dy = torch.randn(5000, 128, device="cuda", generator=g)
+    x = torch.randn(5000, 64, device="cuda", generator=g)
+    whole = hl.hip_linear_wgrad(dy, x)
+    monkeypatch.setattr(hl, "MAX_WGRAD_ROWS", 2048)
+    parts = hl.hip_linear_wgrad(dy, x)
+    ref = dy.double().t() @ x.double()
+    assert rel_err(parts.cpu().numpy(), ref.cpu().numpy()) < 2e-5 and rel_err(whole.cpu().numpy(), ref.cpu().numpy()) < 2e-5
