@@ -237,6 +237,22 @@ int smk_attention(const float *q, const float *k, const float *v, void *out, int
                   int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
                   void *stream);
 
+/* Training form of smk_attention (chaos_attention.py:102-112 under autograd, train.py:88-89): the same forward with fp32 output,
+ * plus lse [B][L][H] = log2 sum_j 2^(scale * log2(e) * q_i.k_j) per (token, head) -- the softmax normaliser the backward
+ * recomputes P from (log2 units). */
+int smk_attention_forward_lse(const float *q, const float *k, const float *v, float *out, float *lse, int32_t B, int32_t L,
+                              int32_t H, int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale,
+                              void *stream);
+
+/* Backward of that attention: dq, dk, dv [B][L][ldd*] (head h = columns 64h .. 64h+63) from q, k, v, the output gradient dout
+ * [B][L][ldo], the forward's lse and delta [B][L][H] = sum_d dout * out per (token, head).  Two launches of one kernel body
+ * (dk/dv per 128-key block, dq per 128-query block), split-bf16 MFMA like the forward, deterministic (no atomics).
+ * Same shape limits as smk_attention. */
+int smk_attention_backward(const float *q, const float *k, const float *v, const float *dout, const float *lse,
+                           const float *delta, float *dq, float *dk, float *dv, int32_t B, int32_t L, int32_t H,
+                           int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk,
+                           int64_t lddv, double scale, void *stream);
+
 /* nn.LayerNorm over the last dimension (smokephys_net.py:149-150, applied at :161,:165; biased variance, eps as given):
  * x [rows][ldx] -> y [rows][ldy], weight / bias [D].  D % 4 == 0, D <= 2048 (else SMK_ERR_UNSUPPORTED).
  * y_format: smk_format of y (split: D % 8 == 0, dense rows, ldy == D). */

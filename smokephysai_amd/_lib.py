@@ -69,6 +69,9 @@ _SIGNATURES = {
                          C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p],
     "smk_attention": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                       C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_void_p],
+    "smk_attention_forward_lse": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p],
+    "smk_attention_backward": [C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_int64] * 7 + [C.c_double, C.c_void_p],
     "smk_layernorm": [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64,
                       C.c_int32, C.c_void_p],
     "smk_decoder_create": [C.POINTER(SmkDecoderWeights), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],

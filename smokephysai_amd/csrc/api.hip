@@ -623,6 +623,55 @@ int smk_attention(const float *q, const float *k, const float *v, void *out, int
     return check_launch(launch_attention_x3(a, (hipStream_t)stream), "attention_x3");
 }
 
+int smk_attention_forward_lse(const float *q, const float *k, const float *v, float *out, float *lse, int32_t B, int32_t L,
+                              int32_t H, int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale,
+                              void *stream) {
+    SMK_REQUIRE(q && k && v && out && lse, "null q/k/v/out/lse");
+    SMK_REQUIRE(B >= 1 && H >= 1 && L >= 128, "B >= 1, H >= 1, L >= 128");
+    if (head_dim != 64 || L % 128 != 0) {
+        set_error("attention: HIP path is built for head_dim 64 and L a multiple of 128");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    const int64_t cols = (int64_t)H * 64;
+    SMK_REQUIRE(ldq >= cols && ldk >= cols && ldv >= cols && ldo >= cols, "row pitches >= H * head_dim");
+    SMK_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "row pitches multiples of 4 floats");
+    SMK_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "16-byte aligned tensors");
+    SMK_REQUIRE((int64_t)B * L * ldk < (1LL << 29) && (int64_t)B * L * ldv < (1LL << 29) && (int64_t)B * H * (L / 128) < (1LL << 31),
+                "B * L * ld < 2^29 floats (32-bit buffer offsets)");
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = out; a.o_split = 0; a.lse = lse;
+    a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo;
+    a.B = B; a.L = L; a.H = H;
+    a.scale_log2e = (float)(scale * 1.4426950408889634074);
+    return check_launch(launch_attention_x3(a, (hipStream_t)stream), "attention_x3");
+}
+
+int smk_attention_backward(const float *q, const float *k, const float *v, const float *dout, const float *lse,
+                           const float *delta, float *dq, float *dk, float *dv, int32_t B, int32_t L, int32_t H,
+                           int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk,
+                           int64_t lddv, double scale, void *stream) {
+    SMK_REQUIRE(q && k && v && dout && lse && delta && dq && dk && dv, "null pointer");
+    SMK_REQUIRE(B >= 1 && H >= 1 && L >= 128, "B >= 1, H >= 1, L >= 128");
+    if (head_dim != 64 || L % 128 != 0) {
+        set_error("attention: HIP path is built for head_dim 64 and L a multiple of 128");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    const int64_t cols = (int64_t)H * 64;
+    SMK_REQUIRE(ldq >= cols && ldk >= cols && ldv >= cols && ldo >= cols && lddq >= cols && lddk >= cols && lddv >= cols,
+                "row pitches >= H * head_dim");
+    SMK_REQUIRE((ldq | ldk | ldv | ldo | lddq | lddk | lddv) % 4 == 0, "row pitches multiples of 4 floats");
+    SMK_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                "16-byte aligned tensors");
+    SMK_REQUIRE((int64_t)B * H * (L / 128) < (1LL << 31), "B * H * L / 128 < 2^31");
+    AttnBwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.dout = dout; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo; a.lddq = (int)lddq; a.lddk = (int)lddk; a.lddv = (int)lddv;
+    a.B = B; a.L = L; a.H = H;
+    a.scale = (float)scale;
+    a.scale_log2e = (float)(scale * 1.4426950408889634074);
+    return check_launch(launch_attention_bwd_x3(a, (hipStream_t)stream), "attention_bwd_x3");
+}
+
 // ------------------------------------------------------------------ LayerNorm
 int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const float *weight, const float *bias, double eps,
                   void *y, int64_t ldy, int32_t y_format, void *stream) {

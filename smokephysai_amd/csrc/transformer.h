@@ -20,8 +20,21 @@ struct AttnArgs {
     int B, L, H;
     float scale_log2e;                   // softmax scale * log2(e), folded into Q
     int o_split;                         // o in SMK_FMT_SPLIT_BF16 (dense rows)
+    float *lse = nullptr;                // optional [B][L][H]: log2 of sum_j exp2(score_ij * scale * log2 e) -- saved for the backward
 };
 hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st);
+
+// Backward of the same attention (autograd of chaos_attention.py:102-112 with the chaos term folded into q): dq, dk, dv from q, k, v,
+// the output gradient, the forward's log-sum-exp and delta = rowsum(dout * out).
+struct AttnBwdArgs {
+    const float *q, *k, *v, *dout;       // [B][L][ld*], head h = columns 64h .. 64h+63
+    const float *lse, *delta;            // [B][L][H]
+    float *dq, *dk, *dv;                 // [B][L][ldd*]
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int B, L, H;
+    float scale, scale_log2e;
+};
+hipError_t launch_attention_bwd_x3(const AttnBwdArgs &a, hipStream_t st);
 
 struct LayerNormArgs {
     const float *x; float *y;            // [rows][ld*]

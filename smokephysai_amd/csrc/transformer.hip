@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) 
         const float m_new = fmaxf(m_run, m2);
         const float a1 = __builtin_amdgcn_exp2f(m_run - m_new), a2 = __builtin_amdgcn_exp2f(m2 - m_new);
         l_run = l_run * a1 + l2 * a2;
+        m_run = m_new;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const size_t orow = (size_t)b * a.L + qb * AT_QB + wave * 32 + r;
+    if (a.lse && hh == 0) a.lse[orow * a.H + head] = m_run + __builtin_amdgcn_logf(l_tot);      // v_log_f32 is log2
     if (a.o_split) {   // SMK_FMT_SPLIT_BF16: feature group (64 head + 32 db + 8 q4) / 8, this lane's half (4 hi | 4 lo)
         __bf16 *os = reinterpret_cast<__bf16 *>(a.o) + orow * (2 * (size_t)a.ldo) + (head * 8) * 16 + 4 * hh;
 #pragma unroll
@@ -341,6 +343,247 @@ hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
     if ((force_ks == 1 || force_ks == 2) && (a.L / AT_KV) % force_ks == 0) ks = force_ks;
     if (ks == 2) hipLaunchKernelGGL(k_attention_x3<2>, dim3(nwg), dim3(512), 2 * AT_LDS, st, a);
     else hipLaunchKernelGGL(k_attention_x3<1>, dim3(nwg), dim3(256), AT_LDS, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the attention above, same split-bf16 arithmetic (every product hi*hi + hi*lo + lo*hi, fp32 accumulate).
+// With s_ij = scale q_i.k_j, P = softmax(s) (recomputed from the saved log-sum-exp) and delta_i = sum_d dO_id O_id:
+//     dP_ij = dO_i.v_j      dS_ij = P_ij (dP_ij - delta_i)      dq_i = scale sum_j dS_ij k_j
+//     dk_j = scale sum_i dS_ij q_i                              dv_j = sum_i P_ij dO_i
+// ONE kernel body serves both passes: a workgroup owns 128 "outer" rows (wave w: 32 of them, one per lane and lane half) whose
+// operands X (for the scores) and U (for dP) stay in registers as MFMA B fragments, and walks 64-row "inner" tiles Y, W staged
+// through LDS:   S^T = mfma(Y, X)   T^T = mfma(W, U)   -> lane = outer row, accumulator registers = 32 of the tile's inner rows,
+// exactly the forward's S^T layout; the elementwise results are used IN PLACE as the B fragments of out1^T = mfma(Y^T, dS)
+// (and out2^T = mfma(W^T, P)) against transposed LDS images, like the forward's O^T = mfma(V^T, P).
+//     DKV = false (dq pass): outer = queries  X = q * scale * log2e   U = dO   inner: Y = k   W = v    out1 = dq; lse / delta per lane
+//     DKV = true  (dk, dv):  outer = keys     X = k * scale * log2e   U = v    inner: Y = q   W = dO   out1 = dk, out2 = dv; lse / delta
+//                            of the tile's 64 queries from LDS (they run along the accumulator registers)
+// Single-buffered LDS (54 KB / 72 KB -> 2 workgroups per CU): the next tile's global loads are in flight during the MFMAs.
+constexpr int AB_RPITCH = 144, AB_TPITCH = 136;
+constexpr int AB_RPLANE = 64 * AB_RPITCH, AB_TPLANE = 64 * AB_TPITCH;            // 9216, 8704
+constexpr int AB_YR = 0, AB_YT = 2 * AB_RPLANE, AB_WR = AB_YT + 2 * AB_TPLANE, AB_WT = AB_WR + 2 * AB_RPLANE;
+constexpr int AB_LDS_DQ = AB_WT;                                                   // 54,272 B
+constexpr int AB_SCAL = AB_WT + 2 * AB_TPLANE, AB_LDS_DKV = AB_SCAL + 2 * 64 * 4;   // 72,192 B
+
+template <bool DKV>
+__global__ __launch_bounds__(256, 2) void k_attention_bwd_x3(const AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vid = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int nob = a.L / 128;
+    const int ob = vid % nob, bh = vid / nob, head = bh % a.H, b = bh / a.H;
+    const int NT = a.L / 64;
+    const float *Xp = DKV ? a.k : a.q, *Up = DKV ? a.v : a.dout, *Yp = DKV ? a.q : a.k, *Wp = DKV ? a.dout : a.v;
+    const int ldX = DKV ? a.ldk : a.ldq, ldU = DKV ? a.ldv : a.ldo, ldY = DKV ? a.ldq : a.ldk, ldW = DKV ? a.ldo : a.ldv;
+    const size_t orow = (size_t)b * a.L + ob * 128 + wave * 32 + r;          // this lane's outer row
+
+    // ---- outer operands as B fragments (column = outer row r, k = d 16s + 8hh + j), split; X pre-scaled
+    bf16x8 xh[4], xl[4], uh[4], ul[4];
+    {
+        const float *xp = Xp + orow * ldX + head * 64 + 8 * hh, *up = Up + orow * ldU + head * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(xp + 16 * s), x1 = *reinterpret_cast<const float4 *>(xp + 16 * s + 4);
+            const float4 u0 = *reinterpret_cast<const float4 *>(up + 16 * s), u1 = *reinterpret_cast<const float4 *>(up + 16 * s + 4);
+            const float fx[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const float fu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = fx[j] * a.scale_log2e;
+                const __bf16 tx = (__bf16)x, tu = (__bf16)fu[j];
+                xh[s][j] = tx; xl[s][j] = (__bf16)(x - (float)tx);
+                uh[s][j] = tu; ul[s][j] = (__bf16)(fu[j] - (float)tu);
+            }
+        }
+    }
+    float lse_o = 0.f, del_o = 0.f;
+    if (!DKV) { lse_o = a.lse[orow * a.H + head]; del_o = a.delta[orow * a.H + head]; }
+
+    // ---- inner tiles: thread = 4 x 4 block (rows 4rq + i, columns 4c4 .. 4c4+3) of Y and of W
+    const int c4 = tid & 15, rq = tid >> 4;
+    float4 yst[4], wst[4];
+    float sc_st = 0.f;
+    auto stage_load = [&](int t) {
+        const size_t row0 = (size_t)b * a.L + t * 64 + 4 * rq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            yst[i] = *reinterpret_cast<const float4 *>(Yp + (row0 + i) * ldY + head * 64 + c4 * 4);
+            wst[i] = *reinterpret_cast<const float4 *>(Wp + (row0 + i) * ldW + head * 64 + c4 * 4);
+        }
+        if (DKV && tid < 128) {
+            const size_t qrow = (size_t)b * a.L + t * 64 + (tid & 63);
+            sc_st = (tid < 64 ? a.lse : a.delta)[qrow * a.H + head];
+        }
+    };
+    auto store_image = [&](const float4 (&st)[4], int off_r, int off_t, bool with_t) {
+        bf16x4 h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) at_split4(st[i], h[i], l[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                          // row-major [row 4rq + i][d 4c4 ..]
+            unsigned char *p = smem + off_r + (4 * rq + i) * AB_RPITCH + c4 * 8;
+            *reinterpret_cast<bf16x4 *>(p) = h[i];
+            *reinterpret_cast<bf16x4 *>(p + AB_RPLANE) = l[i];
+        }
+        if (with_t) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                                      // transposed [d 4c4 + e][rows 4rq .. 4rq+3]
+                bf16x4 th, tl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { th[i] = h[i][e]; tl[i] = l[i][e]; }
+                unsigned char *p = smem + off_t + (c4 * 4 + e) * AB_TPITCH + rq * 8;
+                *reinterpret_cast<bf16x4 *>(p) = th;
+                *reinterpret_cast<bf16x4 *>(p + AB_TPLANE) = tl;
+            }
+        }
+    };
+
+    f32x16 o1[2], o2[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { o1[db][g] = 0.f; o2[db][g] = 0.f; }
+
+    const unsigned char *yr_h = smem + AB_YR + r * AB_RPITCH + hh * 16, *wr_h = smem + AB_WR + r * AB_RPITCH + hh * 16;
+    const unsigned char *yt_h = smem + AB_YT + r * AB_TPITCH + hh * 8, *wt_h = smem + AB_WT + r * AB_TPITCH + hh * 8;
+    const float *scal = reinterpret_cast<const float *>(smem + AB_SCAL);
+
+    stage_load(0);
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        store_image(yst, AB_YR, AB_YT, true);
+        store_image(wst, AB_WR, AB_WT, DKV);
+        if (DKV && tid < 128) reinterpret_cast<float *>(smem + AB_SCAL)[tid] = sc_st;
+        if (t + 1 < NT) stage_load(t + 1);
+        __syncthreads();
+
+        // ---- S^T and T^T: acc[kb][g] = value(outer r, inner 32kb + (g&3) + 8(g>>2) + 4hh)
+        f32x16 sacc[2], tacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { sacc[kb][g] = 0.f; tacc[kb][g] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 yh[2], yl[2], wh[2], wl[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                yh[kb] = *reinterpret_cast<const bf16x8 *>(yr_h + kb * 32 * AB_RPITCH + s * 32);
+                yl[kb] = *reinterpret_cast<const bf16x8 *>(yr_h + AB_RPLANE + kb * 32 * AB_RPITCH + s * 32);
+                wh[kb] = *reinterpret_cast<const bf16x8 *>(wr_h + kb * 32 * AB_RPITCH + s * 32);
+                wl[kb] = *reinterpret_cast<const bf16x8 *>(wr_h + AB_RPLANE + kb * 32 * AB_RPITCH + s * 32);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[kb], xh[s], sacc[kb], 0, 0, 0);
+                tacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kb], uh[s], tacc[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[kb], xl[s], sacc[kb], 0, 0, 0);
+                tacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kb], ul[s], tacc[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[kb], xh[s], sacc[kb], 0, 0, 0);
+                tacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kb], uh[s], tacc[kb], 0, 0, 0);
+            }
+        }
+
+        // ---- P = exp2(S - lse), dS = scale * P * (dP - delta); both end up as B fragments (k = inner row, column = outer row r)
+        bf16x8 dsh[4], dsl[4], ph[4], pl[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float l8[8], d8[8];
+            if (DKV) {      // inner rows 16 s4 + 8 (j>>2) + 4hh + (j&3): two float4 each
+                const float4 la = *reinterpret_cast<const float4 *>(scal + 16 * s4 + 4 * hh), lb = *reinterpret_cast<const float4 *>(scal + 16 * s4 + 8 + 4 * hh);
+                const float4 da = *reinterpret_cast<const float4 *>(scal + 64 + 16 * s4 + 4 * hh), db_ = *reinterpret_cast<const float4 *>(scal + 64 + 16 * s4 + 8 + 4 * hh);
+                l8[0] = la.x; l8[1] = la.y; l8[2] = la.z; l8[3] = la.w; l8[4] = lb.x; l8[5] = lb.y; l8[6] = lb.z; l8[7] = lb.w;
+                d8[0] = da.x; d8[1] = da.y; d8[2] = da.z; d8[3] = da.w; d8[4] = db_.x; d8[5] = db_.y; d8[6] = db_.z; d8[7] = db_.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kb = s4 >> 1, g = 8 * (s4 & 1) + j;
+                const float p = __builtin_amdgcn_exp2f(sacc[kb][g] - (DKV ? l8[j] : lse_o));
+                const float ds = a.scale * p * (tacc[kb][g] - (DKV ? d8[j] : del_o));
+                const __bf16 dt = (__bf16)ds;
+                dsh[s4][j] = dt;
+                dsl[s4][j] = (__bf16)(ds - (float)dt);
+                if (DKV) {
+                    const __bf16 pt = (__bf16)p;
+                    ph[s4][j] = pt;
+                    pl[s4][j] = (__bf16)(p - (float)pt);
+                }
+            }
+        }
+
+        // ---- out1^T += Y^T dS (and out2^T += W^T P): o[db][g] = out(outer r, d 32db + (g&3) + 8(g>>2) + 4hh)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            bf16x8 th[2], tl[2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const unsigned char *p0 = yt_h + db * 32 * AB_TPITCH + s4 * 32;          // inner rows 16 s4 + 4hh .. +3 | +8
+                const bf16x4 h0 = *reinterpret_cast<const bf16x4 *>(p0), h1 = *reinterpret_cast<const bf16x4 *>(p0 + 16);
+                const bf16x4 l0 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE), l1 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE + 16);
+                th[db] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                tl[db] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[db], dsh[s4], o1[db], 0, 0, 0);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], dsl[s4], o1[db], 0, 0, 0);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], dsh[s4], o1[db], 0, 0, 0);
+            if (DKV) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const unsigned char *p0 = wt_h + db * 32 * AB_TPITCH + s4 * 32;
+                    const bf16x4 h0 = *reinterpret_cast<const bf16x4 *>(p0), h1 = *reinterpret_cast<const bf16x4 *>(p0 + 16);
+                    const bf16x4 l0 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE), l1 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE + 16);
+                    th[db] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    tl[db] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[db], ph[s4], o2[db], 0, 0, 0);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], pl[s4], o2[db], 0, 0, 0);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], ph[s4], o2[db], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                       // every read of this tile's images has returned
+    }
+
+    // ---- store: 4 consecutive d per register quad
+    float *p1 = (DKV ? a.dk : a.dq) + orow * (DKV ? a.lddk : a.lddq) + head * 64 + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            *reinterpret_cast<float4 *>(p1 + 32 * db + 8 * q4) = make_float4(o1[db][4 * q4], o1[db][4 * q4 + 1], o1[db][4 * q4 + 2], o1[db][4 * q4 + 3]);
+    if (DKV) {
+        float *p2 = a.dv + orow * a.lddv + head * 64 + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                *reinterpret_cast<float4 *>(p2 + 32 * db + 8 * q4) = make_float4(o2[db][4 * q4], o2[db][4 * q4 + 1], o2[db][4 * q4 + 2], o2[db][4 * q4 + 3]);
+    }
+}
+
+hipError_t launch_attention_bwd_x3(const AttnBwdArgs &a, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_attention_bwd_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_DQ);
+        (void)hipFuncSetAttribute((const void *)k_attention_bwd_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_DKV);
+        attr_done = true;
+    }
+    const int nwg = a.B * a.H * (a.L / 128);
+    hipLaunchKernelGGL(k_attention_bwd_x3<true>, dim3(nwg), dim3(256), AB_LDS_DKV, st, a);
+    hipLaunchKernelGGL(k_attention_bwd_x3<false>, dim3(nwg), dim3(256), AB_LDS_DQ, st, a);
     return hipGetLastError();
 }
 

@@ -42,6 +42,54 @@ def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: 
     return out
 
 
+class _HipAttentionFn(torch.autograd.Function):
+    """softmax(q k^T * scale) v over token-major [B, L, H*64] tensors with forward AND backward on libsmokehip
+    (smk_attention_forward_lse / smk_attention_backward)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads, scale):
+        dev = _lib.require_cuda(q.device, "hip_attention_train")
+        B, L, D = q.shape
+        q, k, v = [t if (t.stride(2) == 1 and t.stride(0) == L * t.stride(1) and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0)
+                   else t.contiguous() for t in (q, k, v)]
+        out = torch.empty(B, L, D, device=dev, dtype=torch.float32)
+        lse = torch.empty(B, L, num_heads, device=dev, dtype=torch.float32)
+        bmax = max(1, (MAX_QKV_ELEMS - 1) // (L * max(q.stride(1), k.stride(1), v.stride(1), D)))
+        for b0 in range(0, B, bmax):
+            nb = min(bmax, B - b0)
+            _lib.check(_lib.load().smk_attention_forward_lse(
+                q[b0:].data_ptr(), k[b0:].data_ptr(), v[b0:].data_ptr(), out[b0:].data_ptr(), lse[b0:].data_ptr(), nb, L, num_heads,
+                D // num_heads, q.stride(1), k.stride(1), v.stride(1), D, float(scale), _lib.stream_ptr(dev)))
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.num_heads, ctx.scale = num_heads, float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, L, D = q.shape
+        H = ctx.num_heads
+        dout = dout.contiguous()
+        delta = (dout * out).view(B, L, H, D // H).sum(-1)                      # [B, L, H]
+        dq, dk, dv = torch.empty_like(out), torch.empty_like(out), torch.empty_like(out)
+        dev = q.device
+        bmax = max(1, (MAX_QKV_ELEMS - 1) // (L * max(q.stride(1), k.stride(1), v.stride(1), D)))
+        for b0 in range(0, B, bmax):
+            nb = min(bmax, B - b0)
+            _lib.check(_lib.load().smk_attention_backward(
+                q[b0:].data_ptr(), k[b0:].data_ptr(), v[b0:].data_ptr(), dout[b0:].data_ptr(), lse[b0:].data_ptr(),
+                delta[b0:].data_ptr(), dq[b0:].data_ptr(), dk[b0:].data_ptr(), dv[b0:].data_ptr(), nb, L, H, D // H,
+                q.stride(1), k.stride(1), v.stride(1), D, D, D, D, ctx.scale, _lib.stream_ptr(dev)))
+        return dq, dk, dv, None, None
+
+
+def hip_attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, scale: float) -> torch.Tensor:
+    """Differentiable hip_attention: q, k, v [B, L, H*64] float32 on a ROCm device -> [B, L, H*64]."""
+    if q.dtype != torch.float32 or q.shape != k.shape or q.shape != v.shape:
+        raise ValueError("hip_attention_train: q, k, v float32 of one shape [B, L, H*64]")
+    return _HipAttentionFn.apply(q, k, v, num_heads, scale)
+
+
 def hip_layernorm_supported(D: int) -> bool:
     return D % 4 == 0 and 4 <= D <= 2048
 

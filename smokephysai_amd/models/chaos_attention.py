@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .attention import hip_attention_supported, hip_attention_train
 from .linear import TrainableHipLinear
 
 
@@ -35,6 +36,7 @@ class ChaosAttention(nn.Module):
         self.register_buffer("lorenz_rho", torch.tensor(28.0))
         self.register_buffer("lorenz_beta", torch.tensor(8.0 / 3.0))
         self._lorenz_host = None
+        self.hip_train = False      # set by SmokePhysNet(linear_dtype="bf16x3"): attention forward + backward on libsmokehip in training
 
     def lorenz_system(self, x, y, z, dt: float = 0.01):
         """chaos_attention.py:39-45 (explicit Euler)."""
@@ -104,15 +106,22 @@ class ChaosAttention(nn.Module):
         B, L, D = x.shape
         H, d = self.num_heads, self.head_dim
         q = self.q_proj(x)
-        k = self.k_proj(x).view(B, L, H, d).transpose(1, 2)
-        v = self.v_proj(x).view(B, L, H, d).transpose(1, 2)
         add5 = self.chaos_addend(B, x.device, x.dtype, noise)                        # [B,5,D]
         reps = (L + 4) // 5
-        q = (q + add5.repeat(1, reps, 1)[:, :L]).view(B, L, H, d).transpose(1, 2)
+        q = q + add5.repeat(1, reps, 1)[:, :L]
+        scale = 1.0 / (math.sqrt(d) * self.temperature)
+        if (self.hip_train and mask is None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and hip_attention_supported(L, d)):
+            # training on a ROCm device: flash attention forward + backward on libsmokehip, token-major in and out
+            # (no head transposes, no merge-heads copy)
+            out = hip_attention_train(q, self.k_proj(x), self.v_proj(x), H, scale)
+            return self.out_proj(out)
+        k = self.k_proj(x).view(B, L, H, d).transpose(1, 2)
+        v = self.v_proj(x).view(B, L, H, d).transpose(1, 2)
+        q = q.view(B, L, H, d).transpose(1, 2)
         attn_mask = None
         if mask is not None:
             attn_mask = (mask != 0)[:, None, None, :]
-        scale = 1.0 / (math.sqrt(d) * self.temperature)
         out = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, scale=scale)
         out = out.transpose(1, 2).contiguous().view(B, L, D)
         return self.out_proj(out)

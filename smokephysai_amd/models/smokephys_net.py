@@ -82,7 +82,7 @@ class SmokePhysNet(nn.Module):
         self._hip_dec = None         # (HipDecoder, weight fingerprint)
         # training: the token-wise linear layers run their forward and input-gradient GEMMs on libsmokehip as well (models/linear.py)
         for m in self.modules():
-            if isinstance(m, TrainableHipLinear):
+            if isinstance(m, (TrainableHipLinear, ChaosAttention)):
                 m.hip_train = linear_dtype == "bf16x3"
 
     # copy.deepcopy / pickling of the module: the libsmokehip handles are per-instance device mirrors, rebuilt on first use

@@ -188,3 +188,71 @@ def test_large_inputs_are_chunked_transparently(monkeypatch):
     assert torch.equal(lin(x, periodic_add=padd), y_p)
     assert torch.equal(lin(x, residual=res), y_r)
     assert torch.equal(A.hip_attention(qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:], 8, 0.125), o)
+
+
+# ---------------------------------------------------------------- training: attention forward + backward on libsmokehip
+@pytest.mark.parametrize("B,L,H,spread", [(1, 128, 2, 1.0), (2, 1024, 8, 1.0), (2, 256, 4, 3.0), (1, 384, 1, 1.0)])
+def test_attention_backward_matches_fp64_autograd(B, L, H, spread):
+    """smk_attention_forward_lse + smk_attention_backward (dq, dk, dv) against fp64 softmax attention under autograd;
+    strided q/k/v (slices of one fused tensor); deterministic."""
+    from smokephysai_amd.models.attention import hip_attention_train
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + L + H)
+    D = 64 * H
+    qkv = torch.randn(B, L, 3 * D, device="cuda", generator=g) * spread
+    qkv.requires_grad_(True)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    dout = torch.randn(B, L, D, device="cuda", generator=g)
+    scale = 0.125
+    out = hip_attention_train(q, k, v, H, scale)
+    out.backward(dout)
+    got = qkv.grad.clone()
+
+    ref_in = qkv.detach().double().requires_grad_(True)
+    q64, k64, v64 = [ref_in[..., i * D:(i + 1) * D].view(B, L, H, 64).transpose(1, 2) for i in range(3)]
+    p = torch.softmax(q64 @ k64.transpose(-1, -2) * scale, dim=-1)
+    ref = (p @ v64).transpose(1, 2).reshape(B, L, D)
+    ref.backward(dout.double())
+    tol = 2e-5 if spread == 1.0 else 1e-4
+
+    def err(a, b):
+        return rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    assert err(out, ref) < tol
+    for i, name in enumerate("qkv"):
+        e = err(got[..., i * D:(i + 1) * D], ref_in.grad[..., i * D:(i + 1) * D])
+        assert e < tol, (name, e)
+    qkv.grad = None
+    hip_attention_train(q, k, v, H, scale).backward(dout)
+    assert torch.equal(qkv.grad, got)
+
+
+def test_chaos_attention_module_trains_on_the_hip_attention():
+    """ChaosAttention (dim 128, 2 heads of 64) in train mode: output and every parameter / input gradient with linears + attention on
+    libsmokehip against the same module in fp64 on PyTorch ops."""
+    import copy
+    torch.manual_seed(11)
+    attn = ChaosAttention(128, 2).cuda().train()
+    attn.hip_train = True
+    for m in attn.modules():
+        if hasattr(m, "hip_train"):
+            m.hip_train = True
+    ref_mod = copy.deepcopy(attn).double()
+    for m in ref_mod.modules():
+        if hasattr(m, "hip_train"):
+            m.hip_train = False
+    x = torch.randn(2, 256, 128, device="cuda", requires_grad=True)
+    noise = torch.randn(3, 2, 1, device="cuda")
+    dy = torch.randn(2, 256, 128, device="cuda")
+    y = attn(x, noise=noise)
+    assert "HipLinearFn" in type(y.grad_fn).__name__                    # out_proj on the HIP node, fed by _HipAttentionFn
+    y.backward(dy)
+    x64 = x.detach().double().requires_grad_(True)
+    y64 = ref_mod(x64, noise=noise.double())
+    y64.backward(dy.double())
+
+    def err(a, b):
+        return rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    assert err(y, y64) < 1e-4 and err(x.grad, x64.grad) < 1e-4
+    scale = max(float(p.grad.abs().max()) for p in ref_mod.parameters())
+    for (n, p), (_, p64) in zip(attn.named_parameters(), ref_mod.named_parameters()):
+        if float(p64.grad.abs().max()) > 1e-9 * scale:
+            assert err(p.grad, p64.grad) < 1e-4, n
