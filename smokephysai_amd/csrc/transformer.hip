@@ -459,99 +459,91 @@ __global__ __launch_bounds__(256, 2) void k_attention_bwd_x3(const AttnBwdArgs a
         if (t + 1 < NT) stage_load(t + 1);
         __syncthreads();
 
-        // ---- S^T and T^T: acc[kb][g] = value(outer r, inner 32kb + (g&3) + 8(g>>2) + 4hh)
-        f32x16 sacc[2], tacc[2];
+        // The 64 inner rows go in two halves of 32 (kb): scores, elementwise, output MFMAs -- one half's accumulators and fragments
+        // live at a time (the whole tile at once needs ~290 registers in the dk/dv pass).
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            // ---- S^T and T^T: acc[g] = value(outer r, inner 32kb + (g&3) + 8(g>>2) + 4hh)
+            f32x16 sacc, tacc;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { sacc[kb][g] = 0.f; tacc[kb][g] = 0.f; }
+            for (int g = 0; g < 16; ++g) { sacc[g] = 0.f; tacc[g] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 yh[2], yl[2], wh[2], wl[2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                yh[kb] = *reinterpret_cast<const bf16x8 *>(yr_h + kb * 32 * AB_RPITCH + s * 32);
-                yl[kb] = *reinterpret_cast<const bf16x8 *>(yr_h + AB_RPLANE + kb * 32 * AB_RPITCH + s * 32);
-                wh[kb] = *reinterpret_cast<const bf16x8 *>(wr_h + kb * 32 * AB_RPITCH + s * 32);
-                wl[kb] = *reinterpret_cast<const bf16x8 *>(wr_h + AB_RPLANE + kb * 32 * AB_RPITCH + s * 32);
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 yh = *reinterpret_cast<const bf16x8 *>(yr_h + kb * 32 * AB_RPITCH + s * 32);
+                const bf16x8 yl = *reinterpret_cast<const bf16x8 *>(yr_h + AB_RPLANE + kb * 32 * AB_RPITCH + s * 32);
+                const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(wr_h + kb * 32 * AB_RPITCH + s * 32);
+                const bf16x8 wl = *reinterpret_cast<const bf16x8 *>(wr_h + AB_RPLANE + kb * 32 * AB_RPITCH + s * 32);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh[s], sacc, 0, 0, 0);
+                tacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, uh[s], tacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl[s], sacc, 0, 0, 0);
+                tacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ul[s], tacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh[s], sacc, 0, 0, 0);
+                tacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, uh[s], tacc, 0, 0, 0);
             }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[kb], xh[s], sacc[kb], 0, 0, 0);
-                tacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kb], uh[s], tacc[kb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[kb], xl[s], sacc[kb], 0, 0, 0);
-                tacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kb], ul[s], tacc[kb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[kb], xh[s], sacc[kb], 0, 0, 0);
-                tacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[kb], uh[s], tacc[kb], 0, 0, 0);
-            }
-        }
 
-        // ---- P = exp2(S - lse), dS = scale * P * (dP - delta); both end up as B fragments (k = inner row, column = outer row r)
-        bf16x8 dsh[4], dsl[4], ph[4], pl[4];
+            // ---- P = exp2(S - lse), dS = scale * P * (dP - delta); both end up as B fragments (k = inner row, column = outer row r)
+            bf16x8 dsh[2], dsl[2], ph[2], pl[2];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            float l8[8], d8[8];
-            if (DKV) {      // inner rows 16 s4 + 8 (j>>2) + 4hh + (j&3): two float4 each
-                const float4 la = *reinterpret_cast<const float4 *>(scal + 16 * s4 + 4 * hh), lb = *reinterpret_cast<const float4 *>(scal + 16 * s4 + 8 + 4 * hh);
-                const float4 da = *reinterpret_cast<const float4 *>(scal + 64 + 16 * s4 + 4 * hh), db_ = *reinterpret_cast<const float4 *>(scal + 64 + 16 * s4 + 8 + 4 * hh);
-                l8[0] = la.x; l8[1] = la.y; l8[2] = la.z; l8[3] = la.w; l8[4] = lb.x; l8[5] = lb.y; l8[6] = lb.z; l8[7] = lb.w;
-                d8[0] = da.x; d8[1] = da.y; d8[2] = da.z; d8[3] = da.w; d8[4] = db_.x; d8[5] = db_.y; d8[6] = db_.z; d8[7] = db_.w;
-            }
+            for (int sl = 0; sl < 2; ++sl) {
+                const int s4 = 2 * kb + sl;
+                float l8[8], d8[8];
+                if (DKV) {      // inner rows 16 s4 + 8 (j>>2) + 4hh + (j&3): two float4 each
+                    const float4 la = *reinterpret_cast<const float4 *>(scal + 16 * s4 + 4 * hh), lb = *reinterpret_cast<const float4 *>(scal + 16 * s4 + 8 + 4 * hh);
+                    const float4 da = *reinterpret_cast<const float4 *>(scal + 64 + 16 * s4 + 4 * hh), db_ = *reinterpret_cast<const float4 *>(scal + 64 + 16 * s4 + 8 + 4 * hh);
+                    l8[0] = la.x; l8[1] = la.y; l8[2] = la.z; l8[3] = la.w; l8[4] = lb.x; l8[5] = lb.y; l8[6] = lb.z; l8[7] = lb.w;
+                    d8[0] = da.x; d8[1] = da.y; d8[2] = da.z; d8[3] = da.w; d8[4] = db_.x; d8[5] = db_.y; d8[6] = db_.z; d8[7] = db_.w;
+                }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int kb = s4 >> 1, g = 8 * (s4 & 1) + j;
-                const float p = __builtin_amdgcn_exp2f(sacc[kb][g] - (DKV ? l8[j] : lse_o));
-                const float ds = a.scale * p * (tacc[kb][g] - (DKV ? d8[j] : del_o));
-                const __bf16 dt = (__bf16)ds;
-                dsh[s4][j] = dt;
-                dsl[s4][j] = (__bf16)(ds - (float)dt);
-                if (DKV) {
-                    const __bf16 pt = (__bf16)p;
-                    ph[s4][j] = pt;
-                    pl[s4][j] = (__bf16)(p - (float)pt);
+                for (int j = 0; j < 8; ++j) {
+                    const int g = 8 * sl + j;
+                    const float p = __builtin_amdgcn_exp2f(sacc[g] - (DKV ? l8[j] : lse_o));
+                    const float ds = a.scale * p * (tacc[g] - (DKV ? d8[j] : del_o));
+                    const __bf16 dt = (__bf16)ds;
+                    dsh[sl][j] = dt;
+                    dsl[sl][j] = (__bf16)(ds - (float)dt);
+                    if (DKV) {
+                        const __bf16 pt = (__bf16)p;
+                        ph[sl][j] = pt;
+                        pl[sl][j] = (__bf16)(p - (float)pt);
+                    }
                 }
             }
-        }
 
-        // ---- out1^T += Y^T dS (and out2^T += W^T P): o[db][g] = out(outer r, d 32db + (g&3) + 8(g>>2) + 4hh)
+            // ---- out1^T += Y^T dS (and out2^T += W^T P): o[db][g] = out(outer r, d 32db + (g&3) + 8(g>>2) + 4hh)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            bf16x8 th[2], tl[2];
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const unsigned char *p0 = yt_h + db * 32 * AB_TPITCH + s4 * 32;          // inner rows 16 s4 + 4hh .. +3 | +8
-                const bf16x4 h0 = *reinterpret_cast<const bf16x4 *>(p0), h1 = *reinterpret_cast<const bf16x4 *>(p0 + 16);
-                const bf16x4 l0 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE), l1 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE + 16);
-                th[db] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                tl[db] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[db], dsh[s4], o1[db], 0, 0, 0);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], dsl[s4], o1[db], 0, 0, 0);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], dsh[s4], o1[db], 0, 0, 0);
-            if (DKV) {
+            for (int sl = 0; sl < 2; ++sl) {
+                const int s4 = 2 * kb + sl;
+                bf16x8 th[2], tl[2];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const unsigned char *p0 = wt_h + db * 32 * AB_TPITCH + s4 * 32;
+                    const unsigned char *p0 = yt_h + db * 32 * AB_TPITCH + s4 * 32;          // inner rows 16 s4 + 4hh .. +3 | +8
                     const bf16x4 h0 = *reinterpret_cast<const bf16x4 *>(p0), h1 = *reinterpret_cast<const bf16x4 *>(p0 + 16);
                     const bf16x4 l0 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE), l1 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE + 16);
                     th[db] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                     tl[db] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
-                for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[db], ph[s4], o2[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[db], dsh[sl], o1[db], 0, 0, 0);
 #pragma unroll
-                for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], pl[s4], o2[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], dsl[sl], o1[db], 0, 0, 0);
 #pragma unroll
-                for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], ph[s4], o2[db], 0, 0, 0);
+                for (int db = 0; db < 2; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], dsh[sl], o1[db], 0, 0, 0);
+                if (DKV) {
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const unsigned char *p0 = wt_h + db * 32 * AB_TPITCH + s4 * 32;
+                        const bf16x4 h0 = *reinterpret_cast<const bf16x4 *>(p0), h1 = *reinterpret_cast<const bf16x4 *>(p0 + 16);
+                        const bf16x4 l0 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE), l1 = *reinterpret_cast<const bf16x4 *>(p0 + AB_TPLANE + 16);
+                        th[db] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        tl[db] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[db], ph[sl], o2[db], 0, 0, 0);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], pl[sl], o2[db], 0, 0, 0);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) o2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[db], ph[sl], o2[db], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                                       // every read of this tile's images has returned
