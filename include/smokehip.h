@@ -216,6 +216,23 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream);
 
+/* Training-mode BatchNorm2d (batch statistics) + ReLU + pool x pool mean pooling of an NCHW fp32 convolution output -- the
+ * norm / activation / pool blocks of SmokePhysNet.input_encoder under autograd (smokephys_net.py:24-32 Conv -> BatchNorm2d -> ReLU,
+ * :87-91 the two adaptive average pools as one block mean; train.py:88-89).
+ *   forward:  z [B][C][H][W], gamma / beta [C], eps -> out [B][C][H/pool][W/pool] = blockmean(relu(bn(z))), and the batch
+ *             statistics mean / var (biased) / rstd [C] (the caller updates running_mean / running_var from them);
+ *   backward: dout [B][C][H/pool][W/pool] -> dz [B][C][H][W], dgamma / dbeta [C]; the ReLU mask is recomputed from z.
+ * pool in {1, 4, 8}; H * W a multiple of 4,096 (pool 8: 16,384); pool > 1 needs W == 32 * pool.  `workspace`:
+ * smk_bn_train_workspace(B, C, H, W, pool) bytes of device memory (partial sums), caller-owned.  Reductions are two-stage
+ * in a fixed order (deterministic).  Enqueued on `stream`. */
+int64_t smk_bn_train_workspace(int32_t B, int32_t C, int32_t H, int32_t W, int32_t pool);
+int smk_bn_relu_pool_forward(const float *z, int32_t B, int32_t C, int32_t H, int32_t W, const float *gamma, const float *beta,
+                             double eps, int32_t pool, float *out, float *mean, float *var, float *rstd, void *workspace,
+                             void *stream);
+int smk_bn_relu_pool_backward(const float *z, const float *dout, int32_t B, int32_t C, int32_t H, int32_t W, const float *gamma,
+                              const float *beta, const float *mean, const float *rstd, int32_t pool, float *dz, float *dgamma,
+                              float *dbeta, void *workspace, void *stream);
+
 /* The chaos term of one ChaosAttention layer folded into Q (chaos_attention.py:39-66 lorenz_system + generate_chaos_field,
  * :85-100 chaos_proj / chaos_gate / chaos_strength): noise [3][B] = the three randn(B,1) draws (before the 0.1 scale),
  * proj_w [D][3], proj_b [D], gate_w [D], gate_b [1] (PyTorch layouts) -> addend [B][5][ld_addend] (columns 0..D-1

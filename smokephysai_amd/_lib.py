@@ -72,6 +72,8 @@ _SIGNATURES = {
     "smk_attention_forward_lse": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p],
     "smk_attention_backward": [C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_int64] * 7 + [C.c_double, C.c_void_p],
+    "smk_bn_relu_pool_forward": [C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_double, C.c_int32] + [C.c_void_p] * 6,
+    "smk_bn_relu_pool_backward": [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 5,
     "smk_layernorm": [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64,
                       C.c_int32, C.c_void_p],
     "smk_decoder_create": [C.POINTER(SmkDecoderWeights), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
@@ -85,7 +87,7 @@ _SIGNATURES = {
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
-EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace"] + list(_SIGNATURES)
+EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace"] + list(_SIGNATURES)
 
 _lib = None
 
@@ -107,6 +109,8 @@ def load():
         L.smk_last_error.restype = C.c_char_p
         L.smk_linear_wgrad_workspace.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         L.smk_linear_wgrad_workspace.restype = C.c_int64          # a byte count, not a status
+        L.smk_bn_train_workspace.argtypes = [C.c_int32] * 5
+        L.smk_bn_train_workspace.restype = C.c_int64
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -7,6 +7,7 @@
 #include "decoder.h"
 #include "encoder.h"
 #include "linear.h"
+#include "norm.h"
 #include "stencil.h"
 #include "transformer.h"
 
@@ -670,6 +671,50 @@ int smk_attention_backward(const float *q, const float *k, const float *v, const
     a.scale = (float)scale;
     a.scale_log2e = (float)(scale * 1.4426950408889634074);
     return check_launch(launch_attention_bwd_x3(a, (hipStream_t)stream), "attention_bwd_x3");
+}
+
+// ------------------------------------------------------------------ training-mode BatchNorm + ReLU + pool
+static int bn_check(int32_t B, int32_t C, int32_t H, int32_t W, int32_t pool) {
+    SMK_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1, "positive sizes");
+    const int64_t chunk = pool == 8 ? 16384 : 4096;
+    if (!(pool == 1 || pool == 4 || pool == 8) || ((int64_t)H * W) % chunk != 0 || (pool > 1 && (W != 32 * pool || H % pool != 0)) ||
+        (int64_t)B * (H * (int64_t)W / chunk) >= (1LL << 31) || C > 65535) {
+        set_error("bn_relu_pool: HIP path is built for pool in {1, 4, 8}, H * W a multiple of 4096 (pool 8: 16384), W == 32 * pool when pooling");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return SMK_OK;
+}
+
+int64_t smk_bn_train_workspace(int32_t B, int32_t C, int32_t H, int32_t W, int32_t pool) {
+    if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
+    return bn_train_workspace_floats(B, C, H, W, pool) * (int64_t)sizeof(float);
+}
+
+int smk_bn_relu_pool_forward(const float *z, int32_t B, int32_t C, int32_t H, int32_t W, const float *gamma, const float *beta,
+                             double eps, int32_t pool, float *out, float *mean, float *var, float *rstd, void *workspace,
+                             void *stream) {
+    SMK_REQUIRE(z && gamma && beta && out && mean && var && rstd && workspace, "null pointer");
+    int rc = bn_check(B, C, H, W, pool);
+    if (rc) return rc;
+    SMK_REQUIRE((((uintptr_t)z | (uintptr_t)out | (uintptr_t)workspace) & 15) == 0, "16-byte aligned tensors");
+    BnTrainArgs a = {};
+    a.z = z; a.gamma = gamma; a.beta = beta; a.B = B; a.C = C; a.H = H; a.W = W; a.pool = pool; a.eps = (float)eps;
+    a.part = (float *)workspace; a.out = out; a.mean = mean; a.var = var; a.rstd = rstd;
+    return check_launch(launch_bn_relu_pool_forward(a, (hipStream_t)stream), "bn_relu_pool_forward");
+}
+
+int smk_bn_relu_pool_backward(const float *z, const float *dout, int32_t B, int32_t C, int32_t H, int32_t W, const float *gamma,
+                              const float *beta, const float *mean, const float *rstd, int32_t pool, float *dz, float *dgamma,
+                              float *dbeta, void *workspace, void *stream) {
+    SMK_REQUIRE(z && dout && gamma && beta && mean && rstd && dz && dgamma && dbeta && workspace, "null pointer");
+    int rc = bn_check(B, C, H, W, pool);
+    if (rc) return rc;
+    SMK_REQUIRE((((uintptr_t)z | (uintptr_t)dz | (uintptr_t)dout | (uintptr_t)workspace) & 15) == 0, "16-byte aligned tensors");
+    BnTrainArgs a = {};
+    a.z = z; a.gamma = gamma; a.beta = beta; a.B = B; a.C = C; a.H = H; a.W = W; a.pool = pool;
+    a.part = (float *)workspace; a.mean = const_cast<float *>(mean); a.rstd = const_cast<float *>(rstd);
+    a.dout = dout; a.dz = dz; a.dgamma = dgamma; a.dbeta = dbeta;
+    return check_launch(launch_bn_relu_pool_backward(a, (hipStream_t)stream), "bn_relu_pool_backward");
 }
 
 // ------------------------------------------------------------------ LayerNorm

@@ -22,6 +22,7 @@ from .decoder import HipDecoder, decoder_weight_dict, hip_decoder_supported
 from .encoder import HipEncoder, encoder_weight_dict
 from .hip_body import HipBody
 from .linear import TrainableHipLinear, hip_linear_supported
+from .norm import hip_bn_relu_pool, hip_bn_relu_pool_supported
 from .physics_regularizer import PhysicsRegularizer
 
 
@@ -114,6 +115,16 @@ class SmokePhysNet(nn.Module):
     def encode_frames(self, x: torch.Tensor, dtype: Optional[str] = None) -> torch.Tensor:
         """input_encoder + both pools (smokephys_net.py:87-91): [B,1,H,W] -> [B,128,32,32]."""
         if self.training and torch.is_grad_enabled():
+            conv1, bn1, _, conv2, bn2, _, pool = self.input_encoder
+            H, W = x.shape[-2:]
+            P = H // 32
+            mid = pool.output_size[0]              # first pool target; no up-sampling stage and whole-number windows: one P x P mean
+            if (self.linear_dtype == "bf16x3" and x.is_cuda and x.dtype == torch.float32 and H == W and P in (4, 8) and W == 32 * P
+                    and pool.output_size[0] == pool.output_size[1] and H % mid == 0 and mid % 32 == 0):
+                # libsmokehip: BatchNorm (batch statistics) + ReLU as two passes over the conv output, and for the second block
+                # the two average pools (one P x P block mean) in the same pass -- the 256 x 256 x 128 maps are never written
+                a1 = hip_bn_relu_pool(conv1(x), bn1, 1)
+                return hip_bn_relu_pool(conv2(a1), bn2, P)
             encoded = x
             for m in self.input_encoder:
                 encoded = _avg_pool_to(encoded, m.output_size) if isinstance(m, nn.AdaptiveAvgPool2d) else m(encoded)

@@ -147,3 +147,76 @@ print("ok32")
         g = np.load(os.path.join(root, f"tests/golden/encoder_io_{N}.npz"))
         f16 = enc16(torch.from_numpy(g["frames"]).cuda()[:, None], input_dim=128, dtype="bf16x3").cpu().numpy()
         assert rel_err(f16, np.load(f"/tmp/smk_feat32_{N}.npy")) < 1e-5, N
+
+
+# ---------------------------------------------------------------- training: BatchNorm (batch statistics) + ReLU + pool on libsmokehip
+@pytest.mark.parametrize("B,C,H,pool", [(3, 64, 128, 1), (2, 128, 128, 4), (2, 128, 256, 8), (5, 16, 64, 1)])
+def test_bn_relu_pool_training_kernels_match_fp64_autograd(B, C, H, pool):
+    """smk_bn_relu_pool_forward / _backward against nn.BatchNorm2d(train) -> ReLU -> avg_pool2d in fp64: output, dz, dgamma, dbeta
+    and the running-statistics update; deterministic."""
+    from smokephysai_amd.models.norm import hip_bn_relu_pool
+    torch.manual_seed(B * C + H + pool)
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    ref_bn = torch.nn.BatchNorm2d(C).cuda().double().train()
+    ref_bn.load_state_dict({k: v.double() if v.is_floating_point() else v.clone() for k, v in bn.state_dict().items()})
+    z = (torch.randn(B, C, H, H, device="cuda") * 2.0 + 3.0 * torch.randn(1, C, 1, 1, device="cuda")).requires_grad_(True)
+    dout = torch.randn(B, C, H // pool, H // pool, device="cuda")
+    out = hip_bn_relu_pool(z, bn, pool)
+    out.backward(dout)
+    z64 = z.detach().double().requires_grad_(True)
+    pre64 = ref_bn(z64)
+    y64 = torch.relu(pre64)
+    ref = y64 if pool == 1 else torch.nn.functional.avg_pool2d(y64, pool)
+    ref.backward(dout.double())
+
+    def err(a, b):
+        return rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    # ReLU is discontinuous in its derivative: an activation within rounding of 0 (about one of the 1.7e7 elements here) takes the
+    # other branch in fp32 than in fp64 -- as it does in PyTorch's own fp32 kernels; those elements are excluded from the dz check
+    sure = (pre64.detach().abs() > 1e-5)
+    assert float((~sure).sum()) < 1e-4 * sure.numel()
+    assert err(out, ref) < 1e-5 and err(z.grad * sure, z64.grad * sure) < 1e-4
+    # (the same flipped element enters the channel sums with a weight of |dout| / pool^2: up to a few 1e-4 of the largest dbeta)
+    assert err(bn.weight.grad, ref_bn.weight.grad) < 1e-3 and err(bn.bias.grad, ref_bn.bias.grad) < 1e-3
+    assert err(bn.running_mean, ref_bn.running_mean) < 1e-5 and err(bn.running_var, ref_bn.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    g1 = z.grad.clone()
+    z.grad = None
+    bn.zero_grad()
+    hip_bn_relu_pool(z, bn, pool).backward(dout)
+    assert torch.equal(z.grad, g1)
+
+
+def test_training_encoder_path_on_hip_norm_blocks_matches_the_pytorch_path():
+    """SmokePhysNet.encode_frames in train mode at 128^2: conv (MIOpen) + libsmokehip BatchNorm/ReLU/pool against the all-PyTorch
+    module path (linear_dtype='f32' disables the HIP route): features, input-encoder gradients, running statistics."""
+    import copy
+    from smokephysai_amd.models import SmokePhysNet
+    torch.manual_seed(2)
+    hip = SmokePhysNet(input_dim=32, hidden_dim=64, num_layers=1, num_heads=4).cuda().train()
+    ref = copy.deepcopy(hip)
+    ref.linear_dtype = "f32"
+    x = torch.rand(3, 1, 128, 128, device="cuda")
+    g = torch.randn(3, 128, 32, 32, device="cuda")
+    fh = hip.encode_frames(x)
+    fr = ref.encode_frames(x)
+    assert "HipBnReluPool" in type(fh.grad_fn).__name__ and "HipBnReluPool" not in type(fr.grad_fn).__name__
+    fh.backward(g)
+    fr.backward(g)
+
+    def err(a, b):
+        return rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    assert err(fh, fr) < 1e-5
+    scale = max(float(q.grad.abs().max()) for q in ref.input_encoder.parameters())
+    for (n, p), (_, q) in zip(hip.input_encoder.named_parameters(), ref.input_encoder.named_parameters()):
+        if float(q.grad.abs().max()) > 1e-3 * scale:
+            assert err(p.grad, q.grad) < 2e-3, n                            # fp32 conv weight gradients of MIOpen itself: ~1e-3 noise
+        else:                                                               # conv biases in front of a BatchNorm: gradient 0 (rounding noise)
+            assert float(p.grad.abs().max()) < 1e-3 * scale, n
+    for k in ("1.running_mean", "1.running_var", "4.running_mean", "4.running_var"):
+        assert err(hip.input_encoder.state_dict()[k], ref.input_encoder.state_dict()[k]) < 1e-5, k
