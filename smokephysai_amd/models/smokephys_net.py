@@ -120,6 +120,7 @@ class SmokePhysNet(nn.Module):
             P = H // 32
             mid = pool.output_size[0]              # first pool target; no up-sampling stage and whole-number windows: one P x P mean
             if (self.linear_dtype == "bf16x3" and x.is_cuda and x.dtype == torch.float32 and H == W and P in (4, 8) and W == 32 * P
+                    and type(bn1) is nn.BatchNorm2d and type(bn2) is nn.BatchNorm2d          # not SyncBatchNorm (cross-rank statistics)
                     and pool.output_size[0] == pool.output_size[1] and H % mid == 0 and mid % 32 == 0):
                 # libsmokehip: BatchNorm (batch statistics) + ReLU as two passes over the conv output, and for the second block
                 # the two average pools (one P x P block mean) in the same pass -- the 256 x 256 x 128 maps are never written
