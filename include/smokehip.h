@@ -276,6 +276,14 @@ int smk_attention_backward(const float *q, const float *k, const float *v, const
 int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const float *weight, const float *bias, double eps,
                   void *y, int64_t ldy, int32_t y_format, void *stream);
 
+/* Backward of smk_layernorm (autograd of nn.LayerNorm, train.py:89): dx [rows][ld_dx] from x, dy and weight (the row statistics
+ * are recomputed), dweight / dbias [D] as column sums over the rows added in a fixed order (deterministic).  `workspace`:
+ * smk_layernorm_bwd_workspace(D) bytes of device memory, caller-owned.  Same D limits as smk_layernorm. */
+int64_t smk_layernorm_bwd_workspace(int32_t D);
+int smk_layernorm_backward(const float *x, const float *dy, int64_t rows, int32_t D, int64_t ldx, int64_t ld_dy,
+                           const float *weight, double eps, float *dx, int64_t ld_dx, float *dweight, float *dbias,
+                           void *workspace, void *stream);
+
 /* ------------------------------------------------------------------ reconstruction head */
 /* Eval-mode SmokePhysNet.reconstruction_head (smokephys_net.py:57-66): ConvTranspose2d(64,32,4,2,1) + BN + ReLU ->
  * ConvTranspose2d(32,16,4,2,1) + BN + ReLU -> Conv2d(16,1,3,padding 1) -> Sigmoid.  Device pointers, PyTorch layouts:

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "smk_bn_relu_pool_backward": [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 5,
     "smk_layernorm": [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64,
                       C.c_int32, C.c_void_p],
+    "smk_layernorm_backward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_double, C.c_void_p,
+                               C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_decoder_create": [C.POINTER(SmkDecoderWeights), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
     "smk_decoder_destroy": [C.c_void_p],
     "smk_decoder_forward": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -87,7 +89,7 @@ _SIGNATURES = {
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
-EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace"] + list(_SIGNATURES)
+EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace"] + list(_SIGNATURES)
 
 _lib = None
 
@@ -111,6 +113,8 @@ def load():
         L.smk_linear_wgrad_workspace.restype = C.c_int64          # a byte count, not a status
         L.smk_bn_train_workspace.argtypes = [C.c_int32] * 5
         L.smk_bn_train_workspace.restype = C.c_int64
+        L.smk_layernorm_bwd_workspace.argtypes = [C.c_int32]
+        L.smk_layernorm_bwd_workspace.restype = C.c_int64
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -735,6 +735,25 @@ int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const fl
     return check_launch(launch_layernorm(a, (hipStream_t)stream), "layernorm");
 }
 
+int64_t smk_layernorm_bwd_workspace(int32_t D) { return D >= 1 ? (int64_t)LN_BWD_WGS * 2 * D * (int64_t)sizeof(float) : 0; }
+
+int smk_layernorm_backward(const float *x, const float *dy, int64_t rows, int32_t D, int64_t ldx, int64_t ld_dy,
+                           const float *weight, double eps, float *dx, int64_t ld_dx, float *dweight, float *dbias,
+                           void *workspace, void *stream) {
+    SMK_REQUIRE(x && dy && weight && dx && dweight && dbias && workspace, "null pointer");
+    SMK_REQUIRE(rows >= 1 && rows < (1LL << 31) - 4, "1 <= rows < 2^31");
+    if (D < 4 || D % 4 != 0 || D > 2048) {
+        set_error("layernorm: HIP path is built for D a multiple of 4, at most 2048");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    SMK_REQUIRE(ldx >= D && ld_dy >= D && ld_dx >= D && ldx % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0, "row pitches >= D, multiples of 4 floats");
+    SMK_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)weight | (uintptr_t)workspace) & 15) == 0, "16-byte aligned tensors");
+    LayerNormBwdArgs a;
+    a.x = x; a.dy = dy; a.w = weight; a.dx = dx; a.dw = dweight; a.db = dbias; a.part = (float *)workspace;
+    a.ldx = ldx; a.lddy = ld_dy; a.lddx = ld_dx; a.rows = (int)rows; a.D = D; a.eps = (float)eps;
+    return check_launch(launch_layernorm_bwd(a, (hipStream_t)stream), "layernorm_bwd");
+}
+
 // ------------------------------------------------------------------ reconstruction head
 int smk_decoder_create(const smk_decoder_weights *w, int32_t device_id, void *stream, smk_decoder **out) {
     SMK_REQUIRE(w && out, "null weights/out");

@@ -46,4 +46,18 @@ struct LayerNormArgs {
 };
 hipError_t launch_layernorm(const LayerNormArgs &a, hipStream_t st);
 
+// Backward of that LayerNorm (autograd, train.py:89): dx per row, dw / db as column sums over the rows (two-stage, fixed order).
+struct LayerNormBwdArgs {
+    const float *x, *dy;                 // [rows][ld*]
+    const float *w;                      // [D]
+    float *dx;                           // [rows][lddx]
+    float *dw, *db;                      // [D]
+    float *part;                         // workspace [LN_BWD_WGS][2][D]
+    long long ldx, lddy, lddx;
+    int rows, D;
+    float eps;
+};
+constexpr int LN_BWD_WGS = 1024;
+hipError_t launch_layernorm_bwd(const LayerNormBwdArgs &a, hipStream_t st);
+
 }  // namespace smk

@@ -637,6 +637,130 @@ __global__ __launch_bounds__(256) void k_layernorm(const LayerNormArgs a) {
     }
 }
 
+// Backward: a wave walks rows (row in registers, statistics recomputed), writes dx = rstd (g - mean(g) - xhat mean(g xhat)) with g = dy w and
+// keeps per-lane column partials of dy xhat and dy; the 4 waves of a workgroup merge theirs through LDS into one [2][D] partial, and
+// k_layernorm_bwd_finish adds the LN_BWD_WGS partials per column in a fixed order (deterministic, no atomics).
+template <int NV>
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const LayerNormBwdArgs a) {
+    __shared__ float red[3][2][NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 wv[NV], dwp[NV], dbp[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        wv[i] = c < a.D ? *reinterpret_cast<const float4 *>(a.w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dwp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dbp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float invD = 1.0f / (float)a.D;
+    for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+        const float *xp = a.x + (long long)row * a.ldx, *gp = a.dy + (long long)row * a.lddy;
+        float4 v[NV], g[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const bool ok = c < a.D;
+            v[i] = ok ? *reinterpret_cast<const float4 *>(xp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[i] = ok ? *reinterpret_cast<const float4 *>(gp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum * invD;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < a.D) {
+                const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = 1.0f / sqrtf(sq * invD + a.eps);
+        float s1 = 0.f, s2 = 0.f;                              // sum(g w), sum(g w xhat)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < a.D) {
+                const float xh[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+                const float gy[4] = {g[i].x, g[i].y, g[i].z, g[i].w}, ww[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
+                dwp[i].x += gy[0] * xh[0]; dwp[i].y += gy[1] * xh[1]; dwp[i].z += gy[2] * xh[2]; dwp[i].w += gy[3] * xh[3];
+                dbp[i].x += gy[0]; dbp[i].y += gy[1]; dbp[i].z += gy[2]; dbp[i].w += gy[3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gw = gy[j] * ww[j];
+                    s1 += gw;
+                    s2 += gw * xh[j];
+                }
+                v[i] = make_float4(xh[0], xh[1], xh[2], xh[3]);                 // keep xhat
+                g[i] = make_float4(gy[0] * ww[0], gy[1] * ww[1], gy[2] * ww[2], gy[3] * ww[3]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float c1 = s1 * invD, c2 = s2 * invD;
+        float *dp = a.dx + (long long)row * a.lddx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < a.D)
+                *reinterpret_cast<float4 *>(dp + c) = make_float4(rstd * (g[i].x - c1 - v[i].x * c2), rstd * (g[i].y - c1 - v[i].y * c2),
+                                                                  rstd * (g[i].z - c1 - v[i].z * c2), rstd * (g[i].w - c1 - v[i].w * c2));
+        }
+    }
+    // merge the four waves' column partials (waves 1..3 park theirs, wave 0 adds them in wave order)
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            *reinterpret_cast<float4 *>(&red[wave - 1][0][(i * 64 + lane) * 4]) = dwp[i];
+            *reinterpret_cast<float4 *>(&red[wave - 1][1][(i * 64 + lane) * 4]) = dbp[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *pw = a.part + (size_t)blockIdx.x * 2 * a.D, *pb = pw + a.D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < a.D) {
+                float4 sw = dwp[i], sb = dbp[i];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 tw = *reinterpret_cast<const float4 *>(&red[k][0][c]), tb = *reinterpret_cast<const float4 *>(&red[k][1][c]);
+                    sw.x += tw.x; sw.y += tw.y; sw.z += tw.z; sw.w += tw.w;
+                    sb.x += tb.x; sb.y += tb.y; sb.z += tb.z; sb.w += tb.w;
+                }
+                *reinterpret_cast<float4 *>(pw + c) = sw;
+                *reinterpret_cast<float4 *>(pb + c) = sb;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_layernorm_bwd_finish(const LayerNormBwdArgs a, int nwg) {
+    const int c = blockIdx.x * 256 + threadIdx.x;                // column of [dw | db]
+    if (c >= 2 * a.D) return;
+    float acc = 0.f;
+    for (int k = 0; k < nwg; ++k) acc += a.part[(size_t)k * 2 * a.D + c];
+    (c < a.D ? a.dw : a.db - a.D)[c] = acc;
+}
+
+hipError_t launch_layernorm_bwd(const LayerNormBwdArgs &a, hipStream_t st) {
+    const int nwg = a.rows / 4 < LN_BWD_WGS ? (a.rows + 3) / 4 : LN_BWD_WGS;
+    const dim3 grid(nwg), block(256);
+    const int nv = (a.D + 255) / 256;
+    if (nv <= 1) hipLaunchKernelGGL(k_layernorm_bwd<1>, grid, block, 0, st, a);
+    else if (nv <= 2) hipLaunchKernelGGL(k_layernorm_bwd<2>, grid, block, 0, st, a);
+    else if (nv <= 4) hipLaunchKernelGGL(k_layernorm_bwd<4>, grid, block, 0, st, a);
+    else if (nv <= 8) hipLaunchKernelGGL(k_layernorm_bwd<8>, grid, block, 0, st, a);
+    else return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_layernorm_bwd_finish, dim3((2 * a.D + 255) / 256), block, 0, st, a, nwg);
+    return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const LayerNormArgs &a, hipStream_t st) {
     const dim3 grid((a.rows + 3) / 4), block(256);
     const int nv = (a.D + 255) / 256;

@@ -108,3 +108,47 @@ def hip_layernorm(x: torch.Tensor, ln: torch.nn.LayerNorm, out: Optional[torch.T
     _lib.check(_lib.load().smk_layernorm(x2.data_ptr(), x2.shape[0], D, x2.stride(0), ln.weight.data_ptr(), ln.bias.data_ptr(),
                                         float(ln.eps), out.data_ptr(), ldy, int(out_split), _lib.stream_ptr(dev)))
     return out
+
+
+class _HipLayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension with forward and backward on libsmokehip (smk_layernorm / smk_layernorm_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        dev = _lib.require_cuda(x.device, "hip_layernorm_train")
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+            x2 = x2.contiguous()
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        y = torch.empty(x.shape, device=dev, dtype=torch.float32)
+        _lib.check(_lib.load().smk_layernorm(x2.data_ptr(), x2.shape[0], D, x2.stride(0), w.data_ptr(), b.data_ptr(), float(eps),
+                                            y.data_ptr(), D, 0, _lib.stream_ptr(dev)))
+        ctx.save_for_backward(x2, w)
+        ctx.eps = float(eps)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        L = _lib.load()
+        dev = x2.device
+        rows, D = x2.shape
+        dy2 = dy.reshape(rows, D)
+        if dy2.stride(1) != 1 or dy2.stride(0) % 4 != 0 or dy2.data_ptr() % 16 != 0:
+            dy2 = dy2.contiguous()
+        dx = torch.empty(rows, D, device=dev, dtype=torch.float32)
+        dwb = torch.empty(2, D, device=dev, dtype=torch.float32)
+        ws = torch.empty(int(L.smk_layernorm_bwd_workspace(D)), device=dev, dtype=torch.uint8)
+        _lib.check(L.smk_layernorm_backward(x2.data_ptr(), dy2.data_ptr(), rows, D, x2.stride(0), dy2.stride(0), w.data_ptr(), ctx.eps,
+                                            dx.data_ptr(), D, dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), _lib.stream_ptr(dev)))
+        return dx.view(ctx.shape), dwb[0], dwb[1], None
+
+
+def hip_layernorm_train(x: torch.Tensor, ln: torch.nn.LayerNorm) -> torch.Tensor:
+    """Differentiable hip_layernorm (x [..., D] float32 on a ROCm device; ln with elementwise affine over the last dimension)."""
+    if ln.weight is None or ln.bias is None or tuple(ln.normalized_shape) != (x.shape[-1],):
+        raise ValueError("hip_layernorm_train: an affine LayerNorm over the last dimension")
+    return _HipLayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .attention import hip_layernorm_supported, hip_layernorm_train
 from .chaos_attention import ChaosAttention
 from .decoder import HipDecoder, decoder_weight_dict, hip_decoder_supported
 from .encoder import HipEncoder, encoder_weight_dict
@@ -83,7 +84,7 @@ class SmokePhysNet(nn.Module):
         self._hip_dec = None         # (HipDecoder, weight fingerprint)
         # training: the token-wise linear layers run their forward and input-gradient GEMMs on libsmokehip as well (models/linear.py)
         for m in self.modules():
-            if isinstance(m, (TrainableHipLinear, ChaosAttention)):
+            if isinstance(m, (TrainableHipLinear, ChaosAttention, ChaosTransformerLayer)):
                 m.hip_train = linear_dtype == "bf16x3"
 
     # copy.deepcopy / pickling of the module: the libsmokehip handles are per-instance device mirrors, rebuilt on first use
@@ -238,7 +239,15 @@ class ChaosTransformerLayer(nn.Module):
         self.ffn = nn.Sequential(TrainableHipLinear(dim, 4 * dim), nn.GELU(), nn.Dropout(dropout), TrainableHipLinear(4 * dim, dim),
                                  nn.Dropout(dropout))
 
+    hip_train = False        # set by SmokePhysNet(linear_dtype="bf16x3"): LayerNorm forward + backward on libsmokehip in training
+
+    def _norm(self, ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+        if (self.hip_train and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and hip_layernorm_supported(x.shape[-1])
+                and ln.weight is not None and ln.bias is not None):
+            return hip_layernorm_train(x, ln)
+        return ln(x)
+
     def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        x = x + self.chaos_attention(self.norm1(x), noise=noise)
-        x = x + self.ffn(self.norm2(x))
+        x = x + self.chaos_attention(self._norm(self.norm1, x), noise=noise)
+        x = x + self.ffn(self._norm(self.norm2, x))
         return x

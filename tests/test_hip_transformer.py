@@ -256,3 +256,32 @@ def test_chaos_attention_module_trains_on_the_hip_attention():
     for (n, p), (_, p64) in zip(attn.named_parameters(), ref_mod.named_parameters()):
         if float(p64.grad.abs().max()) > 1e-9 * scale:
             assert err(p.grad, p64.grad) < 1e-4, n
+
+
+@pytest.mark.parametrize("rows,D", [(4096, 512), (1030, 512), (37, 64), (300, 2048), (5, 132)])
+def test_layernorm_backward_matches_fp64_autograd(rows, D):
+    from smokephysai_amd.models.attention import hip_layernorm_train
+    torch.manual_seed(rows + D)
+    ln = torch.nn.LayerNorm(D).cuda()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(rows, D, device="cuda") * 2.0 + 1.0).requires_grad_(True)
+    dy = torch.randn(rows, D, device="cuda")
+    y = hip_layernorm_train(x, ln)
+    y.backward(dy)
+    ln64 = torch.nn.LayerNorm(D).cuda().double()
+    ln64.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    x64 = x.detach().double().requires_grad_(True)
+    y64 = ln64(x64)
+    y64.backward(dy.double())
+
+    def err(a, b):
+        return rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    assert err(y, y64) < 1e-5 and err(x.grad, x64.grad) < 1e-5
+    assert err(ln.weight.grad, ln64.weight.grad) < 1e-5 and err(ln.bias.grad, ln64.bias.grad) < 1e-5
+    g1 = (x.grad.clone(), ln.weight.grad.clone())
+    x.grad = None
+    ln.zero_grad()
+    hip_layernorm_train(x, ln).backward(dy)
+    assert torch.equal(x.grad, g1[0]) and torch.equal(ln.weight.grad, g1[1])
