@@ -5,7 +5,7 @@ constructor weights, same four public term methods, same forward(predictions, ta
 `mass_conservation`, `continuity`, `energy_conservation`, `divergence`, `total_physics_loss`).
 These are a handful of scalar reductions under autograd, so they stay PyTorch-ROCm tensor ops.
 """
-from typing import Callable, Dict, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn

@@ -23,7 +23,7 @@ from .decoder import HipDecoder, decoder_weight_dict, hip_decoder_supported
 from .encoder import HipEncoder, encoder_weight_dict
 from .hip_body import HipBody
 from .linear import TrainableHipLinear, hip_linear_supported
-from .norm import hip_bn_relu_pool, hip_bn_relu_pool_supported
+from .norm import hip_bn_relu_pool
 from .physics_regularizer import PhysicsRegularizer
 
 

@@ -1,5 +1,5 @@
 """Timing of smk_linear_forward (split-bf16 MFMA) against torch's fp32 GEMM at the transformer-body shapes."""
-import math, os, sys, time
+import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from smokephysai_amd.models.linear import HipLinear
