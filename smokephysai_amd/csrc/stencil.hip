@@ -182,8 +182,8 @@ __global__ void k_copy_cells(Geom g, const float *src, float *dst) {
 // ---- register-resident, temporally blocked Jacobi (one wave = one grid row, VEC = W/64 cells per lane) -------------
 // A workgroup of 16 waves holds a band of TR = 16*RPW full rows of p and div in registers and runs `iters` sweeps
 // without touching HBM: horizontal neighbours come from the adjacent lanes (DPP wave shifts), vertical neighbours
-// across waves through a double-buffered LDS edge exchange (one barrier per sweep).  Each band carries (TR-BR)/2
-// redundant halo rows on every non-physical side, so `iters` <= that many sweeps are exact on the BR owned rows
+// across waves through a double-buffered LDS edge exchange (one barrier per sweep).  Each band carries `halo`
+// redundant rows on every non-physical side, so `iters` <= that many sweeps are exact on the rows it owns
 // (the garbage front moves one row per sweep).  Per cell the arithmetic is exactly k_jacobi_sweep's.
 // bound_ctrl zero-fills the lane without a source (lane 0 / lane 63: grid-edge cells, whose neighbour value is never used), so no
 // copy of `x` into the destination is needed before the DPP move: one instruction per shift instead of two.
@@ -209,9 +209,14 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
     constexpr int TR = JB_NW * RPW, ROWF = 64 * VEC;
     __shared__ float edge[2][JB_NW][2][ROWF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, own0 = blockIdx.x * BR;
-    const int own1 = own0 + BR < g.H ? own0 + BR : g.H;
-    int r0 = own0 - (TR - BR) / 2;
+    // Bands own unequal row ranges: the first and last band of a grid need a halo only on their inner side (the other side is the
+    // physical boundary), so they own TR - HALO rows and the middle bands TR - 2 HALO (HALO = BR here).  One band: the whole grid.
+    const int b = blockIdx.y, nb = gridDim.x, halo = BR;
+    const int e_rows = TR - halo, m_rows = TR - 2 * halo;
+    const int own0 = blockIdx.x == 0 ? 0 : e_rows + ((int)blockIdx.x - 1) * m_rows;
+    int own1 = (int)blockIdx.x == nb - 1 ? g.H : e_rows + (int)blockIdx.x * m_rows;
+    own1 = own1 < g.H ? own1 : g.H;
+    int r0 = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == nb - 1 ? g.H - TR : own0 - halo);
     if (r0 > g.H - TR) r0 = g.H - TR;
     if (r0 < 0) r0 = 0;
     const int row0 = r0 + wave * RPW, j0 = lane * VEC;
@@ -377,11 +382,16 @@ static bool plan_jacobi(const Geom &g, JacobiPlan &pl) {
         if (TR > g.H) continue;
         for (int nb = 1; nb <= g.H / 8; ++nb) {
             if (env_nb && atoi(env_nb) != nb) continue;
-            const int br = (g.H + nb - 1) / nb;
-            if ((nb - 1) * br >= g.H) continue;               // last band would be empty
-            int halo = nb == 1 ? 1 << 20 : (TR - br) / 2;
-            if (br > TR || halo < 2) continue;
-            if (halo > 64) halo = 64;
+            // nb bands of TR rows cover H owned rows with a halo on every inner side: 2 (TR - h) + (nb - 2)(TR - 2h) >= H
+            int halo = nb == 1 ? 1 << 20 : (nb * TR - g.H) / (2 * nb - 2);
+            if (nb == 1 && TR != g.H) continue;
+            if (nb * TR < g.H || halo < 2) continue;
+            if (nb > 1) {
+                if (halo > 64) halo = 64;
+                if (halo > (TR - 1) / 2) halo = (TR - 1) / 2;          // middle bands keep at least one owned row
+                if ((TR - halo) + (nb - 2) * (TR - 2 * halo) >= g.H) continue;   // a smaller halo than the cover needs: the last band would own nothing
+            }
+            const int br = halo;                              // handed to the kernel (it derives the owned ranges from it)
             const double wgs = (double)nb * g.B, rounds = ceil(wgs / 256.0);
             // measured on MI355X (256^2 x 64, profiles/r01): ~6 us fixed per launch, ~1.33 us per sweep at 96 rows per
             // workgroup (barrier + LDS round trip bound, roughly linear in the rows a CU owns)
