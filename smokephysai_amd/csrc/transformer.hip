@@ -464,9 +464,20 @@ __global__ __launch_bounds__(256, 2) void k_attention_bwd_x3(const AttnBwdArgs a
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             // ---- S^T and T^T: acc[g] = value(outer r, inner 32kb + (g&3) + 8(g>>2) + 4hh)
+            // the accumulators start at -lse and -delta, so the MFMAs leave S - lse and dP - delta (no subtraction per element)
             f32x16 sacc, tacc;
+            if (DKV) {      // inner rows 32kb + 8 (g>>2) + 4hh + (g&3): the tile's lse / delta values from LDS
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { sacc[g] = 0.f; tacc[g] = 0.f; }
+                for (int q = 0; q < 4; ++q) {
+                    const float4 l4 = *reinterpret_cast<const float4 *>(scal + 32 * kb + 8 * q + 4 * hh);
+                    const float4 d4 = *reinterpret_cast<const float4 *>(scal + 64 + 32 * kb + 8 * q + 4 * hh);
+                    sacc[4 * q] = -l4.x; sacc[4 * q + 1] = -l4.y; sacc[4 * q + 2] = -l4.z; sacc[4 * q + 3] = -l4.w;
+                    tacc[4 * q] = -d4.x; tacc[4 * q + 1] = -d4.y; tacc[4 * q + 2] = -d4.z; tacc[4 * q + 3] = -d4.w;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { sacc[g] = -lse_o; tacc[g] = -del_o; }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 yh = *reinterpret_cast<const bf16x8 *>(yr_h + kb * 32 * AB_RPITCH + s * 32);
@@ -481,23 +492,15 @@ __global__ __launch_bounds__(256, 2) void k_attention_bwd_x3(const AttnBwdArgs a
                 tacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, uh[s], tacc, 0, 0, 0);
             }
 
-            // ---- P = exp2(S - lse), dS = scale * P * (dP - delta); both end up as B fragments (k = inner row, column = outer row r)
+            // ---- P = exp2(S - lse), dS = P * (dP - delta) (x scale at the end); both end up as B fragments (k = inner row, column = outer row r)
             bf16x8 dsh[2], dsl[2], ph[2], pl[2];
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
-                const int s4 = 2 * kb + sl;
-                float l8[8], d8[8];
-                if (DKV) {      // inner rows 16 s4 + 8 (j>>2) + 4hh + (j&3): two float4 each
-                    const float4 la = *reinterpret_cast<const float4 *>(scal + 16 * s4 + 4 * hh), lb = *reinterpret_cast<const float4 *>(scal + 16 * s4 + 8 + 4 * hh);
-                    const float4 da = *reinterpret_cast<const float4 *>(scal + 64 + 16 * s4 + 4 * hh), db_ = *reinterpret_cast<const float4 *>(scal + 64 + 16 * s4 + 8 + 4 * hh);
-                    l8[0] = la.x; l8[1] = la.y; l8[2] = la.z; l8[3] = la.w; l8[4] = lb.x; l8[5] = lb.y; l8[6] = lb.z; l8[7] = lb.w;
-                    d8[0] = da.x; d8[1] = da.y; d8[2] = da.z; d8[3] = da.w; d8[4] = db_.x; d8[5] = db_.y; d8[6] = db_.z; d8[7] = db_.w;
-                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int g = 8 * sl + j;
-                    const float p = __builtin_amdgcn_exp2f(sacc[g] - (DKV ? l8[j] : lse_o));
-                    const float ds = a.scale * p * (tacc[g] - (DKV ? d8[j] : del_o));
+                    const float p = __builtin_amdgcn_exp2f(sacc[g]);
+                    const float ds = p * tacc[g];                      // the softmax scale is applied once, to the finished out1 accumulators
                     const __bf16 dt = (__bf16)ds;
                     dsh[sl][j] = dt;
                     dsl[sl][j] = (__bf16)(ds - (float)dt);
@@ -555,7 +558,8 @@ __global__ __launch_bounds__(256, 2) void k_attention_bwd_x3(const AttnBwdArgs a
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
-            *reinterpret_cast<float4 *>(p1 + 32 * db + 8 * q4) = make_float4(o1[db][4 * q4], o1[db][4 * q4 + 1], o1[db][4 * q4 + 2], o1[db][4 * q4 + 3]);
+            *reinterpret_cast<float4 *>(p1 + 32 * db + 8 * q4) = make_float4(a.scale * o1[db][4 * q4], a.scale * o1[db][4 * q4 + 1],
+                                                                             a.scale * o1[db][4 * q4 + 2], a.scale * o1[db][4 * q4 + 3]);
     if (DKV) {
         float *p2 = a.dv + orow * a.lddv + head * 64 + 4 * hh;
 #pragma unroll
