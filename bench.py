@@ -139,6 +139,37 @@ def inference_ms(dev, N, frames, encoder_dtype):
     return res
 
 
+def train_step_ms(dev, N, B, steps=3):
+    """train.py's step (zero_grad, batch_losses, backward, clip 1.0, AdamW) on a device-built batch; ms per step."""
+    import train
+    from smokephysai_amd.models import SmokePhysNet
+    from smokephysai_amd.models.physics_regularizer import PhysicsRegularizer
+    torch.manual_seed(0)
+    model = SmokePhysNet().to(dev).train()
+    reg = PhysicsRegularizer()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    seq = torch.rand(B, 20, N, N, device=dev)
+    batch = {"input": seq[:, 9:10].contiguous(), "target": seq[:, 10:11].contiguous(),
+             "chaos_features": torch.rand(B, 3, device=dev), "sequence": seq}
+
+    def step():
+        opt.zero_grad()
+        total = train.batch_losses(model, reg, batch, dev)[0]
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        opt.step()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3, "batch": B, "grid": N,
+            "note": "forward + backward + clip + AdamW; linear GEMMs, attention, LayerNorm and the encoder's BatchNorm/ReLU/pool on libsmokehip, "
+                    "convolutions / GELU / dropout on PyTorch-ROCm"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +186,9 @@ def main():
     ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
     ap.add_argument("--no-alt", action="store_true", help="time only --encoder-dtype (profiling runs)")
     ap.add_argument("--no-inference", action="store_true", help="skip the per-frame inference-ms measurement (metric M2)")
+    ap.add_argument("--train-step", action="store_true",
+                    help="also time train.py's optimisation step (BASELINE configs[3]'s per-GPU shape: --batch frames of --grid^2, full model; "
+                         "adds about a minute: MIOpen tunes its convolutions on first use)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -285,6 +319,8 @@ def main():
             out["hbm_copy_measured_GBs"] = hbm_copy_gbs(dev)
         if world == 1 and not args.no_encode and not args.no_inference:
             out["inference_ms_per_frame"] = inference_ms(dev, N, frame, args.encoder_dtype)
+        if world == 1 and args.train_step:
+            out["train_step"] = train_step_ms(dev, N, B)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
         print(json.dumps(out), flush=True)
