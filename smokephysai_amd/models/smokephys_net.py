@@ -11,6 +11,7 @@ token mean are PyTorch-ROCm ops.
 Training (train mode): the encoder runs as autograd-tracked PyTorch ops with batch-statistics BatchNorm, exactly the
 reference's op sequence (smokephys_net.py:87-91).
 """
+import warnings
 from typing import Optional
 
 import torch
@@ -113,9 +114,34 @@ class SmokePhysNet(nn.Module):
             self._hip = (HipEncoder(encoder_weight_dict(self.input_encoder), device=dev), fp)
         return self._hip[0]
 
+    def _encoder_route(self, x: torch.Tensor) -> str:
+        """Which implementation of input_encoder + pools serves this call:
+        'train'   -- module in train mode: batch statistics (and their running update), as nn.BatchNorm2d does with or without grad;
+        'modules' -- eval mode, but a gradient is wanted through the encoder (the fused kernel is forward-only), or a frame shape the
+                     fused kernel is not built for on a ROCm device (a warning is issued once);
+        'hip'     -- the fused libsmokehip encoder (eval, no gradient; raises off-GPU: no CPU fallback)."""
+        if self.training:
+            return "train"
+        if not x.is_cuda:
+            return "hip"                           # eval off-GPU: the product refuses (no CPU fallback)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.input_encoder.parameters())):
+            return "modules"
+        H, W = x.shape[-2:]
+        ok = H == W and H in (64, 128, 256) and self.input_dim % 32 == 0 and (self.input_dim % H == 0 or H % self.input_dim == 0)
+        if not ok:
+            if not self.__dict__.get("_warned_shape"):
+                self.__dict__["_warned_shape"] = True
+                warnings.warn(f"SmokePhysNet: frames of {H}x{W} are outside the fused HIP encoder's shapes (square 64/128/256); "
+                              "this call runs input_encoder on PyTorch-ROCm ops", stacklevel=3)
+            return "modules"
+        return "hip"
+
     def encode_frames(self, x: torch.Tensor, dtype: Optional[str] = None) -> torch.Tensor:
         """input_encoder + both pools (smokephys_net.py:87-91): [B,1,H,W] -> [B,128,32,32]."""
-        if self.training and torch.is_grad_enabled():
+        route = self._encoder_route(x)
+        if route == "modules":                     # eval-mode BatchNorm through the PyTorch-ROCm modules (differentiable; any frame size)
+            return F.adaptive_avg_pool2d(self.input_encoder(x), (32, 32))
+        if route == "train":
             conv1, bn1, _, conv2, bn2, _, pool = self.input_encoder
             H, W = x.shape[-2:]
             P = H // 32
@@ -200,7 +226,7 @@ class SmokePhysNet(nn.Module):
         B = x.shape[0]
         pool_size = 32
         dt = encoder_dtype or self.encoder_dtype
-        if not (self.training and torch.is_grad_enabled()) and dt in ("bf16x3", "bf16"):
+        if self._encoder_route(x) == "hip" and dt in ("bf16x3", "bf16"):
             # the bf16 MFMA kernels write the token-major layout feature_proj consumes (smokephys_net.py:95) directly
             flattened = self.hip_encoder().tokens(x, input_dim=self.input_dim, dtype=dt)
         else:

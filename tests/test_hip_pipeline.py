@@ -264,6 +264,30 @@ def test_short_training_run_tracks_the_all_pytorch_path():
     assert min(hip[1:]) < 0.2 * hip[0] and min(ref[1:]) < 0.2 * ref[0], (hip, ref)
 
 
+def test_eval_forward_routes_gradients_and_other_frame_sizes_through_the_modules():
+    """The fused encoder kernel is forward-only and built for square 64/128/256 frames: an eval forward that wants a gradient through
+    the encoder, or sees another frame size, runs input_encoder on PyTorch-ROCm ops instead (same numbers within 1e-4)."""
+    import warnings
+    torch.manual_seed(0)
+    model = SmokePhysNet(input_dim=32, hidden_dim=128, num_layers=1, num_heads=2, output_channels=16).cuda().eval()
+    x = torch.rand(2, 1, 128, 128, device="cuda")
+    noise = torch.randn(1, 3, 2, 1, device="cuda")
+    with torch.no_grad():
+        fast = model(x, chaos_noise=noise)                               # fused HIP encoder + HIP body
+    slow = model(x, chaos_noise=noise)                                   # grad enabled: differentiable route
+    assert slow["reconstructed"].grad_fn is not None and fast["reconstructed"].grad_fn is None
+    for k in fast:
+        assert rel_err(slow[k].detach().cpu().numpy(), fast[k].cpu().numpy()) < 1e-4, k
+    slow["reconstructed"].sum().backward()
+    assert model.input_encoder[0].weight.grad is not None and float(model.input_encoder[0].weight.grad.abs().max()) > 0
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        odd = model(torch.rand(2, 1, 96, 160, device="cuda"), chaos_noise=noise)
+    assert odd["reconstructed"].shape == (2, 1, 128, 128) and any("outside the fused HIP encoder" in str(m.message) for m in w)
+    ref = torch.nn.functional.adaptive_avg_pool2d(model.input_encoder(torch.rand(1, 1, 96, 160, device="cuda")), (32, 32))
+    assert ref.shape == (1, 128, 32, 32)
+
+
 def test_train_losses_at_256_pool_the_target():
     """BASELINE config 4 trains on 256^2 grids; the head emits 128^2 (the reference's loss raises there): the target is
     block-averaged to the head's resolution."""
