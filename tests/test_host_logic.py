@@ -125,6 +125,19 @@ def test_full_model_init_matches_reference_checksums(golden):
         np.testing.assert_allclose(got, cs, rtol=1e-12, atol=1e-9, err_msg=k)
 
 
+def test_encoder_route_selection_on_host_tensors():
+    """Train mode always means batch-statistics semantics (with or without grad); eval off-GPU is the fused-kernel route, which refuses."""
+    model = SmokePhysNet(input_dim=32, hidden_dim=64, num_layers=1, num_heads=4)
+    x = torch.zeros(1, 1, 64, 64)
+    assert model.train()._encoder_route(x) == "train"
+    with torch.no_grad():
+        assert model._encoder_route(x) == "train"
+    assert model.eval()._encoder_route(x) == "hip"
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        with torch.no_grad():
+            model(x)
+
+
 def test_model_deepcopy_drops_the_device_mirrors():
     """copy.deepcopy / pickling must not share (or try to pickle) libsmokehip handles: the copy rebuilds them on first use."""
     import copy
