@@ -125,6 +125,10 @@ class SmokePhysNet(nn.Module):
         if not x.is_cuda:
             return "hip"                           # eval off-GPU: the product refuses (no CPU fallback)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.input_encoder.parameters())):
+            if not self.__dict__.get("_warned_grad"):
+                self.__dict__["_warned_grad"] = True
+                warnings.warn("SmokePhysNet: eval forward with autograd enabled runs the differentiable PyTorch-ROCm route; wrap inference in "
+                              "torch.no_grad() to use the fused libsmokehip kernels", stacklevel=3)
             return "modules"
         H, W = x.shape[-2:]
         ok = H == W and H in (64, 128, 256) and self.input_dim % 32 == 0 and (self.input_dim % H == 0 or H % self.input_dim == 0)
