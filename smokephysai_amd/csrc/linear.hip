@@ -128,7 +128,7 @@ struct LinearArgs {
     int swz, stagger, stagger_unit, num_cu;
     unsigned long long *stamps;
     int dbg;              // timing ablations, honoured only by -DSMK_LN_DIAG builds (results are wrong when non-zero): 1 A loads re-read tile 0,
-                          // 2 B ring re-reads k-step 0, 4 no epilogue
+                          // 2 B ring re-reads k-step 0, 4 no epilogue, 8 epilogue stores as whole 128-byte row pieces
 };
 
 // AS: the activations arrive already split (SMK_FMT_SPLIT_BF16: per row, per 8 k: 8 hi | 8 lo bf16 -- the same 4 bytes per
@@ -450,6 +450,9 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                     __bf16 *ys = reinterpret_cast<__bf16 *>(a.c.y) + (size_t)row * (2 * N) + ((ncol >> 3) + q) * 16 + 4 * hi;
                     *reinterpret_cast<bf16x4 *>(ys) = vh;
                     *reinterpret_cast<bf16x4 *>(ys + 8) = vl;
+                } else if (LN_DBG(a, 8)) {   // timing ablation: the same bytes as 8 rows x 128 contiguous bytes per store instruction (values misplaced)
+                    const int L = r + 32 * hi, rr = row - r + 8 * q + (L >> 3);
+                    if (rr < M) *reinterpret_cast<float4 *>(y_seg + (long long)rr * a.c.ldy + (ncol - 4 * hi) + (L & 7) * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     *reinterpret_cast<float4 *>(y_seg + (long long)row * a.c.ldy + ncol + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
                 }
