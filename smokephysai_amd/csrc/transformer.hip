@@ -95,8 +95,11 @@ __device__ __forceinline__ void at_split4(const float4 &v, bf16x4 &h, bf16x4 &l)
 
 // KS = 2 (small grids: at most one workgroup per CU): 512 threads; wave group wave >> 2 takes half of the key tiles for the
 // same 128 queries, with its own LDS double buffer; the two partial (m, l, O) are merged through LDS at the end.
-template <int KS>
-__global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) {
+// SB (KS = 1 only): one LDS tile buffer instead of two (35,840 B): three workgroups per CU = 3 waves per SIMD (168 registers), two
+// barriers per tile; the next tile's global loads are still in flight during the MFMAs.  With 2 waves per SIMD the S -> softmax -> PV
+// chain of a wave is exposed (SQ counters: matrix pipe 43 % busy, VALU issue 49 %); a third wave fills part of it.
+template <int KS, bool SB = false>
+__global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
     unsigned char *smem = smem_all + grp * AT_LDS;
@@ -170,9 +173,11 @@ __global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) 
     };
 
     stage_load(0);
-    stage_store(0);
-    stage_load(1);
-    __syncthreads();
+    if (!SB) {
+        stage_store(0);
+        stage_load(1);
+        __syncthreads();
+    }
 
     f32x16 oacc[2];
 #pragma unroll
@@ -183,8 +188,13 @@ __global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) 
 
 #pragma unroll 1
     for (int t = 0; t < NT; ++t) {
-        const unsigned char *kb_h = smem + (t & 1) * AT_BUF + r * AT_KPITCH + hh * 16;
-        const unsigned char *vt_h = smem + (t & 1) * AT_BUF + 2 * AT_KPLANE + r * AT_VPITCH + hh * 8;
+        if (SB) {                                              // tile t -> the single buffer (every read of tile t-1 ended at the barrier below)
+            stage_store(0);
+            stage_load(t + 1);
+            __syncthreads();
+        }
+        const unsigned char *kb_h = smem + (SB ? 0 : (t & 1)) * AT_BUF + r * AT_KPITCH + hh * 16;
+        const unsigned char *vt_h = smem + (SB ? 0 : (t & 1)) * AT_BUF + 2 * AT_KPLANE + r * AT_VPITCH + hh * 8;
         // ---- S^T = K Q^T (log2 units): sacc[kb][g] = score(query r, key 32kb + (g&3) + 8(g>>2) + 4hh)
         f32x16 sacc[2];
 #pragma unroll
@@ -209,8 +219,10 @@ __global__ __launch_bounds__(256 * KS, 2) void k_attention_x3(const AttnArgs a) 
         }
         // the staged registers hold tile t+1: split + write it to the other buffer (its last reads ended before the barrier
         // that closed tile t-1), then re-issue the loads for tile t+2
-        if (t + 1 < NT) stage_store((t + 1) & 1);
-        stage_load(t + 2);
+        if (!SB) {
+            if (t + 1 < NT) stage_store((t + 1) & 1);
+            stage_load(t + 2);
+        }
 
         // ---- online softmax (per lane: its query's 32 of the tile's 64 keys; lane ^ 32 holds the other 32)
         float mx = sacc[0][0];
@@ -341,7 +353,10 @@ hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
     // a grid that leaves the second workgroup slot of every CU empty runs the split-KV form instead (8 waves per CU either way)
     int ks = (nwg <= num_cu && (a.L / AT_KV) % 2 == 0) ? 2 : 1;
     if ((force_ks == 1 || force_ks == 2) && (a.L / AT_KV) % force_ks == 0) ks = force_ks;
+    static int sb = -1;
+    if (sb < 0) { const char *sv = getenv("SMK_ATTN_SB"); sb = sv ? atoi(sv) : 1; }     // measured at B = 64: 553 -> 535 us (interleaved A/B)
     if (ks == 2) hipLaunchKernelGGL(k_attention_x3<2>, dim3(nwg), dim3(512), 2 * AT_LDS, st, a);
+    else if (sb && nwg > 2 * num_cu) hipLaunchKernelGGL((k_attention_x3<1, true>), dim3(nwg), dim3(256), AT_BUF, st, a);
     else hipLaunchKernelGGL(k_attention_x3<1>, dim3(nwg), dim3(256), AT_LDS, st, a);
     return hipGetLastError();
 }
