@@ -7,7 +7,15 @@ Jacobi pressure projection, three advections, fractal frame emit) + the fused CN
 (256^2 grid, batch 64, Jacobi-100).  Grids are independent: ranks own disjoint grids, no data-path collective
 ("scaling": "weak", batch 64 per GPU).
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N>1 runs one process per GPU over RCCL.  Either the caller starts the ranks (python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* come from the environment) or plain
+`python bench.py --gpus N` starts them itself: with WORLD_SIZE unset the parent spawns torch.distributed.run as a child
+process BEFORE anything touches the GPU, relays the children's output (rank 0's single JSON line) and exits with their
+code (`--dry-run` prints the launch command instead).  The data path has no collective; the `train_step` block is the
+one place a collective runs: train.py's optimisation step under DistributedDataParallel (configs[3]'s per-GPU shape,
+27.8 M fp32 gradients = 111 MB all-reduced per step over RCCL), timed with the same barrier + max-over-ranks rule.
 
 Prints ONE JSON line on rank 0.  `roofline*` use SURVEY.md 8(d)'s algorithmic figures: stencil 4*(27+3J) bytes per
 cell per step against HBM 8 TB/s; encoder 153,728*N^2 flop per frame against the dense MFMA peak of the dtype.
@@ -139,38 +147,163 @@ def inference_ms(dev, N, frames, encoder_dtype):
     return res
 
 
-def train_step_ms(dev, N, B, steps=3):
-    """train.py's step (zero_grad, batch_losses, backward, clip 1.0, AdamW) on a device-built batch; ms per step."""
+def source_stamp():
+    """sha256 over the kernel sources + ABI header (what the committed rocprofv3 counter extracts under profiles/ were
+    taken on; tools/stamp_profiles.py writes the same hash into them).  The built .so is hashed too, for the record."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "smokephysai_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "smokephysai_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "smokephysai_amd", "csrc", "Makefile"), os.path.join(ROOT, "include", "smokehip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    so = os.path.join(ROOT, "smokephysai_amd", "libsmokehip.so")
+    lib = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16] if os.path.exists(so) else None
+    return {"csrc_sha256": h.hexdigest()[:16], "lib_sha256": lib}
+
+
+def attach_counters(out, encoder_dtype):
+    """roofline*.traffic / .pmc come from rocprofv3 --pmc passes (tools/profile.sh, tools/pmc_encoder.sh) committed under
+    profiles/: they are REPLAYED here, not measured live, so each carries the stamp of the sources it was taken on and
+    `stale` says whether this build's kernel sources differ from that stamp."""
+    now = source_stamp()
+    out["build_stamp"] = now
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        tr = json.load(open(pmc))
+        st = tr.get("stamp", {})
+        stale = st.get("csrc_sha256") != now["csrc_sha256"]
+        for key, kname in (("roofline_stencil", "stencil"), ("roofline_encoder", "encoder")):
+            if key in out and kname in tr and tr.get("encoder_dtype", "bf16x3") == encoder_dtype:
+                r = out[key]
+                r["traffic"] = tr[kname]
+                r["traffic_source"] = {"file": "profiles/pmc_traffic.json (replayed from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                                       "stamp": st, "stale": stale}
+                # the honest HBM figure: bytes seen at the counters / live launch time, against the 8 TB/s pin rate
+                r["measured_GBs"] = tr[kname] / (r["ms_per_launch"] * 1e-3) / 1e9
+                r["frac_measured"] = r["measured_GBs"] / HBM_PEAK_GBS
+        if "roofline_stencil" in out and "detail" in tr:
+            out["roofline_stencil"]["traffic_by_kernel"] = {
+                k: round(v.get("fetch_bytes_per_dispatch", 0) + v.get("write_bytes_per_dispatch", 0))
+                for k, v in tr["detail"].items() if any(s in k for s in ("k_jacobi", "k_buoy", "k_advect", "k_grad", "k_div", "k_step"))}
+    sq = os.path.join(ROOT, "profiles", "pmc_mfma.json")
+    if os.path.exists(sq) and "roofline_encoder" in out and encoder_dtype == "bf16x3":
+        d = json.load(open(sq))
+        d["stale"] = d.get("stamp", {}).get("csrc_sha256") != now["csrc_sha256"]
+        out["roofline_encoder"]["pmc"] = d
+
+
+def train_step_leg(dev, N, B, dist, world, backend, steps=4):
+    """train.py's step (zero_grad, batch_losses, backward, clip 1.0, AdamW) on a device-built batch of B frames per rank
+    (BASELINE configs[3]'s per-GPU shape), the model wrapped by utils.distributed.wrap_ddp exactly like train.py:main does:
+    with N > 1 ranks the 27.8 M fp32 gradients (111 MB) are all-reduced over RCCL in 64 MB buckets overlapped with backward.
+    Timing rule of the headline: barrier + synchronize on both sides, max over ranks."""
     import train
     from smokephysai_amd.models import SmokePhysNet
     from smokephysai_amd.models.physics_regularizer import PhysicsRegularizer
+    from smokephysai_amd.utils.distributed import ddp_bucket_report, wrap_ddp
+    rank = dist.get_rank() if dist is not None else 0
     torch.manual_seed(0)
     model = SmokePhysNet().to(dev).train()
+    ddp = wrap_ddp(model, dev)
     reg = PhysicsRegularizer()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
-    seq = torch.rand(B, 20, N, N, device=dev)
+    opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3, weight_decay=0.01)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)                 # every rank its own frames
+    seq = torch.rand(B, 20, N, N, device=dev, generator=g)
     batch = {"input": seq[:, 9:10].contiguous(), "target": seq[:, 10:11].contiguous(),
-             "chaos_features": torch.rand(B, 3, device=dev), "sequence": seq}
+             "chaos_features": torch.rand(B, 3, device=dev, generator=g), "sequence": seq}
 
-    def step():
+    def step(sync=True):
+        import contextlib
         opt.zero_grad()
-        total = train.batch_losses(model, reg, batch, dev)[0]
-        total.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        ctx = contextlib.nullcontext() if sync or ddp is model else ddp.no_sync()
+        with ctx:
+            total = train.batch_losses(ddp, reg, batch, dev)[0]
+            total.backward()
+        torch.nn.utils.clip_grad_norm_(ddp.parameters(), max_norm=1.0)
         opt.step()
+
+    def timed(n, sync=True):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(sync)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el / n * 1e3
+
     for _ in range(2):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    return {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3, "batch": B, "grid": N,
-            "note": "forward + backward + clip + AdamW; linear GEMMs, attention, LayerNorm and the encoder's BatchNorm/ReLU/pool on libsmokehip, "
-                    "convolutions / GELU / dropout on PyTorch-ROCm"}
+    ms = timed(steps)
+    nparam = sum(p.numel() for p in model.parameters())
+    res = {"ms_per_step": ms, "frames_per_s": world * B / (ms * 1e-3), "batch_per_gpu": B, "global_batch": world * B, "grid": N,
+           "rccl_ranks": world if (dist is not None and backend == "nccl") else 0, "ranks": world,
+           "collective_backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None,
+           "grad_bytes_fp32": nparam * 4,
+           "note": "forward + backward + gradient all-reduce (DDP, overlapped) + clip + AdamW; linear GEMMs, attention, LayerNorm and the "
+                   "encoder's BatchNorm/ReLU/pool on libsmokehip, convolutions / GELU / dropout on PyTorch-ROCm"}
+    if dist is not None:
+        res["ms_per_step_no_allreduce"] = timed(steps, sync=False)          # same step under ddp.no_sync(): what the exchange costs
+        res["ddp_buckets"] = ddp_bucket_report(ddp)
+        # the gradient exchange alone: one flat fp32 all-reduce of the same byte count (algorithm bandwidth = bytes / time;
+        # bus bandwidth = 2 (n-1)/n of that -- a ring on xGMI is bound by one 153 GB/s link, SURVEY.md section 5)
+        flat = torch.zeros(nparam, device=dev if backend == "nccl" else "cpu")
+        for _ in range(2):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        ar = (time.perf_counter() - t0) / 5
+        res["allreduce_flat"] = {"bytes": nparam * 4, "ms": ar * 1e3, "algbw_GBs": nparam * 4 / ar / 1e9,
+                                 "busbw_GBs": nparam * 4 / ar / 1e9 * 2 * (world - 1) / world}
+    return res
 
 
-def main():
+def second_config(dev, rank, K, W):
+    """BASELINE configs[1] -- 128x128 grid, batch 32, Jacobi-20 (the reference's own J), CNN encoder fp32 -- through the same
+    step (stepper + encoder per step, HBM-resident), so that it is driver-timed too; this rank's HIP events only."""
+    from smokephysai_amd.models.encoder import HipEncoder
+    from smokephysai_amd.physics import SmokeSimulator
+    B, N, J = 32, 128, 20
+    sim = SmokeSimulator((N, N), device=dev, batch_size=B, jacobi_iters=J)
+    sim.ns_solver.add_smoke_sources(draw_sources(B, N, seed=100 + rank))
+    enc = HipEncoder(encoder_weights(0), device=dev)
+    frame = torch.empty(B, N, N, device=dev)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    for k in range(-W, K):
+        if k >= 0: ev[k][0].record()
+        sim.ns_solver.step_into(frame, 1, add_fractal=True, fractal_intensity=0.05)
+        if k >= 0: ev[k][1].record()
+        feats = enc(frame, input_dim=128, dtype="f32")
+        if k >= 0: ev[k][2].record()
+    torch.cuda.synchronize()
+    assert torch.isfinite(feats).all()
+    ms_sim = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_enc = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    ms = float(np.mean([e[0].elapsed_time(e[2]) for e in ev]))
+    sten = B * N * N * 4.0 * (27 + 3 * J) / (ms_sim * 1e-3) / 1e9
+    tf = B * 153728.0 * N * N / (ms_enc * 1e-3) / 1e12
+    return {"workload": f"configs[1]: {N}x{N} grid, batch {B}, Jacobi-{J}, CNN encoder fp32", "value": B / (ms * 1e-3), "unit": "frames/s",
+            "ms_per_step": ms, "ms_sim_per_step": ms_sim, "ms_encode_per_step": ms_enc, "steps": K, "dtype": "f32",
+            "timing": "HIP events on the launch stream (mean over the timed steps of this process)",
+            "roofline_stencil": {"bound": "hbm", "achieved": sten, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sten / HBM_PEAK_GBS},
+            "roofline_encoder": {"bound": "mfma", "kernel": "k_encoder_f32 (v_mfma_f32_32x32x2_f32)", "achieved": tf,
+                                 "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS["f32"]}}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -186,16 +319,66 @@ def main():
     ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
     ap.add_argument("--no-alt", action="store_true", help="time only --encoder-dtype (profiling runs)")
     ap.add_argument("--no-inference", action="store_true", help="skip the per-frame inference-ms measurement (metric M2)")
-    ap.add_argument("--train-step", action="store_true",
-                    help="also time train.py's optimisation step (BASELINE configs[3]'s per-GPU shape: --batch frames of --grid^2, full model; "
-                         "adds about a minute: MIOpen tunes its convolutions on first use)")
-    args = ap.parse_args()
+    ap.add_argument("--no-config1", action="store_true", help="skip the secondary configs[1] block (128^2 x 32, Jacobi-20, fp32 encoder)")
+    ap.add_argument("--train-step", dest="train_step", action="store_true", default=None,
+                    help="time train.py's optimisation step (BASELINE configs[3]'s per-GPU shape: --batch frames of --grid^2, full model; "
+                         "under DistributedDataParallel when N > 1). Default: on when N > 1 (that is where the RCCL gradient all-reduce "
+                         "runs), off at N = 1 (adds about a minute: MIOpen tunes its convolutions on first use)")
+    ap.add_argument("--no-train-step", dest="train_step", action="store_false")
+    ap.add_argument("--train-step-limit", type=float, default=420.0,
+                    help="seconds after which a stuck train-step leg is abandoned: rank 0 prints the headline line without it")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
+    ap.add_argument("--dry-run", action="store_true", help="self-launch only: print the child command as JSON and exit")
+    return ap.parse_args(argv)
+
+
+def launch_command(args, argv):
+    """The child command of a self-launched N>1 run: one torch.distributed.run agent that starts one rank per GPU."""
+    port = args.master_port
+    if not port:
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    child = [a for a in argv if a != "--dry-run"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no torchrun environment: start the ranks as fresh child processes.  This parent has
+    not touched the GPU (importing torch does not initialise HIP) and never execs: it waits, relays, and returns the code."""
+    import subprocess
+    cmd = launch_command(args, argv)
+    if args.dry_run:
+        print(json.dumps({"launch": cmd, "n_gpus": args.gpus}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    lines = 0
+    for line in proc.stdout:                                     # rank 0's single JSON line (anything else is passed through to stderr)
+        if line.startswith("{") and '"metric"' in line:
+            sys.stdout.write(line); sys.stdout.flush(); lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: expected one JSON line from rank 0, saw {lines}", file=sys.stderr)
+        return 1
+    return rc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run):
+        raise SystemExit(self_launch(args, argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     # one process per GPU; SMK_BENCH_BACKEND=gloo lets a 1-GPU box rehearse the N>1 control path (ranks share cuda:0)
     backend = os.environ.get("SMK_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
@@ -203,12 +386,13 @@ def main():
     dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))       # RCCL over xGMI
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=600))
 
     from smokephysai_amd.models.encoder import HipEncoder
     from smokephysai_amd.physics import SmokeSimulator
@@ -268,14 +452,21 @@ def main():
         alt = {"encoder_dtype": other, "value": B * K / a_el, "unit": "frames/s", "ms_per_step": a_el / K * 1e3,
                "ms_encode_per_step": a_enc, "counted_TFLOPs": B * 153728.0 * N * N / (a_enc * 1e-3) / 1e12}
 
+    out = None
     if rank == 0:
         frames_total = world * B * K
         stencil_bytes = B * N * N * 4.0 * (27 + 3 * J)          # algorithmic bytes per stencil pass
         enc_flops = B * 153728.0 * N * N                         # algorithmic flop per encoder launch
         sten_gbs = stencil_bytes / (ms_sim * 1e-3) / 1e9
+        plan = sim.ns_solver.jacobi_plan() if hasattr(sim.ns_solver, "jacobi_plan") else None
         roof_stencil = {"bound": "hbm", "kernel": "stencil pass (all kernels of one time step, B grids)",
                         "achieved": sten_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sten_gbs / HBM_PEAK_GBS,
-                        "traffic": None, "ms_per_launch": ms_sim}
+                        "traffic": None, "ms_per_launch": ms_sim,
+                        "note": "achieved = SURVEY 8(d)'s pass-model bytes 4*(27+3J) per cell over the measured time; it exceeds the pin rate "
+                                "because the J Jacobi sweeps run register/LDS-resident and never touch HBM -- frac is therefore NOT a bound. "
+                                "frac_measured (counter bytes / time / 8 TB/s) is the HBM figure; on_chip_bound names what limits the sweeps"}
+        if plan:
+            roof_stencil["on_chip_bound"] = plan
         out = {"metric": "simulated+encoded frames/sec at 256^2 grid, batch 64", "value": frames_total / elapsed,
                "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -298,6 +489,8 @@ def main():
                         "ms_per_launch": ms_enc,
                         "note": "achieved counts SURVEY 8(d)'s algorithmic flops; the x3 modes execute 3 MFMA products per "
                                 "counted multiply (split operands), so matrix-pipe work is 3x the counted figure"}
+            if args.encoder_dtype in ("bf16x3", "i8x3"):
+                roof_enc["mfma_work_frac"] = 3.0 * tf / peak if args.encoder_dtype == "bf16x3" else None
             out.update({"encode_only_frames_per_s": B / (ms_enc * 1e-3), "ms_encode_per_step": ms_enc,
                         "roofline": roof_enc if ms_enc >= ms_sim else roof_stencil,
                         "roofline_stencil": roof_stencil, "roofline_encoder": roof_enc})
@@ -306,23 +499,43 @@ def main():
             out["roofline"] = roof_stencil
         if alt is not None:
             out["alt"] = alt
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):                                  # filled by tools/pmc_traffic.py from rocprofv3 --pmc passes
-            tr = json.load(open(pmc))
-            for key, kname in (("roofline_stencil", "stencil"), ("roofline_encoder", "encoder")):
-                if key in out and kname in tr:
-                    out[key]["traffic"] = tr[kname]
-        sq = os.path.join(ROOT, "profiles", "pmc_mfma.json")     # tools/pmc_encoder.sh: matrix-pipe busy cycles of the headline kernel
-        if os.path.exists(sq) and "roofline_encoder" in out and args.encoder_dtype == "bf16x3":
-            out["roofline_encoder"]["pmc"] = json.load(open(sq))
+        attach_counters(out, args.encoder_dtype)
         if world == 1:
             out["hbm_copy_measured_GBs"] = hbm_copy_gbs(dev)
         if world == 1 and not args.no_encode and not args.no_inference:
             out["inference_ms_per_frame"] = inference_ms(dev, N, frame, args.encoder_dtype)
-        if world == 1 and args.train_step:
-            out["train_step"] = train_step_ms(dev, N, B)
+        if world == 1 and not args.no_config1:
+            out["config1"] = second_config(dev, rank, K, W)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
+
+    want_train = args.train_step if args.train_step is not None else world > 1
+    if want_train:
+        # a collective that never completes on one rank would hang every rank: a watchdog on each rank abandons the leg
+        # at the same deadline, rank 0 printing the headline line it already holds
+        import threading
+        done = threading.Event()
+
+        def abandon():
+            if done.is_set():
+                return
+            if rank == 0:
+                out["train_step"] = {"error": f"abandoned after {args.train_step_limit:.0f} s (watchdog)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.train_step_limit, abandon)
+        dog.daemon = True
+        dog.start()
+        del sim, enc
+        torch.cuda.empty_cache()
+        try:
+            ts = train_step_leg(dev, N, B, dist, world, backend)
+        except Exception as e:                                   # the headline number must survive a failure of this leg
+            ts = {"error": f"{type(e).__name__}: {e}"[:400]}
+        done.set(); dog.cancel()
+        if rank == 0:
+            out["train_step"] = ts
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 3
+#define SMK_ABI_VERSION 4
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -117,6 +117,13 @@ int smk_apply_fractal(const float *in, float *out, int32_t n_fields, int32_t N, 
  * which = 0/1/2 selects the field's shape (u-like [H+1][pitch_c], v-like [H][pitch_v], cell [H][pitch_c]); no decay. */
 int smk_advect(const float *field, float *out, int32_t which, const float *u, const float *v, int32_t B, int32_t H,
                int32_t W, int32_t pitch_c, int32_t pitch_v, double dt, void *stream);
+/* NavierStokesSimulator.bilinear_interpolate(field, y, x) (navier_stokes.py:111-131; mode 0),
+ * .interpolate_velocity_u(u, y, x) (:97-102; mode 1: x + 0.5 clamped to [0, w-1] first) and .interpolate_velocity_v(v, y, x)
+ * (:104-109; mode 2: y + 0.5 clamped to [0, h-1] first) as pure gathers: B fields [h][pitch] (field_stride floats apart), n
+ * coordinate pairs per field (coord_stride floats apart; 0 = one list shared by all fields), out [B][n].  Coordinates may be any
+ * float (floor -> index clamp -> weights from the clamped indices, so a coordinate exactly on the upper edge yields 0). */
+int smk_interpolate(int32_t mode, const float *field, int32_t B, int32_t h, int32_t w, int32_t pitch, int64_t field_stride,
+                    const float *y, const float *x, int64_t coord_stride, int64_t n, float *out, void *stream);
 /* FractalGenerator.generate_perlin_noise / generate_mandelbrot_field (fractal_generator.py:12-51) for an N x N grid:
  * writes [N][N] fp32 each (any pointer may be NULL): perlin, mandelbrot (counts/100), 0.7*perlin+0.3*mandelbrot. */
 int smk_fractal_constants(int32_t N, float *perlin, float *mandel, float *field, void *stream);

@@ -137,6 +137,16 @@ def bilinear_interpolate(field, y, x):                     # navier_stokes.py:11
     return out
 
 
+def interpolate_velocity_u(u, y, x):                       # navier_stokes.py:97-102: x + 0.5 clamped to [0, u.shape[1] - 1]
+    xs = np.clip(_c(x) + np.float32(0.5), np.float32(0), np.float32(np.asarray(u).shape[1] - 1)).astype(np.float32)
+    return bilinear_interpolate(u, y, xs)
+
+
+def interpolate_velocity_v(v, y, x):                       # navier_stokes.py:104-109: y + 0.5 clamped to [0, v.shape[0] - 1]
+    ys = np.clip(_c(y) + np.float32(0.5), np.float32(0), np.float32(np.asarray(v).shape[0] - 1)).astype(np.float32)
+    return bilinear_interpolate(v, ys, x)
+
+
 def perlin(h, w):                                          # fractal_generator.py:12-31
     out = np.empty((w, h), np.float32)
     lib().so_perlin(h, w, out)

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "smk_advect": [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                    C.c_int32, C.c_int32, C.c_double, C.c_void_p],
     "smk_fractal_constants": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "smk_interpolate": [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                        C.c_int64, C.c_int64, C.c_void_p, C.c_void_p],
     "smk_chaos_stats": [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                         C.c_void_p],
     "smk_frame_diff_norms": [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],

@@ -339,6 +339,18 @@ int smk_advect(const float *field, float *out, int32_t which, const float *u, co
                                       nullptr, (hipStream_t)stream), "advect");
 }
 
+int smk_interpolate(int32_t mode, const float *field, int32_t B, int32_t h, int32_t w, int32_t pitch, int64_t field_stride,
+                    const float *y, const float *x, int64_t coord_stride, int64_t n, float *out, void *stream) {
+    SMK_REQUIRE(field && y && x && out, "null pointer");
+    SMK_REQUIRE(mode >= 0 && mode <= 2, "mode: 0 bilinear_interpolate, 1 interpolate_velocity_u, 2 interpolate_velocity_v");
+    SMK_REQUIRE(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && pitch >= w && n >= 0 && field_stride >= 0 && coord_stride >= 0,
+                "1 <= B <= 65535, h,w >= 1, pitch >= w, n >= 0");
+    SMK_REQUIRE(n < ((int64_t)1 << 38), "n < 2^38 coordinates per field");
+    if (n == 0) return SMK_OK;
+    return check_launch(launch_interp(mode, field, B, h, w, pitch, (size_t)field_stride, y, x, (size_t)coord_stride, (size_t)n, out,
+                                      (hipStream_t)stream), "interpolate");
+}
+
 int smk_fractal_constants(int32_t N, float *perlin, float *mandel, float *field, void *stream) {
     SMK_REQUIRE(N >= 2, "N >= 2");
     hipStream_t st = (hipStream_t)stream;

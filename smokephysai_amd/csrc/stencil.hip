@@ -582,6 +582,52 @@ hipError_t launch_advect(const Geom &g, int kind, const float *field, float *out
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- the public interpolation helpers (navier_stokes.py:97-131)
+// bilinear_interpolate / interpolate_velocity_u / interpolate_velocity_v as pure gathers on caller-given coordinates (any float:
+// the reference floors to int64 and clamps, so coordinates far outside the field are legal).  floor() is saturated in float
+// before the int conversion: every value below -2 / above dim + 1 clamps to the same indices as the int64 original.
+__device__ __forceinline__ int floor_sat(float x, int dim) {
+    float f = floorf(x);
+    f = f < -2.0f ? -2.0f : f;
+    f = f > (float)(dim + 1) ? (float)(dim + 1) : f;
+    return (int)f;
+}
+
+// MODE 0: bilinear(field, y, x); 1: x <- clamp(x + 0.5, 0, w - 1) first (:97-102); 2: y <- clamp(y + 0.5, 0, h - 1) first (:104-109)
+template <int MODE>
+__global__ void k_interp(const float *field, int h, int w, int pitch, size_t fstride, const float *ys, const float *xs,
+                         size_t cstride, size_t n, float *out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int b = blockIdx.y;
+    const float *f = field + b * fstride;
+    float y = ys[b * cstride + k], x = xs[b * cstride + k];
+    if (MODE == 1) x = clampf(x + 0.5f, 0.f, (float)(w - 1));
+    if (MODE == 2) y = clampf(y + 0.5f, 0.f, (float)(h - 1));
+    int x0 = floor_sat(x, w), y0 = floor_sat(y, h);
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = clampi(x0, 0, w - 1); x1 = clampi(x1, 0, w - 1);
+    y0 = clampi(y0, 0, h - 1); y1 = clampi(y1, 0, h - 1);
+    const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
+    const float wa = (fx1 - x) * (fy1 - y);
+    const float wb = (x - fx0) * (fy1 - y);
+    const float wc = (fx1 - x) * (y - fy0);
+    const float wd = (x - fx0) * (y - fy0);
+    float r = wa * f[(size_t)y0 * pitch + x0] + wb * f[(size_t)y0 * pitch + x1];
+    r = r + wc * f[(size_t)y1 * pitch + x0];
+    r = r + wd * f[(size_t)y1 * pitch + x1];
+    out[(size_t)b * n + k] = r;
+}
+
+hipError_t launch_interp(int mode, const float *field, int B, int h, int w, int pitch, size_t fstride, const float *y,
+                         const float *x, size_t cstride, size_t n, float *out, hipStream_t st) {
+    dim3 grid((unsigned)((n + 255) / 256), B), block(256);
+    if (mode == 0) hipLaunchKernelGGL(k_interp<0>, grid, block, 0, st, field, h, w, pitch, fstride, y, x, cstride, n, out);
+    else if (mode == 1) hipLaunchKernelGGL(k_interp<1>, grid, block, 0, st, field, h, w, pitch, fstride, y, x, cstride, n, out);
+    else hipLaunchKernelGGL(k_interp<2>, grid, block, 0, st, field, h, w, pitch, fstride, y, x, cstride, n, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- fractal constants (fractal_generator.py:12-51)
 // torch.linspace fp32 CPU kernel: one rounding per element (FMA form), symmetric halves.
 __device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {

@@ -30,6 +30,7 @@ class GraphedSmokePhysNet:
         self.return_features = bool(return_features)
         self._graphs: Dict[Tuple, Tuple] = {}
         self._weights_seen = None
+        self.captures = 0            # how many graphs were recorded so far (tests / harnesses: stable once warm)
 
     def _capture(self, x: torch.Tensor, chaos_noise: Optional[torch.Tensor], encoder_dtype: Optional[str]):
         require_cuda(x.device, "GraphedSmokePhysNet")
@@ -42,6 +43,7 @@ class GraphedSmokePhysNet:
             for _ in range(max(1, self.warmup)):       # lazy inits (encoder handle, occupancy query, pos-embed cache)
                 self.model(static_x, **kwargs)
         torch.cuda.current_stream(x.device).wait_stream(side)
+        self.captures += 1
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
             static_out = self.model(static_x, **kwargs)
@@ -52,7 +54,8 @@ class GraphedSmokePhysNet:
         if self.model.training:
             raise RuntimeError("GraphedSmokePhysNet replays the eval forward; call model.eval() first")
         # the encoder's folded weights, the split linear weights and the resized pos-embedding live outside the parameter tensors the graph reads,
-        # so a weight update (load_state_dict, an optimizer step) invalidates what was captured
+        # so a weight update (load_state_dict, an optimizer step) invalidates what was captured.  The fingerprint covers the source
+        # tensors only, so the lazily built mirrors of the first forward do not change it (no re-capture on the second call).
         weights_now = self.model.hip_weights_fingerprint()
         if weights_now != self._weights_seen:
             self._graphs.clear()

@@ -50,6 +50,13 @@ def _avg_pool_to(t: torch.Tensor, size) -> torch.Tensor:
     return F.adaptive_avg_pool2d(t, size)
 
 
+def _hip_bn_ok(bn) -> bool:
+    """The fused libsmokehip BatchNorm + ReLU + pool block implements exactly a training-mode affine nn.BatchNorm2d with running
+    statistics and a fixed momentum.  Anything else -- SyncBatchNorm (cross-rank statistics), a frozen block (bn.eval() inside
+    model.train()), momentum=None (cumulative average), track_running_stats=False, affine=False -- runs the PyTorch modules."""
+    return (type(bn) is nn.BatchNorm2d and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None)
+
+
 def _mlp(din: int, dhid: int, dout: int, linear=nn.Linear) -> nn.Sequential:
     return nn.Sequential(linear(din, dhid), nn.ReLU(inplace=True), linear(dhid, dout))
 
@@ -151,7 +158,7 @@ class SmokePhysNet(nn.Module):
             P = H // 32
             mid = pool.output_size[0]              # first pool target; no up-sampling stage and whole-number windows: one P x P mean
             if (self.linear_dtype == "bf16x3" and x.is_cuda and x.dtype == torch.float32 and H == W and P in (4, 8) and W == 32 * P
-                    and type(bn1) is nn.BatchNorm2d and type(bn2) is nn.BatchNorm2d          # not SyncBatchNorm (cross-rank statistics)
+                    and _hip_bn_ok(bn1) and _hip_bn_ok(bn2)
                     and pool.output_size[0] == pool.output_size[1] and H % mid == 0 and mid % 32 == 0):
                 # libsmokehip: BatchNorm (batch statistics) + ReLU as two passes over the conv output, and for the second block
                 # the two average pools (one P x P block mean) in the same pass -- the 256 x 256 x 128 maps are never written
@@ -192,11 +199,35 @@ class SmokePhysNet(nn.Module):
         return self._hip_dec[0]
 
     def hip_weights_fingerprint(self):
-        """Identity + version of every tensor libsmokehip keeps a re-laid-out copy of (GraphedSmokePhysNet re-captures
-        when this changes)."""
-        dec = self._decoder_fingerprint() if self._hip_dec is not None else None
-        return (self._encoder_fingerprint(), (self.pos_embedding.data_ptr(), self.pos_embedding._version),
-                self._hip_body.fingerprint(), dec)
+        """Identity + version of every parameter and buffer of the module, plus the mirror epoch -- a function of the SOURCE
+        tensors only (not of which lazily built libsmokehip mirrors exist yet), so it is the same before and after the first
+        forward; GraphedSmokePhysNet re-captures when it changes."""
+        import itertools
+        return (self.__dict__.get("_mirror_epoch", 0),) + tuple(
+            (t.data_ptr(), t._version) for t in itertools.chain(self.parameters(), self.buffers()))
+
+    def invalidate_hip_mirrors(self) -> None:
+        """Drop every re-laid-out device copy libsmokehip keeps of this module's weights (folded encoder / decoder weights, split
+        linear weights, resized pos-embedding; training handles of the token-wise linears).  The mirrors are keyed on
+        (data_ptr, _version) of their source tensors, which a write through `param.data` (EMA updates, `p.data.clamp_()`,
+        `p.data.copy_()`) does NOT bump: call this after such a write, or write with `with torch.no_grad(): p.copy_(...)`."""
+        if self._hip is not None:
+            self._hip[0].close()
+        if self._hip_dec is not None:
+            self._hip_dec[0].close()
+        self._hip = self._hip_dec = self._pos_cache = None
+        body = self._hip_body
+        for h, _ in body.linears.values():
+            h.close()
+        body.linears.clear(); body.sources.clear()
+        for m in self.modules():
+            if isinstance(m, TrainableHipLinear):
+                for k in ("_hip_fwd", "_hip_bwd"):
+                    h = m.__dict__.pop(k, None)
+                    if h is not None:
+                        h.close()
+                m.__dict__.pop("_hip_fwd_fp", None); m.__dict__.pop("_hip_bwd_fp", None)
+        self.__dict__["_mirror_epoch"] = self.__dict__.get("_mirror_epoch", 0) + 1
 
     def _body_hip(self, tokens: torch.Tensor, chaos_noise: Optional[torch.Tensor], pool_size: int):
         """feature_proj + pos-embed, the pre-LN chaos transformer layers and output_decoder (smokephys_net.py:95-114,

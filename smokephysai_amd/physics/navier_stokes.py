@@ -126,6 +126,41 @@ class NavierStokesSimulator(nn.Module):
                                       h, w, w, w + 1, float(self.dt), self._st()))
         return out if batched else out[0]
 
+    # ---- the three public interpolation helpers (navier_stokes.py:97-131) as pure gathers ---------------------------------
+    def _interp(self, mode: int, field: torch.Tensor, y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        f = torch.as_tensor(field, dtype=torch.float32, device=self._dev)
+        yy = torch.as_tensor(y, dtype=torch.float32, device=self._dev)
+        xx = torch.as_tensor(x, dtype=torch.float32, device=self._dev)
+        if f.dim() not in (2, 3):
+            raise ValueError("field must be [h, w] or a batch [B, h, w]")
+        if yy.shape != xx.shape:
+            yy, xx = torch.broadcast_tensors(yy, xx)
+        batched = f.dim() == 3
+        f3 = (f if batched else f[None]).contiguous()
+        B, h, w = f3.shape
+        # batched field [B, h, w]: coordinates of 3+ dimensions with the same leading B are one list per field; anything else
+        # (the reference's 2-D meshgrids) is one list shared by all fields
+        shared = not (batched and yy.dim() >= 3 and yy.shape[0] == B)
+        yc, xc = yy.contiguous(), xx.contiguous()
+        n = yc.numel() if shared else yc[0].numel()
+        out = torch.empty((B,) + (tuple(yc.shape) if shared else tuple(yc.shape[1:])), device=self._dev, dtype=torch.float32)
+        _lib.check(self._L.smk_interpolate(mode, f3.data_ptr(), B, h, w, w, h * w, yc.data_ptr(), xc.data_ptr(),
+                                           0 if shared else n, n, out.data_ptr(), self._st()))
+        return out if batched else out[0]
+
+    def bilinear_interpolate(self, field: torch.Tensor, y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """navier_stokes.py:111-131 -- indices are clamped BEFORE the weights are formed, so a coordinate exactly on the upper
+        edge (x == w-1 or y == h-1) returns 0, not the edge value (the reference's quirk, reproduced)."""
+        return self._interp(0, field, y, x)
+
+    def interpolate_velocity_u(self, u: torch.Tensor, y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """navier_stokes.py:97-102 -- u sampled at (y, clamp(x + 0.5, 0, u.shape[-1] - 1))."""
+        return self._interp(1, u, y, x)
+
+    def interpolate_velocity_v(self, v: torch.Tensor, y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """navier_stokes.py:104-109 -- v sampled at (clamp(y + 0.5, 0, v.shape[-2] - 1), x)."""
+        return self._interp(2, v, y, x)
+
     def pressure_projection(self):
         """navier_stokes.py:133-149 (in place on u, v, p)."""
         _lib.check(self._L.smk_sim_run_stage(self._handle, _lib.STAGE_PROJECT, self._st()))

@@ -50,10 +50,52 @@ def wrap_ddp(model: torch.nn.Module, device, sync_bn: bool = False) -> torch.nn.
     return torch.nn.parallel.DistributedDataParallel(model)
 
 
+def ddp_bucket_report(ddp) -> dict:
+    """What the gradient exchange of one step looks like: the reducer's bucket sizes (bytes, in all-reduce launch order)
+    and the collective backend.  Empty for an unwrapped (single-process) model."""
+    if not isinstance(ddp, torch.nn.parallel.DistributedDataParallel):
+        return {}
+    try:
+        log = ddp._get_ddp_logging_data()
+    except Exception:                                    # private API: report what is known without it
+        log = {}
+    sizes = [int(x) for x in str(log.get("bucket_sizes", "")).split(",") if x.strip()]
+    total = sum(p.numel() * p.element_size() for p in ddp.parameters() if p.requires_grad)
+    return {"backend": log.get("backend_name", dist.get_backend()), "world_size": dist.get_world_size(),
+            "bucket_cap_bytes": int(log.get("bucket_cap_bytes", 0)) or None, "bucket_bytes": sizes,
+            "num_buckets": len(sizes) or None, "grad_bytes": int(total),
+            "gradient_as_bucket_view": bool(log.get("gradient_as_bucket_view", False))}
+
+
 def all_reduce_mean_scalars(values, device):
     """Mean over ranks of a few logging scalars (one small all-reduce)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [float(v) for v in values]
-    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dev = torch.device(device)
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64,
+                     device=dev if (dev.type == "cuda" and dist.get_backend() == "nccl") else "cpu")
     dist.all_reduce(t)
     return (t / dist.get_world_size()).tolist()
+
+
+def all_reduce_weighted_mean(sums, count, device):
+    """sum over ranks of `sums` / sum over ranks of `count`: a sample-weighted mean when the ranks hold blocks of different
+    size (`sums` = per-rank sum of value x samples, `count` = per-rank samples)."""
+    vals = [float(v) for v in sums] + [float(count)]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = torch.device(device)
+        t = torch.tensor(vals, dtype=torch.float64, device=dev if (dev.type == "cuda" and dist.get_backend() == "nccl") else "cpu")
+        dist.all_reduce(t)
+        vals = t.tolist()
+    n = max(vals[-1], 1.0)
+    return [v / n for v in vals[:-1]]
+
+
+def max_over_ranks(value: int, device) -> int:
+    """The largest `value` any rank holds (one tiny all-reduce); `value` itself for a single process."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(value)
+    dev = torch.device(device)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev if (dev.type == "cuda" and dist.get_backend() == "nccl") else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())

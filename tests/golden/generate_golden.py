@@ -17,6 +17,9 @@ What is recorded:
   encoder_*.npz           input_encoder weights (+ BN running stats), frames, features
   model_small.npz         small-config SmokePhysNet weights + explicit chaos noise + outputs
   train_batch.npz         one seeded batch -> the four train.py loss scalars + grad norm
+  interp_64.npz           the reference's own bilinear_interpolate / interpolate_velocity_u / _v on seeded fields and coordinates
+                          (interior, exact upper edge = the zero quirk, negative, far outside)
+  ref_cache_64.pkl        the pickle cache the REFERENCE's SyntheticSmokeDataset writes (data_loader.py:25-35), 2 samples at 64^2
   transformer_layer.npz   one ChaosTransformerLayer (dim 128, 2 heads of 64, L=128): weights, input, the three noise draws,
                           the ChaosAttention output and the layer output
 """
@@ -435,9 +438,55 @@ def gen_transformer_layer():
     save("transformer_layer.npz", **rec)
 
 
+# ---------------------------------------------------------------- interpolation helpers (navier_stokes.py:97-131)
+def gen_interp():
+    """The three public interpolation methods, called directly."""
+    rng = np.random.RandomState(11)
+    h, w = 48, 64
+    ns = NavierStokesSimulator((h, w), device="cpu")
+    rec = {}
+    fields = {"cell": (h, w), "u": (h + 1, w), "v": (h, w + 1)}
+    for name, (R, C) in fields.items():
+        f = rng.randn(R, C).astype(np.float32)
+        n = 4096
+        # interior points, points exactly on integer coordinates, the exact upper edge (zero quirk), and out-of-range values
+        y = rng.uniform(-3.0, R + 2.0, n).astype(np.float32)
+        x = rng.uniform(-3.0, C + 2.0, n).astype(np.float32)
+        y[:256] = rng.randint(0, R, 256).astype(np.float32)
+        x[128:384] = rng.randint(0, C, 256).astype(np.float32)
+        y[400:420] = R - 1
+        x[410:440] = C - 1
+        y[440:450] = np.float32(R - 1) - np.float32(1e-4)
+        x[450:460] = np.float32(C - 1) - np.float32(1e-4)
+        y[460:470] = [-0.0, -0.5, -1.0, -1e-7, 1e-7, 0.5, R - 0.5, R, R + 0.5, 1e6]
+        x[470:480] = [-0.0, -0.5, -1.0, -1e-7, 1e-7, 0.5, C - 0.5, C, C + 0.5, -1e6]
+        y2 = y.reshape(64, 64); x2 = x.reshape(64, 64)
+        ft, yt, xt = torch.from_numpy(f), torch.from_numpy(y2), torch.from_numpy(x2)
+        rec[f"{name}_field"], rec[f"{name}_y"], rec[f"{name}_x"] = f, y2, x2
+        rec[f"{name}_bilinear"] = ns.bilinear_interpolate(ft, yt, xt).numpy()
+        rec[f"{name}_interp_u"] = ns.interpolate_velocity_u(ft, yt, xt).numpy()
+        rec[f"{name}_interp_v"] = ns.interpolate_velocity_v(ft, yt, xt).numpy()
+    save("interp_64.npz", **rec)
+
+
+# ---------------------------------------------------------------- the reference's on-disk dataset cache (data_loader.py:25-35)
+def gen_ref_cache():
+    """The pickle the reference writes; same seed as dataset_seed0_64.npz (so both fixtures describe the same samples)."""
+    import tempfile, shutil
+    d = tempfile.mkdtemp()
+    try:
+        np.random.seed(0)
+        torch.manual_seed(0)
+        SyntheticSmokeDataset(num_samples=2, grid_size=(64, 64), device="cpu", cache_path=os.path.join(d, "train_data.pkl"))
+        shutil.copyfile(os.path.join(d, "train_data.pkl"), os.path.join(OUT, "ref_cache_64.pkl"))
+        print(f"wrote ref_cache_64.pkl: {os.path.getsize(os.path.join(OUT, 'ref_cache_64.pkl'))/1024:.1f} KiB")
+    finally:
+        shutil.rmtree(d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stages", "backtrace", "traj", "fractal", "dataset", "chaos", "encoder", "model", "full", "layer"]
-    fns = dict(stages=gen_stages, backtrace=gen_backtrace, traj=gen_traj, fractal=gen_fractal,
+    which = sys.argv[1:] or ["stages", "backtrace", "traj", "fractal", "dataset", "chaos", "encoder", "model", "full", "layer", "interp", "cache"]
+    fns = dict(interp=gen_interp, cache=gen_ref_cache, stages=gen_stages, backtrace=gen_backtrace, traj=gen_traj, fractal=gen_fractal,
                dataset=gen_dataset, chaos=gen_chaos_stats, encoder=gen_encoder, model=gen_model_small,
                full=gen_model_full_checksums, layer=gen_transformer_layer)
     with torch.no_grad():

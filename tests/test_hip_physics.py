@@ -242,3 +242,39 @@ def test_sources_apply_in_list_order_per_grid():
     got = ns.density[1].cpu().numpy()
     assert rel_err(got, o.density) < 1e-6
     assert float(ns.density[2].abs().sum()) == 0.0 and float(ns.density[0].abs().sum()) > 0.0
+
+
+@pytest.mark.parametrize("name", ["cell", "u", "v"])
+def test_public_interpolation_helpers_vs_reference(golden, name):
+    """NavierStokesSimulator.bilinear_interpolate / interpolate_velocity_u / _v (navier_stokes.py:97-131) as
+    stand-alone methods, on the reference's own outputs for seeded fields and coordinates on integers, on the exact upper edge
+    (returns 0: the quirk), negative and far outside the field: bit-exact."""
+    g = golden("interp_64.npz")
+    f, y, x = (torch.from_numpy(g[f"{name}_{k}"]).cuda() for k in ("field", "y", "x"))
+    ns = NavierStokesSimulator((48, 64))
+    np.testing.assert_array_equal(ns.bilinear_interpolate(f, y, x).cpu().numpy(), g[f"{name}_bilinear"])
+    np.testing.assert_array_equal(ns.interpolate_velocity_u(f, y, x).cpu().numpy(), g[f"{name}_interp_u"])
+    np.testing.assert_array_equal(ns.interpolate_velocity_v(f, y, x).cpu().numpy(), g[f"{name}_interp_v"])
+    # upper-edge quirk, stated directly: f[.., w-1] is NOT returned at x == w-1
+    R, C = f.shape
+    yy = torch.full((4,), 3.0, device="cuda"); xx = torch.tensor([C - 1.0, C - 2.0, C - 1.5, 0.0], device="cuda")
+    got = ns.bilinear_interpolate(f, yy, xx).cpu().numpy()
+    assert got[0] == 0.0 and got[1] == g[f"{name}_field"][3, C - 2] and got[3] == g[f"{name}_field"][3, 0]
+    # batched fields: shared 2-D coordinates, and one coordinate list per field
+    fb = torch.stack([f, 2 * f, -f])
+    sh = ns.bilinear_interpolate(fb, y, x)
+    assert sh.shape == (3,) + tuple(y.shape) and torch.equal(sh[1], ns.bilinear_interpolate(2 * f, y, x))
+    yb = torch.stack([y, y + 0.25, y - 1.0]); xb = torch.stack([x, x - 0.5, x + 2.0])
+    per = ns.interpolate_velocity_u(fb, yb, xb)
+    for b in range(3):
+        assert torch.equal(per[b], ns.interpolate_velocity_u(fb[b], yb[b], xb[b]))
+    # the composition the reference's advection_step spells out (navier_stokes.py:74-95) equals the fused advect kernel
+    h, w = 48, 64
+    rng = np.random.RandomState(5)
+    u = torch.from_numpy(rng.randn(h + 1, w).astype(np.float32) * 30).cuda()
+    v = torch.from_numpy(rng.randn(h, w + 1).astype(np.float32) * 30).cuda()
+    d = torch.from_numpy(rng.rand(h, w).astype(np.float32)).cuda()
+    Y, X = torch.meshgrid(torch.arange(h, device="cuda", dtype=torch.float32), torch.arange(w, device="cuda", dtype=torch.float32), indexing="ij")
+    ui, vi = ns.interpolate_velocity_u(u, Y, X), ns.interpolate_velocity_v(v, Y, X)
+    px = torch.clamp(X - ns.dt * ui, 0, w - 1); py = torch.clamp(Y - ns.dt * vi, 0, h - 1)
+    assert torch.equal(ns.bilinear_interpolate(d, py, px), ns.advection_step(d, u, v))

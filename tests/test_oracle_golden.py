@@ -227,3 +227,17 @@ def test_transformer_layer_oracle_matches_reference(golden):
     # the Q-fold identity the HIP path relies on: (Q + strength * gate * C_h) K^T == scores + strength * gate * chaos_scores
     states = oracle.lorenz_states(g["noise"])
     assert states.shape == (2, 5, 3) and states.dtype == np.float32
+
+
+@pytest.mark.parametrize("name", ["cell", "u", "v"])
+def test_interpolation_helpers_vs_reference(golden, name):
+    """The reference's public bilinear_interpolate / interpolate_velocity_u / _v (navier_stokes.py:97-131) called directly on
+    seeded fields with coordinates on integers, on the exact upper edge (the zero quirk), negative and far outside: bit-exact."""
+    g = golden("interp_64.npz")
+    f, y, x = g[f"{name}_field"], g[f"{name}_y"], g[f"{name}_x"]
+    np.testing.assert_array_equal(oracle.bilinear_interpolate(f, y, x), g[f"{name}_bilinear"])
+    np.testing.assert_array_equal(oracle.interpolate_velocity_u(f, y, x), g[f"{name}_interp_u"])
+    np.testing.assert_array_equal(oracle.interpolate_velocity_v(f, y, x), g[f"{name}_interp_v"])
+    R, C = f.shape
+    edge = (y == R - 1) | (x == C - 1)                       # the quirk: exactly 0 on the upper clamp edge
+    assert edge.sum() >= 30 and np.all(g[f"{name}_bilinear"][edge & (y <= R - 1) & (x <= C - 1)] == 0)

@@ -23,7 +23,8 @@ from tqdm import tqdm
 
 from smokephysai_amd.models.physics_regularizer import PhysicsRegularizer
 from smokephysai_amd.utils.data_loader import create_data_loaders
-from smokephysai_amd.utils.distributed import all_reduce_mean_scalars, init_distributed, wrap_ddp
+from smokephysai_amd.utils.distributed import (all_reduce_weighted_mean, ddp_bucket_report, init_distributed, max_over_ranks,
+                                               wrap_ddp)
 
 
 class _NullWriter:
@@ -78,11 +79,28 @@ def batch_losses(model, physics_regularizer, batch, device, chaos_noise=None):
     return total, recon_loss, physics_loss, chaos_loss
 
 
+def _rank_invariant_batches(loader: DataLoader, device):
+    """Every rank must run the same number of optimisation steps: DDP's gradient all-reduce is a collective, and the ranks'
+    sample blocks differ by up to one sample (shard_range), i.e. possibly by one batch.  The step count is the maximum over
+    ranks; a rank that runs out of batches starts its (shuffled) loader again, so no sample is dropped and no rank waits
+    in a collective the others never enter."""
+    steps = max_over_ranks(len(loader), device)
+    it = iter(loader)
+    for _ in range(steps):
+        try:
+            batch = next(it)
+        except StopIteration:
+            it = iter(loader)
+            batch = next(it)
+        yield batch
+
+
 def train_epoch(model: nn.Module, train_loader: DataLoader, optimizer: optim.Optimizer,
                 physics_regularizer: PhysicsRegularizer, device, epoch: int, writer) -> Dict[str, float]:
     model.train()
-    sums = [0.0, 0.0, 0.0, 0.0]
-    pbar = tqdm(train_loader, desc=f"Training Epoch {epoch+1}", leave=True)
+    sums, seen = [0.0, 0.0, 0.0, 0.0], 0
+    steps = max_over_ranks(len(train_loader), device)
+    pbar = tqdm(_rank_invariant_batches(train_loader, device), total=steps, desc=f"Training Epoch {epoch+1}", leave=True)
     for batch_idx, batch in enumerate(pbar):
         optimizer.zero_grad()
         total, recon, phys, chaos = batch_losses(model, physics_regularizer, batch, device)
@@ -90,30 +108,33 @@ def train_epoch(model: nn.Module, train_loader: DataLoader, optimizer: optim.Opt
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
         optimizer.step()
         vals = [total.item(), recon.item(), phys.item(), chaos.item()]
-        sums = [s + v for s, v in zip(sums, vals)]
+        n = int(batch["input"].shape[0])
+        sums = [s + v * n for s, v in zip(sums, vals)]
+        seen += n
         if batch_idx % 50 == 0:
-            step = epoch * len(train_loader) + batch_idx
+            step = epoch * steps + batch_idx
             for name, v in zip(("Total", "Recon", "Physics", "Chaos"), vals):
                 writer.add_scalar(f"Train/Batch_{name}_Loss", v, step)
         pbar.set_postfix({"loss": f"{vals[0]:.4f}", "recon": f"{vals[1]:.4f}", "phys": f"{vals[2]:.4f}"})
-    n = max(len(train_loader), 1)
-    avg = all_reduce_mean_scalars([s / n for s in sums], device)
+    avg = all_reduce_weighted_mean(sums, seen, device)        # sample-weighted over all ranks (blocks differ in size)
     return dict(zip(("total_loss", "recon_loss", "physics_loss", "chaos_loss"), avg))
 
 
 def validate_epoch(model: nn.Module, val_loader: DataLoader, physics_regularizer: PhysicsRegularizer,
                    device) -> Dict[str, float]:
+    """No collective inside the loop (the unwrapped model, eval-mode BatchNorm), so ranks may run different batch counts."""
     model.eval()
-    sums = [0.0, 0.0, 0.0, 0.0]
+    sums, seen = [0.0, 0.0, 0.0, 0.0], 0
     with torch.no_grad():
         pbar = tqdm(val_loader, desc="Validation", leave=True)
         for batch in pbar:
             losses = batch_losses(model, physics_regularizer, batch, device)
             vals = [v.item() if torch.is_tensor(v) else float(v) for v in losses]
-            sums = [s + v for s, v in zip(sums, vals)]
+            n = int(batch["input"].shape[0])
+            sums = [s + v * n for s, v in zip(sums, vals)]
+            seen += n
             pbar.set_postfix({"loss": f"{vals[0]:.4f}", "recon": f"{vals[1]:.4f}"})
-    n = max(len(val_loader), 1)
-    avg = all_reduce_mean_scalars([s / n for s in sums], device)
+    avg = all_reduce_weighted_mean(sums, seen, device)
     return dict(zip(("total_loss", "recon_loss", "physics_loss", "chaos_loss"), avg))
 
 
@@ -148,6 +169,10 @@ def main():
         model.load_state_dict(ckpt["model_state_dict"])
         start_epoch = int(ckpt.get("epoch", -1)) + 1
     ddp_model = wrap_ddp(model, device, sync_bn=bool(hw.get("sync_bn", False)))
+    if ddp_model is not model:                         # SyncBatchNorm conversion replaces modules: validate on the wrapped network
+        model = ddp_model.module
+        if rank == 0:
+            print(f"DDP gradient exchange: {ddp_bucket_report(ddp_model)}")
     optimizer = optim.AdamW(ddp_model.parameters(), lr=config["training"]["learning_rate"],
                             weight_decay=config["training"]["weight_decay"])
     scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=config["training"]["num_epochs"])
