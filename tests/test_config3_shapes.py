@@ -76,7 +76,8 @@ def frames64():
     sim = SmokeSimulator((N, N), batch_size=B, jacobi_iters=20)
     sim.ns_solver.add_smoke_sources(_bench_sources(3))
     frame = torch.empty(B, N, N, device="cuda")
-    sim.ns_solver.step_into(frame, 12, add_fractal=True, fractal_intensity=0.05)
+    for _ in range(12):
+        sim.ns_solver.step_into(frame, 1, add_fractal=True, fractal_intensity=0.05)
     torch.cuda.synchronize()
     return frame
 
