@@ -1,4 +1,6 @@
 // C ABI of libsmokehip.so (see include/smokehip.h for the contract and the reference interfaces replaced).
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
 #include <vector>
@@ -72,7 +74,13 @@ int run_stage(smk_sim *sim, int stage, float *frames, int64_t fsb, const float *
         case SMK_STAGE_BUOY_DIFFUSE:   // s -> t (u2, v2, d2)
             return check_launch(launch_buoy_diffuse(g, s, t, st), "buoy_diffuse");
         case SMK_STAGE_PROJECT: {      // on t.u, t.v with s.p
-            return check_launch(launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st), "project");
+            int rc = check_launch(launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st), "project");
+            static const bool dump = getenv("SMK_DEBUG_DUMP_PROJECT") != nullptr;      // diagnostic: expose the projected (u2, v2) as (u, v)
+            if (rc == SMK_OK && dump) {
+                (void)hipMemcpyAsync(s.u, t.u, (size_t)g.B * g.su * sizeof(float), hipMemcpyDeviceToDevice, st);
+                (void)hipMemcpyAsync(s.v, t.v, (size_t)g.B * g.sv * sizeof(float), hipMemcpyDeviceToDevice, st);
+            }
+            return rc;
         }
         case SMK_STAGE_ADVECT_U:       // u <- adv(u2; u2, v2)
             return check_launch(launch_advect(g, 0, t.u, s.u, t.u, t.v, nullptr, 0, nullptr, 0.f, nullptr, nullptr, st),

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
 //   SMK_JACOBI_RPW, SMK_JACOBI_BANDS   pin the band plan of k_jacobi_band   SMK_JACOBI_ROUND=0     disable k_jacobi_round
 //   SMK_JACOBI_ROUND_MIN_WGS   least workgroups per launch for which k_jacobi_round is chosen (default 128)
 struct StencilKnobs {
-    bool generic, unfused, round;
+    bool generic, unfused, round, debug;
     int rpw, bands, round_min_wgs;
     StencilKnobs() {
         auto flag = [](const char *n, bool dflt) { const char *v = getenv(n); return v ? v[0] == '1' : dflt; };
@@ -376,6 +376,7 @@ struct StencilKnobs {
         generic = flag("SMK_JACOBI_GENERIC", false);
         unfused = flag("SMK_PROJECT_UNFUSED", false);
         round = flag("SMK_JACOBI_ROUND", true);
+        debug = flag("SMK_STENCIL_DEBUG", false);
         rpw = num("SMK_JACOBI_RPW");
         bands = num("SMK_JACOBI_BANDS");
         round_min_wgs = getenv("SMK_JACOBI_ROUND_MIN_WGS") ? num("SMK_JACOBI_ROUND_MIN_WGS") : 128;
@@ -475,38 +476,50 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, size_t floats) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(floats * 4), 0x00020000);
 }
+// (component reads go through __uint_as_float on a VALUE: __builtin_bit_cast on a vector-component lvalue `t.y` reads component 0
+// with this compiler -- every lane column came back as the row's first column)
 template <int VEC>
 __device__ __forceinline__ void ldb_row(float (&dst)[VEC], __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     if constexpr (VEC == 1) {
-        dst[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+        dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
     } else if constexpr (VEC == 2) {
         const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
-        dst[0] = __builtin_bit_cast(float, t.x); dst[1] = __builtin_bit_cast(float, t.y);
+        const unsigned t0 = t[0], t1 = t[1];
+        dst[0] = __uint_as_float(t0); dst[1] = __uint_as_float(t1);
     } else {
         const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-        dst[0] = __builtin_bit_cast(float, t.x); dst[1] = __builtin_bit_cast(float, t.y);
-        dst[2] = __builtin_bit_cast(float, t.z); dst[3] = __builtin_bit_cast(float, t.w);
+        const unsigned t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+        dst[0] = __uint_as_float(t0); dst[1] = __uint_as_float(t1); dst[2] = __uint_as_float(t2); dst[3] = __uint_as_float(t3);
     }
 }
+// Stores put the row offset into the VECTOR offset and leave soffset at 0.  Measured on gfx950 (ROCm 7.2): a buffer_store_dwordx4 whose
+// soffset is an SGPR, followed directly by a VALU instruction that overwrites its data registers, stores the NEW value in the last four
+// lanes of every 16-lane group (the store reads its data in passes, and hipcc's hazard recognizer inserts the wait state only when
+// soffset is NOT a register) -- u came back with p differences in columns 48, 52, ... of sporadic rows.  With soffset = 0 the
+// compiler inserts the wait state itself.
 template <int VEC>
-__device__ __forceinline__ void stb_row(__amdgpu_buffer_rsrc_t rs, int voff, int soff, const float (&src)[VEC]) {
+__device__ __forceinline__ void stb_row(__amdgpu_buffer_rsrc_t rs, int voff, int row_off, const float (&src)[VEC]) {
+    const int vo = voff + row_off;
     if constexpr (VEC == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, src[0]), rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(src[0]), rs, vo, 0, 0);
     } else if constexpr (VEC == 2) {
-        u32x2_t t = {__builtin_bit_cast(unsigned, src[0]), __builtin_bit_cast(unsigned, src[1])};
-        __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, 0);
+        u32x2_t t;
+        t[0] = __float_as_uint(src[0]); t[1] = __float_as_uint(src[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(t, rs, vo, 0, 0);
     } else {
-        u32x4_t t = {__builtin_bit_cast(unsigned, src[0]), __builtin_bit_cast(unsigned, src[1]), __builtin_bit_cast(unsigned, src[2]),
-                     __builtin_bit_cast(unsigned, src[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, 0);
+        u32x4_t t;
+        t[0] = __float_as_uint(src[0]); t[1] = __float_as_uint(src[1]); t[2] = __float_as_uint(src[2]); t[3] = __float_as_uint(src[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, vo, 0, 0);
     }
 }
 
-// K sweeps on the wave's R rows.  ROLE 0: no ring row in the tile; 1: grid row 0 sits at tile row K (first wave of a grid's first
-// band: its tile starts at row -K); 2: grid row H-1 sits at tile row R-1-K (last wave of the last band: its tile ends at row H+K).
-// The ring row is simply never updated (it holds 0); the virtual rows beyond it compute on clamped loads and feed nothing else.
-template <int VEC, int R, int K, int ROLE>
-__device__ __forceinline__ void jr_round(float (&pv)[R][VEC], const float (&dv)[R][VEC], bool first_col, bool last_col) {
+// K sweeps on the wave's R rows.  A ring row of the grid can sit at two tile rows only: grid row 0 at tile row K (first wave of a
+// grid's first band: its tile starts at row -K) and grid row H-1 at tile row R-1-K (last wave of the last band: its tile ends at
+// row H+K) -- `ring_top` / `ring_bot` (wave-uniform) say whether this wave is that wave; only those two rows carry the select
+// that forces the ring to zero.  The virtual rows beyond a ring row compute on clamped loads and feed nothing else.
+template <int VEC, int R, int K>
+__device__ __forceinline__ void jr_round(float (&pv)[R][VEC], const float (&dv)[R][VEC], bool first_col, bool last_col, bool ring_top,
+                                         bool ring_bot) {
 #pragma unroll
     for (int s = 1; s <= K; ++s) {
         float prev[VEC];
@@ -514,11 +527,6 @@ __device__ __forceinline__ void jr_round(float (&pv)[R][VEC], const float (&dv)[
         for (int c = 0; c < VEC; ++c) prev[c] = pv[s - 1][c];
 #pragma unroll
         for (int k = s; k <= R - 1 - s; ++k) {
-            if ((ROLE == 1 && k == K) || (ROLE == 2 && k == R - 1 - K)) {
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) prev[c] = 0.f;              // the ring row: stays 0, and is the next row's `up`
-                continue;
-            }
             float cur[VEC], nw[VEC];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) cur[c] = pv[k][c];
@@ -535,6 +543,11 @@ __device__ __forceinline__ void jr_round(float (&pv)[R][VEC], const float (&dv)[
             }
             nw[0] = first_col ? 0.f : nw[0];
             nw[VEC - 1] = last_col ? 0.f : nw[VEC - 1];
+            if (k == K || k == R - 1 - K) {
+                const bool z = k == K ? ring_top : ring_bot;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) nw[c] = z ? 0.f : nw[c];
+            }
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
                 prev[c] = cur[c];
@@ -598,18 +611,14 @@ __global__ __launch_bounds__(JR_NW * 64, 2) void k_jacobi_round(Geom g, const fl
         for (int k = 0; k < R; ++k) ldb_row<VEC>(dv[k], drs, vo, crow(row0 + k) * pcb);
     }
     // which waves hold a ring row (wave-uniform): by construction of the tiles it sits at a fixed tile row
-    const int role = (band == 0 && wave == 0) ? 1 : ((band == nb - 1 && wave == JR_NW - 1) ? 2 : 0);
-    if (role == 1) {
+    const bool ring_top = band == 0 && wave == 0, ring_bot = band == nb - 1 && wave == JR_NW - 1;
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) pv[K][c] = 0.f;
-    } else if (role == 2) {
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) pv[R - 1 - K][c] = 0.f;
+    for (int c = 0; c < VEC; ++c) {                           // (a caller may have assigned a p with a non-zero ring)
+        pv[K][c] = ring_top ? 0.f : pv[K][c];
+        pv[R - 1 - K][c] = ring_bot ? 0.f : pv[R - 1 - K][c];
     }
     for (int rd = 0; rd < rounds; ++rd) {
-        if (role == 0) jr_round<VEC, R, K, 0>(pv, dv, first_col, last_col);
-        else if (role == 1) jr_round<VEC, R, K, 1>(pv, dv, first_col, last_col);
-        else jr_round<VEC, R, K, 2>(pv, dv, first_col, last_col);
+        jr_round<VEC, R, K>(pv, dv, first_col, last_col, ring_top, ring_bot);
         if (rd == rounds - 1) break;
         const int par = rd & 1;
 #pragma unroll
@@ -803,6 +812,9 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
     RoundPlan rp;
     if (!knobs().unfused && plan_round(g, iters, rp)) {
         const int total = iters / JR_K, L = round_launches(rp, total);
+        if (knobs().debug)
+            fprintf(stderr, "[smk] project %dx%dx%d J=%d: round plan nb=%d e=%d m=%d halo=%d max_rounds=%d -> %d launches for %d rounds\n",
+                    g.B, g.H, g.W, iters, rp.nb, rp.e_rows, rp.m_rows, rp.halo, rp.max_rounds, L, total);
         if (L <= total) {                                      // every launch runs at least one round
             float *cur = p, *nxt = p2;
             int done = 0;
@@ -828,6 +840,9 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
     }
     const int cap = pl.halo - 1;                              // the fused gradient needs the row above the owned range exact
     const int L = 2 * ((iters + 2 * cap - 1) / (2 * cap));
+    if (knobs().debug)
+        fprintf(stderr, "[smk] project %dx%dx%d J=%d: band plan vec=%d rpw=%d nb=%d halo=%d -> %d launches\n", g.B, g.H, g.W, iters, pl.vec,
+                pl.rpw, pl.nb, pl.halo, L);
     float *cur = p, *nxt = p2;
     int done = 0;
     for (int c = 0; c < L; ++c) {
