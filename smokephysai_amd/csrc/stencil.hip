@@ -513,6 +513,65 @@ __device__ __forceinline__ void stb_row(__amdgpu_buffer_rsrc_t rs, int voff, int
     }
 }
 
+// One row of one sweep: nw = 0.25 * ((((up + dn) + left) + right) - dv), the two ring columns forced to zero.
+// Generic form (any VEC): the compiler's schedule.
+template <int VEC>
+__device__ __forceinline__ void jr_row(float (&nw)[VEC], const float (&up)[VEC], const float (&cur)[VEC], const float (&dn)[VEC],
+                                       const float (&dv)[VEC], unsigned long long m_first, unsigned long long m_last, bool first_col,
+                                       bool last_col) {
+    const float lin = wave_shr1(cur[VEC - 1]), rin = wave_shl1(cur[0]);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        const float l = c > 0 ? cur[c - 1] : lin;
+        const float r = c < VEC - 1 ? cur[c + 1] : rin;
+        float sm = up[c] + dn[c];
+        sm = sm + l;
+        sm = sm + r;
+        sm = sm - dv[c];
+        nw[c] = 0.25f * sm;
+    }
+    nw[0] = first_col ? 0.f : nw[0];
+    nw[VEC - 1] = last_col ? 0.f : nw[VEC - 1];
+}
+// VEC = 4: the same 22 instructions in a FIXED order with the four cells' chains interleaved.  Left to itself the scheduler (register
+// pressure first, at 241 of 256 registers) emits each cell's five dependent operations back to back through one temporary, and a wave
+// then issues one vector instruction per ~8 cycles (measured: SQ_INSTS_VALU x 4 cycles = SQ_WAVE_CYCLES x 4 x 0.5 with two waves per
+// SIMD -- the SIMD issues every 4th cycle).  Interleaved, every instruction's producer is four instructions back.  The DPP forms
+// take the neighbour lane's cell as src0 (v_add_f32 is commutative: same rounding); their sources were written rows ago (no DPP
+// read-after-write wait state is needed).  m_first / m_last: lane masks (bit 0 / bit 63) of the two ring columns.
+template <>
+__device__ __forceinline__ void jr_row<4>(float (&nw)[4], const float (&up)[4], const float (&cur)[4], const float (&dn)[4],
+                                          const float (&dv)[4], unsigned long long m_first, unsigned long long m_last, bool, bool) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "v_add_f32_e32 %0, %4, %12\n\t"
+        "v_add_f32_e32 %1, %5, %13\n\t"
+        "v_add_f32_e32 %2, %6, %14\n\t"
+        "v_add_f32_e32 %3, %7, %15\n\t"
+        "v_add_f32_dpp %0, %11, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_e32 %1, %8, %1\n\t"
+        "v_add_f32_e32 %2, %9, %2\n\t"
+        "v_add_f32_e32 %3, %10, %3\n\t"
+        "v_add_f32_e32 %0, %9, %0\n\t"
+        "v_add_f32_e32 %1, %10, %1\n\t"
+        "v_add_f32_e32 %2, %11, %2\n\t"
+        "v_add_f32_dpp %3, %8, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_sub_f32_e32 %0, %0, %16\n\t"
+        "v_sub_f32_e32 %1, %1, %17\n\t"
+        "v_sub_f32_e32 %2, %2, %18\n\t"
+        "v_sub_f32_e32 %3, %3, %19\n\t"
+        "v_mul_f32_e32 %0, 0x3e800000, %0\n\t"
+        "v_mul_f32_e32 %1, 0x3e800000, %1\n\t"
+        "v_mul_f32_e32 %2, 0x3e800000, %2\n\t"
+        "v_mul_f32_e32 %3, 0x3e800000, %3\n\t"
+        "v_cndmask_b32_e64 %0, %0, 0, %20\n\t"
+        "v_cndmask_b32_e64 %3, %3, 0, %21"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(up[0]), "v"(up[1]), "v"(up[2]), "v"(up[3]), "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]), "v"(dn[0]), "v"(dn[1]),
+          "v"(dn[2]), "v"(dn[3]), "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]), "s"(m_first), "s"(m_last));
+    nw[0] = t0; nw[1] = t1; nw[2] = t2; nw[3] = t3;
+}
+
 // K sweeps on the wave's R rows.  A ring row of the grid can sit at two tile rows only: grid row 0 at tile row K (first wave of a
 // grid's first band: its tile starts at row -K) and grid row H-1 at tile row R-1-K (last wave of the last band: its tile ends at
 // row H+K) -- `ring_top` / `ring_bot` (wave-uniform) say whether this wave is that wave; only those two rows carry the select
@@ -520,6 +579,7 @@ __device__ __forceinline__ void stb_row(__amdgpu_buffer_rsrc_t rs, int voff, int
 template <int VEC, int R, int K>
 __device__ __forceinline__ void jr_round(float (&pv)[R][VEC], const float (&dv)[R][VEC], bool first_col, bool last_col, bool ring_top,
                                          bool ring_bot) {
+    const unsigned long long m_first = __builtin_amdgcn_readfirstlane(0) + 1ull, m_last = 1ull << 63;
 #pragma unroll
     for (int s = 1; s <= K; ++s) {
         float prev[VEC];
@@ -530,19 +590,7 @@ __device__ __forceinline__ void jr_round(float (&pv)[R][VEC], const float (&dv)[
             float cur[VEC], nw[VEC];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) cur[c] = pv[k][c];
-            const float lin = wave_shr1(cur[VEC - 1]), rin = wave_shl1(cur[0]);
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                const float l = c > 0 ? cur[c - 1] : lin;
-                const float r = c < VEC - 1 ? cur[c + 1] : rin;
-                float sm = prev[c] + pv[k + 1][c];
-                sm = sm + l;
-                sm = sm + r;
-                sm = sm - dv[k][c];
-                nw[c] = 0.25f * sm;
-            }
-            nw[0] = first_col ? 0.f : nw[0];
-            nw[VEC - 1] = last_col ? 0.f : nw[VEC - 1];
+            jr_row<VEC>(nw, prev, cur, pv[k + 1], dv[k], m_first, m_last, first_col, last_col);
             if (k == K || k == R - 1 - K) {
                 const bool z = k == K ? ring_top : ring_bot;
 #pragma unroll
@@ -553,9 +601,7 @@ __device__ __forceinline__ void jr_round(float (&pv)[R][VEC], const float (&dv)[
                 prev[c] = cur[c];
                 pv[k][c] = nw[c];
             }
-            // one row at a time: the 4 cells of a lane are independent chains (enough for one wave's 4-cycle issue interval); letting
-            // the scheduler interleave rows only inflates the temporaries past the 256-register budget of two waves per SIMD
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);                // rows in program order (interleaving rows only inflates the temporaries)
         }
     }
 }

@@ -41,8 +41,9 @@ def wrap_ddp(model: torch.nn.Module, device, sync_bn: bool = False) -> torch.nn.
     """DistributedDataParallel around `model` when a process group exists (gradient all-reduce = mean over ranks)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
-    if sync_bn:
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    if sync_bn:      # reference semantics = one process, whole-batch statistics: exchange the per-channel sums (models/sync_bn.py)
+        from ..models.sync_bn import convert_sync_batchnorm
+        model = convert_sync_batchnorm(model)
     dev = torch.device(device)
     if dev.type == "cuda":
         return torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], bucket_cap_mb=64,

@@ -210,3 +210,96 @@ def test_ddp_gradients_equal_single_process(golden, tmp_path):
     scale = max(float(p.grad.abs().max()) for p in model.parameters())
     for k, p in model.named_parameters():
         assert float((p.grad - res["grads"][k]).abs().max()) / scale < 5e-5, k     # fp32 reduction-order noise (observed 1.5e-5)
+
+
+# ---------------------------------------------------------------- N>1: SyncBatchNorm == single-process whole-batch BatchNorm
+def _syncbn_worker(rank, world, port, golden_path, out_path):
+    import torch.distributed as dist
+    from smokephysai_amd.utils.distributed import init_distributed, wrap_ddp
+    import train
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    init_distributed("gloo")
+    g = dict(np.load(golden_path))
+    model = _small_model(g).train()                       # BatchNorm in TRAIN mode: batch statistics
+    ddp = wrap_ddp(model, "cpu", sync_bn=True)
+    from smokephysai_amd.models.sync_bn import SyncBatchNorm2d
+    assert sum(isinstance(m, SyncBatchNorm2d) for m in model.modules()) == 4 and list(model.state_dict()) == [k[3:] for k in g if k.startswith("w::")]
+    lo, hi = shard_range(2, rank, world)
+    batch = {"input": torch.from_numpy(g["inputs"][lo:hi]), "target": torch.from_numpy(g["targets"][lo:hi]),
+             "chaos_features": torch.from_numpy(g["chaos_targets"][lo:hi]), "sequence": torch.zeros(hi - lo, 20, 8, 8)}
+    noise = torch.from_numpy(g["chaos_noise"][:, :, lo:hi])
+    total, *_ = train.batch_losses(ddp, PhysicsRegularizer(), batch, "cpu", chaos_noise=noise)
+    total.backward()
+    if rank == 0:
+        torch.save({"grads": {k: p.grad.clone() for k, p in model.named_parameters()},
+                    "buffers": {k: b.clone() for k, b in model.named_buffers()}}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_ddp_equals_single_process_full_batch(golden, tmp_path):
+    """2 gloo ranks, one sample each, train-mode BatchNorm with sync_bn=True: parameter gradients and BatchNorm running statistics equal
+    the single-process run on the full batch of 2 (the reference's semantics, train.py:59-93 in one process)."""
+    import torch.multiprocessing as mp
+    import train
+    gpath = os.path.join(os.path.dirname(__file__), "golden", "train_batch.npz")
+    out = str(tmp_path / "syncbn.pt")
+    mp.spawn(_syncbn_worker, args=(2, _free_port(), gpath, out), nprocs=2, join=True)
+    res = torch.load(out)
+    g = golden("train_batch.npz")
+    model = _small_model(g).train()
+    batch = {"input": torch.from_numpy(g["inputs"]), "target": torch.from_numpy(g["targets"]),
+             "chaos_features": torch.from_numpy(g["chaos_targets"]), "sequence": torch.zeros(2, 20, 8, 8)}
+    total, *_ = train.batch_losses(model, PhysicsRegularizer(), batch, "cpu", chaos_noise=torch.from_numpy(g["chaos_noise"]))
+    total.backward()
+    scale = max(float(p.grad.abs().max()) for p in model.parameters())
+    for k, p in model.named_parameters():
+        assert float((p.grad - res["grads"][k]).abs().max()) / scale < 2e-4, k
+    for k, b in model.named_buffers():
+        if b.dtype.is_floating_point:
+            assert torch.allclose(b, res["buffers"][k], rtol=1e-4, atol=1e-6), k
+        else:
+            assert torch.equal(b, res["buffers"][k]), k
+    # and WITHOUT the exchange the per-rank statistics give different gradients (the test has teeth)
+    m2 = _small_model(g).train()
+    half = {k: v[:1] for k, v in batch.items()}
+    t2, *_ = train.batch_losses(m2, PhysicsRegularizer(), half, "cpu", chaos_noise=torch.from_numpy(g["chaos_noise"][:, :, :1]))
+    t2.backward()
+    w = "input_encoder.0.weight"
+    gw, gw2 = dict(model.named_parameters())[w].grad, dict(m2.named_parameters())[w].grad
+    assert float((gw2 - gw).abs().max()) / float(gw.abs().max()) > 0.05
+
+
+def _uneven_worker(rank, world, port, out_path):
+    """Ranks with 3 and 2 batches per epoch must run the same number of optimisation steps (DDP hang)."""
+    import torch.distributed as dist
+    from smokephysai_amd.utils.distributed import init_distributed, wrap_ddp
+    import train
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    init_distributed("gloo")
+    torch.manual_seed(0)
+    model = SmokePhysNet(input_dim=32, hidden_dim=64, num_layers=1, num_heads=4, output_channels=16)
+    ddp = wrap_ddp(model, "cpu")
+    n = 5 if rank == 0 else 4                             # 9 samples over 2 ranks, batch 2 -> 3 vs 2 batches
+    g = torch.Generator().manual_seed(rank)
+    items = [{"input": torch.rand(1, 64, 64, generator=g), "target": torch.rand(1, 128, 128, generator=g),
+              "chaos_features": torch.rand(3, generator=g), "sequence": torch.rand(20, 8, 8, generator=g)} for _ in range(n)]
+    loader = torch.utils.data.DataLoader(items, batch_size=2, shuffle=False)
+    opt = torch.optim.AdamW(ddp.parameters(), lr=1e-4)
+    m = train.train_epoch(ddp, loader, opt, PhysicsRegularizer(), "cpu", 0, train._NullWriter())
+    v = train.validate_epoch(model, loader, PhysicsRegularizer(), "cpu")
+    if rank == 0:
+        torch.save({"train": m, "val": v}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_run_equal_step_counts(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "uneven.pt")
+    mp.spawn(_uneven_worker, args=(2, _free_port(), out), nprocs=2, join=True)          # a mismatch would hang in DDP's all-reduce
+    res = torch.load(out)
+    assert set(res["train"]) == {"total_loss", "recon_loss", "physics_loss", "chaos_loss"}
+    assert all(np.isfinite(v) for v in res["train"].values()) and all(np.isfinite(v) for v in res["val"].values())
