@@ -365,21 +365,18 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
 
 // Diagnostic switches of the projection, read ONCE per process (never on the per-step path):
 //   SMK_JACOBI_GENERIC=1   one launch per sweep (k_jacobi_sweep)        SMK_PROJECT_UNFUSED=1  divergence / gradient as own launches
-//   SMK_JACOBI_RPW, SMK_JACOBI_BANDS   pin the band plan of k_jacobi_band   SMK_JACOBI_ROUND=0     disable k_jacobi_round
-//   SMK_JACOBI_ROUND_MIN_WGS   least workgroups per launch for which k_jacobi_round is chosen (default 128)
+//   SMK_JACOBI_RPW, SMK_JACOBI_BANDS   pin the band plan of k_jacobi_band   SMK_STENCIL_DEBUG=1    print the chosen plan
 struct StencilKnobs {
-    bool generic, unfused, round, debug;
-    int rpw, bands, round_min_wgs;
+    bool generic, unfused, debug;
+    int rpw, bands;
     StencilKnobs() {
         auto flag = [](const char *n, bool dflt) { const char *v = getenv(n); return v ? v[0] == '1' : dflt; };
         auto num = [](const char *n) { const char *v = getenv(n); return v ? atoi(v) : 0; };
         generic = flag("SMK_JACOBI_GENERIC", false);
         unfused = flag("SMK_PROJECT_UNFUSED", false);
-        round = flag("SMK_JACOBI_ROUND", true);
         debug = flag("SMK_STENCIL_DEBUG", false);
         rpw = num("SMK_JACOBI_RPW");
         bands = num("SMK_JACOBI_BANDS");
-        round_min_wgs = getenv("SMK_JACOBI_ROUND_MIN_WGS") ? num("SMK_JACOBI_ROUND_MIN_WGS") : 128;
     }
 };
 static const StencilKnobs &knobs() {
@@ -427,368 +424,6 @@ static bool plan_jacobi(const Geom &g, JacobiPlan &pl, int iters = 100) {
 }
 
 
-// ---- wave-autonomous, temporally blocked Jacobi (k_jacobi_round) -----------------------------------------------------------------
-// k_jacobi_band above synchronises its 16 waves once per sweep (publish edge rows -> s_barrier -> read), and that round trip, not
-// arithmetic, sets its sweep time (the vector ALUs issue in ~25 % of the cycles).  Here a wave owns R full rows of p and div in
-// registers and runs a ROUND of K sweeps with no synchronisation at all: sweep s of a round updates rows s .. R-1-s in place (top
-// down, the old value of the row above kept in a temporary), so after K sweeps the middle R - 2K rows -- the rows the wave owns --
-// are exact and the K rows on either side hold partial results.  Only then the waves of a workgroup exchange their outermost K
-// owned rows through LDS (double buffered: one s_barrier per ROUND) and overwrite the neighbours' halo rows.  Across workgroups
-// the scheme of k_jacobi_band applies unchanged: a tile carries `halo` rows beyond the rows its band owns on every inner side,
-// the invalid front advances one row per sweep, and the owned rows are written back once per launch (global ping-pong p <-> p2).
-// Per cell the arithmetic is exactly k_jacobi_sweep's; results are bit-identical to J global sweeps.
-// Rows outside the grid ("virtual" rows of the first / last tile) hold clamped loads: they only ever feed the ring rows 0 and H-1,
-// which are forced to zero in every sweep (RING code path: taken by the waves whose tile contains a ring row).
-constexpr int JR_NW = 8;
-
-template <int VEC, int R, int K>
-struct JrShape {
-    static constexpr int OWN = R - 2 * K, T = JR_NW * OWN + 2 * K, ROWF = 64 * VEC;
-};
-
-template <int VEC> struct VecT;
-template <> struct VecT<1> { using type = float; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<4> { using type = float4; };
-
-template <int VEC>
-__device__ __forceinline__ void ld_row(float (&dst)[VEC], const float *src) {
-    using V = typename VecT<VEC>::type;
-    const V t = *reinterpret_cast<const V *>(src);
-    const float *f = reinterpret_cast<const float *>(&t);
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) dst[c] = f[c];
-}
-template <int VEC>
-__device__ __forceinline__ void st_row(float *dst, const float (&src)[VEC]) {
-    using V = typename VecT<VEC>::type;
-    V t;
-    float *f = reinterpret_cast<float *>(&t);
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) f[c] = src[c];
-    *reinterpret_cast<V *>(dst) = t;
-}
-
-// Row accesses through buffer instructions: the descriptor of one grid's plane in SGPRs, the row offset a SCALAR (the row index is
-// wave-uniform), the lane's column offset the only vector register -- 24 rows of 64-bit flat addresses would cost 48 VGPRs.
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, size_t floats) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(floats * 4), 0x00020000);
-}
-// (component reads go through __uint_as_float on a VALUE: __builtin_bit_cast on a vector-component lvalue `t.y` reads component 0
-// with this compiler -- every lane column came back as the row's first column)
-template <int VEC>
-__device__ __forceinline__ void ldb_row(float (&dst)[VEC], __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    if constexpr (VEC == 1) {
-        dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-    } else if constexpr (VEC == 2) {
-        const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
-        const unsigned t0 = t[0], t1 = t[1];
-        dst[0] = __uint_as_float(t0); dst[1] = __uint_as_float(t1);
-    } else {
-        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-        const unsigned t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-        dst[0] = __uint_as_float(t0); dst[1] = __uint_as_float(t1); dst[2] = __uint_as_float(t2); dst[3] = __uint_as_float(t3);
-    }
-}
-// Stores put the row offset into the VECTOR offset and leave soffset at 0.  Measured on gfx950 (ROCm 7.2): a buffer_store_dwordx4 whose
-// soffset is an SGPR, followed directly by a VALU instruction that overwrites its data registers, stores the NEW value in the last four
-// lanes of every 16-lane group (the store reads its data in passes, and hipcc's hazard recognizer inserts the wait state only when
-// soffset is NOT a register) -- u came back with p differences in columns 48, 52, ... of sporadic rows.  With soffset = 0 the
-// compiler inserts the wait state itself.
-template <int VEC>
-__device__ __forceinline__ void stb_row(__amdgpu_buffer_rsrc_t rs, int voff, int row_off, const float (&src)[VEC]) {
-    const int vo = voff + row_off;
-    if constexpr (VEC == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(src[0]), rs, vo, 0, 0);
-    } else if constexpr (VEC == 2) {
-        u32x2_t t;
-        t[0] = __float_as_uint(src[0]); t[1] = __float_as_uint(src[1]);
-        __builtin_amdgcn_raw_buffer_store_b64(t, rs, vo, 0, 0);
-    } else {
-        u32x4_t t;
-        t[0] = __float_as_uint(src[0]); t[1] = __float_as_uint(src[1]); t[2] = __float_as_uint(src[2]); t[3] = __float_as_uint(src[3]);
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, vo, 0, 0);
-    }
-}
-
-// One row of one sweep: nw = 0.25 * ((((up + dn) + left) + right) - dv), the two ring columns forced to zero.
-// Generic form (any VEC): the compiler's schedule.
-template <int VEC>
-__device__ __forceinline__ void jr_row(float (&nw)[VEC], const float (&up)[VEC], const float (&cur)[VEC], const float (&dn)[VEC],
-                                       const float (&dv)[VEC], unsigned long long m_first, unsigned long long m_last, bool first_col,
-                                       bool last_col) {
-    const float lin = wave_shr1(cur[VEC - 1]), rin = wave_shl1(cur[0]);
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-        const float l = c > 0 ? cur[c - 1] : lin;
-        const float r = c < VEC - 1 ? cur[c + 1] : rin;
-        float sm = up[c] + dn[c];
-        sm = sm + l;
-        sm = sm + r;
-        sm = sm - dv[c];
-        nw[c] = 0.25f * sm;
-    }
-    nw[0] = first_col ? 0.f : nw[0];
-    nw[VEC - 1] = last_col ? 0.f : nw[VEC - 1];
-}
-// VEC = 4: the same 22 instructions in a FIXED order with the four cells' chains interleaved.  Left to itself the scheduler (register
-// pressure first, at 241 of 256 registers) emits each cell's five dependent operations back to back through one temporary, and a wave
-// then issues one vector instruction per ~8 cycles (measured: SQ_INSTS_VALU x 4 cycles = SQ_WAVE_CYCLES x 4 x 0.5 with two waves per
-// SIMD -- the SIMD issues every 4th cycle).  Interleaved, every instruction's producer is four instructions back.  The DPP forms
-// take the neighbour lane's cell as src0 (v_add_f32 is commutative: same rounding); their sources were written rows ago (no DPP
-// read-after-write wait state is needed).  m_first / m_last: lane masks (bit 0 / bit 63) of the two ring columns.
-template <>
-__device__ __forceinline__ void jr_row<4>(float (&nw)[4], const float (&up)[4], const float (&cur)[4], const float (&dn)[4],
-                                          const float (&dv)[4], unsigned long long m_first, unsigned long long m_last, bool, bool) {
-    float t0, t1, t2, t3;
-    asm volatile(
-        "v_add_f32_e32 %0, %4, %12\n\t"
-        "v_add_f32_e32 %1, %5, %13\n\t"
-        "v_add_f32_e32 %2, %6, %14\n\t"
-        "v_add_f32_e32 %3, %7, %15\n\t"
-        "v_add_f32_dpp %0, %11, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_e32 %1, %8, %1\n\t"
-        "v_add_f32_e32 %2, %9, %2\n\t"
-        "v_add_f32_e32 %3, %10, %3\n\t"
-        "v_add_f32_e32 %0, %9, %0\n\t"
-        "v_add_f32_e32 %1, %10, %1\n\t"
-        "v_add_f32_e32 %2, %11, %2\n\t"
-        "v_add_f32_dpp %3, %8, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_sub_f32_e32 %0, %0, %16\n\t"
-        "v_sub_f32_e32 %1, %1, %17\n\t"
-        "v_sub_f32_e32 %2, %2, %18\n\t"
-        "v_sub_f32_e32 %3, %3, %19\n\t"
-        "v_mul_f32_e32 %0, 0x3e800000, %0\n\t"
-        "v_mul_f32_e32 %1, 0x3e800000, %1\n\t"
-        "v_mul_f32_e32 %2, 0x3e800000, %2\n\t"
-        "v_mul_f32_e32 %3, 0x3e800000, %3\n\t"
-        "v_cndmask_b32_e64 %0, %0, 0, %20\n\t"
-        "v_cndmask_b32_e64 %3, %3, 0, %21"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(up[0]), "v"(up[1]), "v"(up[2]), "v"(up[3]), "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]), "v"(dn[0]), "v"(dn[1]),
-          "v"(dn[2]), "v"(dn[3]), "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]), "s"(m_first), "s"(m_last));
-    nw[0] = t0; nw[1] = t1; nw[2] = t2; nw[3] = t3;
-}
-
-// K sweeps on the wave's R rows.  A ring row of the grid can sit at two tile rows only: grid row 0 at tile row K (first wave of a
-// grid's first band: its tile starts at row -K) and grid row H-1 at tile row R-1-K (last wave of the last band: its tile ends at
-// row H+K) -- `ring_top` / `ring_bot` (wave-uniform) say whether this wave is that wave; only those two rows carry the select
-// that forces the ring to zero.  The virtual rows beyond a ring row compute on clamped loads and feed nothing else.
-template <int VEC, int R, int K>
-__device__ __forceinline__ void jr_round(float (&pv)[R][VEC], const float (&dv)[R][VEC], bool first_col, bool last_col, bool ring_top,
-                                         bool ring_bot) {
-    const unsigned long long m_first = __builtin_amdgcn_readfirstlane(0) + 1ull, m_last = 1ull << 63;
-#pragma unroll
-    for (int s = 1; s <= K; ++s) {
-        float prev[VEC];
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) prev[c] = pv[s - 1][c];
-#pragma unroll
-        for (int k = s; k <= R - 1 - s; ++k) {
-            float cur[VEC], nw[VEC];
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) cur[c] = pv[k][c];
-            jr_row<VEC>(nw, prev, cur, pv[k + 1], dv[k], m_first, m_last, first_col, last_col);
-            if (k == K || k == R - 1 - K) {
-                const bool z = k == K ? ring_top : ring_bot;
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) nw[c] = z ? 0.f : nw[c];
-            }
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                prev[c] = cur[c];
-                pv[k][c] = nw[c];
-            }
-            __builtin_amdgcn_sched_barrier(0);                // rows in program order (interleaving rows only inflates the temporaries)
-        }
-    }
-}
-
-// MODE bit 0: first launch of a projection (divergence computed here, stored for the owned rows); bit 1: last launch (gradient
-// subtraction applied to the owned rows of u, v).  `rounds` rounds of K sweeps.  Band geometry: band 0 owns rows [0, e_rows), the
-// middle bands m_rows each, the last band the rest; tile of band 0 starts at row -K, of the last band ends at row H + K, a middle
-// tile starts `halo` rows above the first row its band owns.
-template <int VEC, int R, int K, int MODE>
-__global__ __launch_bounds__(JR_NW * 64, 2) void k_jacobi_round(Geom g, const float *__restrict__ p_in, float *__restrict__ p_out,
-                                                                float *__restrict__ div, float *__restrict__ u, float *__restrict__ v,
-                                                                int rounds, int halo, int e_rows, int m_rows) {
-    using S = JrShape<VEC, R, K>;
-    constexpr int OWN = S::OWN, T = S::T, ROWF = S::ROWF;
-    __shared__ float xch[2][JR_NW][2][K][ROWF];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y, nb = gridDim.x, band = blockIdx.x;
-    const int own0 = band == 0 ? 0 : e_rows + (band - 1) * m_rows;
-    const int own1 = band == nb - 1 ? g.H : e_rows + band * m_rows;
-    const int r0 = band == 0 ? -K : (band == nb - 1 ? g.H + K - T : own0 - halo);
-    const int row0 = r0 + wave * OWN, j0 = lane * VEC;
-    const bool first_col = lane == 0, last_col = lane == 63;
-    float pv[R][VEC], dv[R][VEC];
-    auto crow = [&](int gi) { return gi < 0 ? 0 : (gi > g.H - 1 ? g.H - 1 : gi); };       // scalar (row0 is wave-uniform)
-    const int vo = j0 * 4, pcb = g.pc * 4, pvb = g.pv * 4;
-    const __amdgpu_buffer_rsrc_t prs = plane_rsrc(p_in + b * g.sc, g.sc), drs = plane_rsrc(div + b * g.sc, g.sc);
-#pragma unroll
-    for (int k = 0; k < R; ++k) ldb_row<VEC>(pv[k], prs, vo, crow(row0 + k) * pcb);
-    if (MODE & 1) {
-        const __amdgpu_buffer_rsrc_t urs = plane_rsrc(u + b * g.su, g.su), vrs = plane_rsrc(v + b * g.sv, g.sv);
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int gi = crow(row0 + k);
-            float u0[VEC], u1[VEC], vr[VEC + 1], vx[1];
-            ldb_row<VEC>(u0, urs, vo, gi * pcb);
-            ldb_row<VEC>(u1, urs, vo, (gi + 1) * pcb);
-            ldb_row<VEC>(reinterpret_cast<float (&)[VEC]>(vr), vrs, vo, gi * pvb);
-            ldb_row<1>(vx, vrs, vo + VEC * 4, gi * pvb);
-            vr[VEC] = vx[0];
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                float a = u1[c] - u0[c];
-                a = a + vr[c + 1];
-                a = a - vr[c];
-                dv[k][c] = __fdiv_rn(a, g.dt);
-            }
-            const int gr = row0 + k;
-            if (k >= K && k < R - K && gr >= own0 && gr < own1) stb_row<VEC>(drs, vo, gr * pcb, dv[k]);
-            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);          // keep the row temporaries of 4 rows live, not of all R
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; ++k) ldb_row<VEC>(dv[k], drs, vo, crow(row0 + k) * pcb);
-    }
-    // which waves hold a ring row (wave-uniform): by construction of the tiles it sits at a fixed tile row
-    const bool ring_top = band == 0 && wave == 0, ring_bot = band == nb - 1 && wave == JR_NW - 1;
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) {                           // (a caller may have assigned a p with a non-zero ring)
-        pv[K][c] = ring_top ? 0.f : pv[K][c];
-        pv[R - 1 - K][c] = ring_bot ? 0.f : pv[R - 1 - K][c];
-    }
-    for (int rd = 0; rd < rounds; ++rd) {
-        jr_round<VEC, R, K>(pv, dv, first_col, last_col, ring_top, ring_bot);
-        if (rd == rounds - 1) break;
-        const int par = rd & 1;
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-            st_row<VEC>(&xch[par][wave][0][q][j0], pv[K + q]);               // my first K owned rows -> the wave above
-            st_row<VEC>(&xch[par][wave][1][q][j0], pv[R - 2 * K + q]);       // my last K owned rows  -> the wave below
-        }
-        __syncthreads();
-        if (wave > 0) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) ld_row<VEC>(pv[q], &xch[par][wave - 1][1][q][j0]);
-        }
-        if (wave < JR_NW - 1) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) ld_row<VEC>(pv[R - K + q], &xch[par][wave + 1][0][q][j0]);
-        }
-    }
-    const __amdgpu_buffer_rsrc_t ors = plane_rsrc(p_out + b * g.sc, g.sc);
-#pragma unroll
-    for (int k = K; k < R - K; ++k) {
-        const int gr = row0 + k;
-        if (gr >= own0 && gr < own1) stb_row<VEC>(ors, vo, gr * pcb, pv[k]);
-    }
-    if (MODE & 2) {
-        // u[i,:] -= dt*(p[i,:] - p[i-1,:]) for 1 <= i <= H-1;  v[:,j] -= dt*(p[:,j] - p[:,j-1]) for 1 <= j <= W-1  (as k_grad_subtract)
-        __syncthreads();                                      // the exchange buffers are free again
-        st_row<VEC>(&xch[0][wave][1][0][j0], pv[R - K - 1]);  // my last owned row: the row above the wave below's first owned row
-        __syncthreads();
-        float above[VEC];
-        ld_row<VEC>(above, &xch[0][wave > 0 ? wave - 1 : 0][1][0][j0]);
-        const __amdgpu_buffer_rsrc_t urs = plane_rsrc(u + b * g.su, g.su), vrs = plane_rsrc(v + b * g.sv, g.sv);
-#pragma unroll
-        for (int k = K; k < R - K; ++k) {
-            const int gr = row0 + k;
-            const float lin = wave_shr1(pv[k][VEC - 1]);
-            if (gr >= own0 && gr < own1) {
-                float un[VEC], vn[VEC];
-                ldb_row<VEC>(un, urs, vo, gr * pcb);
-                ldb_row<VEC>(vn, vrs, vo, gr * pvb);
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    if (gr >= 1) {                            // row 0 of u is untouched
-                        const float pu = k > K ? pv[k - 1][c] : above[c];
-                        const float grd = pv[k][c] - pu;
-                        un[c] = un[c] - g.dt * grd;
-                    }
-                    if (!(c == 0 && first_col)) {             // column 0 of v is untouched
-                        const float pl = c > 0 ? pv[k][c - 1] : lin;
-                        const float grd = pv[k][c] - pl;
-                        vn[c] = vn[c] - g.dt * grd;
-                    }
-                }
-                if (gr >= 1) stb_row<VEC>(urs, vo, gr * pcb, un);
-                stb_row<VEC>(vrs, vo, gr * pvb, vn);
-            }
-            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// Plan of k_jacobi_round for a grid shape: bands per grid, rows owned by the first / middle bands, inter-launch halo, rounds per launch.
-struct RoundPlan { int vec, nb, e_rows, m_rows, halo, max_rounds; };
-constexpr int JR_R = 24, JR_K = 4;
-static bool plan_round(const Geom &g, int iters, RoundPlan &pl) {
-    if (!knobs().round || knobs().generic) return false;
-    if (g.W % 64 != 0 || g.pc % 4 != 0 || g.pv % 4 != 0 || iters < JR_K || iters % JR_K != 0) return false;
-    const int vec = g.W / 64;
-    if (vec != 1 && vec != 2 && vec != 4) return false;
-    constexpr int OWN = JR_R - 2 * JR_K, T = JR_NW * OWN + 2 * JR_K, K = JR_K;
-    pl.vec = vec;
-    if (g.H + 2 * K <= T) {                                   // the whole grid in one tile: no halo, any number of rounds per launch
-        if (g.H + 2 * K != T) return false;                   // (the bottom ring row must sit at tile row R-1-K of the last wave)
-        pl.nb = 1; pl.e_rows = g.H; pl.m_rows = 0; pl.halo = 0; pl.max_rounds = 1 << 20;
-        return g.B >= knobs().round_min_wgs;                  // fewer workgroups than half the CUs: k_jacobi_band's finer bands win
-    }
-    const int total = iters / K;
-    double best = 1e30;
-    bool ok = false;
-    for (int nb = 2; nb <= 16; ++nb) {
-        const int m = (g.H + nb - 1) / nb, e = m, last0 = e + (nb - 2) * m, last = g.H - last0;
-        if (last <= 0) break;
-        int h = T - K - e;                                                 // band 0: rows e .. T-K-1 below its owned range
-        if (nb > 2) h = h < (T - m) / 2 ? h : (T - m) / 2;                 // middle: halo on both sides
-        const int hl = last0 - (g.H + K - T);                              // last band: rows above its owned range inside the tile
-        h = h < hl ? h : hl;
-        if (T - K - last < h) h = T - K - last;
-        // a launch of n sweeps needs halo >= n (+1 row for the fused gradient of the last launch)
-        const int mr = (h - 1) / K;
-        if (mr < 1) continue;
-        if ((long long)nb * g.B < knobs().round_min_wgs) continue;         // too few workgroups for the chip: k_jacobi_band's finer bands win
-        int L = (total + mr - 1) / mr;
-        L += L & 1;
-        // ~6 us fixed per launch; a round of K sweeps ~3 us per workgroup resident on a CU (VALU-issue bound, two waves per SIMD)
-        const double cost = 6.0 * L + 3.0 * total * ceil((double)nb * g.B / 256.0);
-        if (cost < best) { best = cost; pl.nb = nb; pl.e_rows = e; pl.m_rows = m; pl.halo = h; pl.max_rounds = mr; ok = true; }
-    }
-    return ok;
-}
-
-template <int VEC, int MODE>
-static void launch_round_vec(const Geom &g, const RoundPlan &pl, const float *pin, float *pout, float *div, float *u, float *v, int rounds,
-                             hipStream_t st) {
-    dim3 grid(pl.nb, g.B), block(JR_NW * 64);
-    hipLaunchKernelGGL((k_jacobi_round<VEC, JR_R, JR_K, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, rounds, pl.halo, pl.e_rows,
-                       pl.m_rows);
-}
-template <int MODE>
-static void launch_round(const Geom &g, const RoundPlan &pl, const float *pin, float *pout, float *div, float *u, float *v, int rounds,
-                         hipStream_t st) {
-    switch (pl.vec) {
-        case 1: launch_round_vec<1, MODE>(g, pl, pin, pout, div, u, v, rounds, st); break;
-        case 2: launch_round_vec<2, MODE>(g, pl, pin, pout, div, u, v, rounds, st); break;
-        case 4: launch_round_vec<4, MODE>(g, pl, pin, pout, div, u, v, rounds, st); break;
-    }
-}
-
-// Launch schedule of one projection on k_jacobi_round: `total` rounds over L launches (L even when bands exchange halos through
-// the p <-> p2 ping-pong; one in-place launch when a tile holds the whole grid).
-static int round_launches(const RoundPlan &pl, int total) {
-    if (pl.nb == 1) return 1;
-    int L = (total + pl.max_rounds - 1) / pl.max_rounds;
-    return L + (L & 1);
-}
-
 template <int VEC, int MODE>
 static void launch_band(const Geom &g, const JacobiPlan &pl, const float *pin, float *pout, float *div, float *u, float *v,
                         int iters, hipStream_t st) {
@@ -819,18 +454,7 @@ hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, i
     dim3 grid(cdiv(g.W, TX), cdiv(g.H, TY), g.B), block(TX, TY);
     JacobiPlan pl;
     float *cur = p, *nxt = p2;
-    RoundPlan rp;
-    if (plan_round(g, iters, rp)) {
-        const int total = iters / JR_K, L = round_launches(rp, total);
-        int done = 0;
-        for (int c = 0; c < L; ++c) {
-            const int n = (total - done + (L - c) - 1) / (L - c);
-            if (n > 0) launch_round<0>(g, rp, cur, rp.nb == 1 ? cur : nxt, const_cast<float *>(div), nullptr, nullptr, n, st);
-            else hipLaunchKernelGGL(k_copy_cells, grid, block, 0, st, g, cur, nxt);
-            done += n;
-            if (rp.nb > 1) { float *t = cur; cur = nxt; nxt = t; }
-        }
-    } else if (plan_jacobi(g, pl, iters)) {
+    if (plan_jacobi(g, pl, iters)) {
         // an even number of nearly equal chunks (global ping-pong ends back in p); each chunk <= halo sweeps
         int L = 2 * ((iters + 2 * pl.halo - 1) / (2 * pl.halo));
         if (iters == 1) L = 1;
@@ -855,28 +479,6 @@ hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, i
 // With a band plan the divergence is computed inside the first Jacobi launch and the gradient subtraction inside the last.
 hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st) {
     JacobiPlan pl;
-    RoundPlan rp;
-    if (!knobs().unfused && plan_round(g, iters, rp)) {
-        const int total = iters / JR_K, L = round_launches(rp, total);
-        if (knobs().debug)
-            fprintf(stderr, "[smk] project %dx%dx%d J=%d: round plan nb=%d e=%d m=%d halo=%d max_rounds=%d -> %d launches for %d rounds\n",
-                    g.B, g.H, g.W, iters, rp.nb, rp.e_rows, rp.m_rows, rp.halo, rp.max_rounds, L, total);
-        if (L <= total) {                                      // every launch runs at least one round
-            float *cur = p, *nxt = p2;
-            int done = 0;
-            for (int c = 0; c < L; ++c) {
-                const int n = (total - done + (L - c) - 1) / (L - c);
-                float *dst = rp.nb == 1 ? cur : nxt;
-                if (L == 1) launch_round<3>(g, rp, cur, dst, div, u, v, n, st);
-                else if (c == 0) launch_round<1>(g, rp, cur, dst, div, u, v, n, st);
-                else if (c == L - 1) launch_round<2>(g, rp, cur, dst, div, u, v, n, st);
-                else launch_round<0>(g, rp, cur, dst, div, u, v, n, st);
-                done += n;
-                if (rp.nb > 1) { float *t = cur; cur = nxt; nxt = t; }
-            }
-            return hipGetLastError();
-        }
-    }
     if (iters < 2 || !plan_jacobi(g, pl, iters) || pl.halo < 3 || knobs().unfused) {
         hipError_t e = launch_divergence(g, u, v, div, g.pc, g.sc, st);
         if (e != hipSuccess) return e;

@@ -282,10 +282,10 @@ def test_public_interpolation_helpers_vs_reference(golden, name):
 
 @pytest.mark.parametrize("H,W,J,B,steps", [(256, 256, 100, 64, 3), (256, 256, 20, 32, 4), (192, 128, 40, 64, 3), (320, 64, 100, 64, 2),
                                             (128, 128, 20, 128, 3), (128, 256, 8, 64, 3), (512, 256, 24, 32, 2)])
-def test_round_jacobi_kernel_shapes_equal_the_oracle(H, W, J, B, steps):
-    """k_jacobi_round (wave-autonomous rounds of 4 sweeps, one barrier per round) is chosen for batches that fill the chip and sweep
-    counts that are multiples of 4.  Shapes with one band per grid (128 rows), 2..4 bands, 1 / 2 / 4 cells per lane, several launches
-    per projection and a single round per launch: the first, a middle and the last grid stay bit-identical to the oracle."""
+def test_chip_filling_batches_equal_the_oracle(H, W, J, B, steps):
+    """Batches that fill the chip (the band plan depends on the batch through the workgroup count): 1 / 2 / 4 cells per lane, one to
+    several bands per grid, several launches per projection and a handful of sweeps -- the first, a middle and the last grid stay
+    bit-identical to the oracle."""
     rng = np.random.RandomState(H * 7 + W + J)
     sim = SmokeSimulator((H, W), batch_size=B, jacobi_iters=J)
     picks = sorted({0, B // 2 + 1, B - 1})
