@@ -74,13 +74,7 @@ int run_stage(smk_sim *sim, int stage, float *frames, int64_t fsb, const float *
         case SMK_STAGE_BUOY_DIFFUSE:   // s -> t (u2, v2, d2)
             return check_launch(launch_buoy_diffuse(g, s, t, st), "buoy_diffuse");
         case SMK_STAGE_PROJECT: {      // on t.u, t.v with s.p
-            int rc = check_launch(launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st), "project");
-            static const bool dump = getenv("SMK_DEBUG_DUMP_PROJECT") != nullptr;      // diagnostic: expose the projected (u2, v2) as (u, v)
-            if (rc == SMK_OK && dump) {
-                (void)hipMemcpyAsync(s.u, t.u, (size_t)g.B * g.su * sizeof(float), hipMemcpyDeviceToDevice, st);
-                (void)hipMemcpyAsync(s.v, t.v, (size_t)g.B * g.sv * sizeof(float), hipMemcpyDeviceToDevice, st);
-            }
-            return rc;
+            return check_launch(launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st), "project");
         }
         case SMK_STAGE_ADVECT_U:       // u <- adv(u2; u2, v2)
             return check_launch(launch_advect(g, 0, t.u, s.u, t.u, t.v, nullptr, 0, nullptr, 0.f, nullptr, nullptr, st),
@@ -223,8 +217,13 @@ int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t fsb, int6
     const float *fr = (add_fractal && frames) ? sim->fractal : nullptr;
     for (int t = 0; t < n_steps; ++t) {
         float *ft = frames ? frames + (size_t)t * fst : nullptr;
-        for (int stage = SMK_STAGE_BUOY_DIFFUSE; stage <= SMK_STAGE_ADVECT_D; ++stage) {
+        static const bool staged = getenv("SMK_ADVECT_STAGED") != nullptr;      // diagnostic: the three advections as three launches
+        for (int stage = SMK_STAGE_BUOY_DIFFUSE; stage <= (staged ? SMK_STAGE_ADVECT_D : SMK_STAGE_PROJECT); ++stage) {
             rc = run_stage(sim, stage, stage == SMK_STAGE_ADVECT_D ? ft : nullptr, fsb, fr, (float)fractal_intensity, st);
+            if (rc) return rc;
+        }
+        if (!staged) {      // u <- adv(u2; u2, v2), v <- adv(v2; u, v2), density <- adv(d2; u, v) * 0.995 (+ frame) in one launch
+            rc = check_launch(launch_advect_fused(sim->g, sim->t, sim->s, ft, fsb, fr, (float)fractal_intensity, st), "advect_fused");
             if (rc) return rc;
         }
     }

@@ -22,6 +22,9 @@ hipError_t launch_grad_subtract(const Geom &g, float *u, float *v, const float *
 hipError_t launch_advect(const Geom &g, int kind, const float *field, float *out, const float *u, const float *v,
                          float *frames, int64_t frame_stride_b, const float *fractal, float fractal_intensity,
                          int32_t *x0, int32_t *y0, hipStream_t st);
+// The three advections of one step (u, v, density with decay + frame emit) as one launch: in = (u2, v2, -, d2), out = (u, v, -, density).
+hipError_t launch_advect_fused(const Geom &g, StateView in, StateView out, float *frames, int64_t frame_stride_b, const float *fractal,
+                               float fractal_intensity, hipStream_t st);
 // mode 0 bilinear_interpolate, 1 interpolate_velocity_u, 2 interpolate_velocity_v on n caller-given coordinates per field
 // (cstride 0: the B fields share one coordinate list).
 hipError_t launch_interp(int mode, const float *field, int B, int h, int w, int pitch, size_t fstride, const float *y,

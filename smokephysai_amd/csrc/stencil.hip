@@ -605,6 +605,162 @@ hipError_t launch_advect(const Geom &g, int kind, const float *field, float *out
     return hipGetLastError();
 }
 
+
+// ---- the three advections of a step as ONE launch (navier_stokes.py:166-171) --------------------------------------------------------
+// u <- adv(u2; u2, v2), v <- adv(v2; u, v2), density <- adv(d2; u, v) * 0.995 are sequentially dependent, but only through the
+// velocity SAMPLING, which happens at the integer cell coordinates (advection_step builds Y, X with meshgrid, :79-81), where
+// interpolate_velocity_u / _v (:97-109) collapse exactly:
+//   u at (Y = i, x + 0.5): y0 = i with weight (y1 - i) in {1, 0}, x-weights 0.5 / 0.5  ->  ui = 0.5*U[i][j] + 0.5*U[i][j+1]   (i <= H-1, j <= W-2)
+//   v at (y + 0.5, X = j): x0 = j with weight (x1 - j) in {1, 0}, y-weights 0.5 / 0.5  ->  vi = 0.5*V[i][j] + 0.5*V[i+1][j]   (i <= H-2, j <= W-1)
+//   and 0 otherwise (both clamped indices coincide: the zero-at-the-upper-edge quirk).  The dropped terms are products with an exact
+//   zero weight: for finite fields they are +-0 and change at most the sign of a zero, which X - dt*ui cannot see (X >= 0).
+// The displacement-dependent gathers read u2, v2, d2 -- inputs of the launch.  So a workgroup that owns a TH x TW tile of cells stages
+// u2, v2, d2 (tile + 1 halo, + 2 on the high side for u2 / v2) in LDS, computes the advected u on the tile extended by one row and
+// column and the advected v on the tile extended by one row (redundantly with its neighbours: ~5 % more points), keeps both in LDS
+// for the next field's sampling, and writes its own cells of u, v, density and the emitted frame.  A back-trace that leaves the
+// staged window (|dt * velocity| >= 1 cell: never in the reference's regime, |velocity| ~ 0.1) gathers from global memory instead
+// -- one wave-level branch per cell, same values either way.  Per point the gather arithmetic is bilinear()'s (one rounding per
+// reference op).  HBM traffic: u2, v2, d2, fractal in; u, v, density, frame out -- 8 floats per cell instead of the 12 of three
+// launches; vector instructions per cell and field: ~60 instead of ~150 (k_advect evaluates all three bilinears in the general form).
+constexpr int AF_TH = 32, AF_TW = 64, AF_THREADS = 256;
+
+// the final gather of advection_step: bilinear_interpolate(field[R][C], py, px) with py, px already clamped into [0, R-1] x [0, C-1]
+// (:91-92), so floor == truncation and the lower index clamps of :120-123 are no-ops.  `f` = window in LDS (top-left cell (oi, oj),
+// nr x nc, pitch lp) or, when the four taps do not all lie inside it, the field in global memory (pitch gp).
+// (the fallback is a real call: inlined, the compiler merges the two arms into ONE flat_load through a selected generic pointer, and
+// flat loads of LDS addresses run at a fraction of ds_read's rate -- the first version of this kernel took 75 us instead of 3 x 19)
+__device__ __attribute__((noinline)) void gather_far(const float *glob, int gp, int y0, int y1, int x0, int x1, float (&f)[4]) {
+    f[0] = glob[(size_t)y0 * gp + x0]; f[1] = glob[(size_t)y0 * gp + x1];
+    f[2] = glob[(size_t)y1 * gp + x0]; f[3] = glob[(size_t)y1 * gp + x1];
+}
+
+__device__ __forceinline__ float gather_cell(const float *lds, int oi, int oj, int nr, int nc, int lp, const float *glob, int gp, int R,
+                                             int C, float py, float px) {
+    const int x0 = (int)px, y0 = (int)py;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x1 = x1 > C - 1 ? C - 1 : x1;
+    y1 = y1 > R - 1 ? R - 1 : y1;
+    const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
+    const float wa = (fx1 - px) * (fy1 - py);
+    const float wb = (px - fx0) * (fy1 - py);
+    const float wc = (fx1 - px) * (py - fy0);
+    const float wd = (px - fx0) * (py - fy0);
+    float f[4];
+    const int r0 = y0 - oi, r1 = y1 - oi, c0 = x0 - oj, c1 = x1 - oj;
+    if (__builtin_expect(r0 >= 0 && r1 < nr && c0 >= 0 && c1 < nc, 1)) {
+        f[0] = lds[r0 * lp + c0]; f[1] = lds[r0 * lp + c1]; f[2] = lds[r1 * lp + c0]; f[3] = lds[r1 * lp + c1];
+    } else {
+        gather_far(glob, gp, y0, y1, x0, x1, f);
+    }
+    float r = wa * f[0] + wb * f[1];
+    r = r + wc * f[2];
+    r = r + wd * f[3];
+    return r;
+}
+
+__global__ __launch_bounds__(AF_THREADS) void k_advect_fused(Geom g, StateView in, StateView out, float *frames, int64_t fsb,
+                                                            const float *fractal, float fint) {
+    constexpr int TH = AF_TH, TW = AF_TW;
+    constexpr int UR = TH + 3, UC = TW + 3;      // u2 / v2 / d2 windows: rows i0-1 .. i0+TH+1, columns j0-1 .. j0+TW+1
+    constexpr int NR = TH + 1, NC = TW + 1;      // advected u and v: rows i0 .. i0+TH, columns j0 .. j0+TW
+    __shared__ float us[UR * UC], vs[UR * UC], ds[UR * UC], un[NR * NC], vn[NR * NC];
+    const int b = blockIdx.z, i0 = blockIdx.y * TH, j0 = blockIdx.x * TW, tid = threadIdx.x;
+    const int i1 = i0 + TH < g.H ? i0 + TH : g.H, j1 = j0 + TW < g.W ? j0 + TW : g.W;
+    const int H = g.H, W = g.W;
+    const float *u2 = in.u + b * g.su, *v2 = in.v + b * g.sv, *d2 = in.d + b * g.sc;
+    // stage the inputs: all loads of a thread are issued before the first LDS write (addresses clamped into the field instead of
+    // branches: a load under a branch waits for its data before the next one is issued -- 30 serial HBM latencies per thread)
+    constexpr int NST = (UR * UC + AF_THREADS - 1) / AF_THREADS;
+    float ru[NST], rv[NST], rd[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        int idx = tid + it * AF_THREADS;
+        idx = idx < UR * UC ? idx : UR * UC - 1;
+        const int r = idx / UC, c = idx - r * UC, gi = i0 - 1 + r, gj = j0 - 1 + c;
+        const int ci = clampi(gi, 0, H - 1), cj = clampi(gj, 0, W - 1);
+        ru[it] = u2[(size_t)clampi(gi, 0, H) * g.pc + cj];
+        rv[it] = v2[(size_t)ci * g.pv + clampi(gj, 0, W)];
+        rd[it] = d2[(size_t)ci * g.pc + cj];
+    }
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int idx = tid + it * AF_THREADS;
+        if (idx < UR * UC) { us[idx] = ru[it]; vs[idx] = rv[it]; ds[idx] = rd[it]; }
+    }
+    __syncthreads();
+    // window-local index of cell (i, j) of the staged inputs
+    auto wi = [&](int i, int j) { return (i - i0 + 1) * UC + (j - j0 + 1); };
+    // 1. u <- adv(u2; u2, v2) on rows i0 .. i0+TH, columns j0 .. j0+TW (field shape [H+1][W])
+    float *uo = out.u + b * g.su;
+    // thread (ty, tx) walks rows ty, ty + 4, ... of column tx (no index division); the extra column TW is a pass of its own
+    const int tx = tid & 63, ty = tid >> 6;
+    auto adv_u = [&](int r, int c) {
+        const int i = i0 + r, j = j0 + c, idx = r * NC + c;
+        if (i > H || j >= W) return;
+        float ui = 0.f, vi = 0.f;
+        if (i <= H - 1 && j <= W - 2) ui = 0.5f * us[wi(i, j)] + 0.5f * us[wi(i, j + 1)];
+        if (i <= H - 2) vi = 0.5f * vs[wi(i, j)] + 0.5f * vs[wi(i + 1, j)];
+        const float px = clampf((float)j - g.dt * ui, 0.f, (float)(W - 1));
+        const float py = clampf((float)i - g.dt * vi, 0.f, (float)H);
+        const float val = gather_cell(us, i0 - 1, j0 - 1, UR, UC, UC, u2, g.pc, H + 1, W, py, px);
+        un[idx] = val;
+        if ((i < i1 || (i == H && i1 == H)) && j < j1) uo[(size_t)i * g.pc + j] = val;
+    };
+#pragma unroll 3
+    for (int r = ty; r < NR; r += 4) adv_u(r, tx);
+    if (tid < NR) adv_u(tid, TW);
+    __syncthreads();
+    // 2. v <- adv(v2; u, v2) on rows i0 .. i0+TH, columns j0 .. j0+TW (field shape [H][W+1]); u = the advected u in LDS
+    float *vo = out.v + b * g.sv;
+    auto adv_v = [&](int r, int c) {
+        const int i = i0 + r, j = j0 + c, idx = r * NC + c;
+        if (i >= H || j > W) return;
+        float ui = 0.f, vi = 0.f;
+        if (j <= W - 2) ui = 0.5f * un[idx] + 0.5f * un[idx + 1];
+        if (i <= H - 2 && j <= W - 1) vi = 0.5f * vs[wi(i, j)] + 0.5f * vs[wi(i + 1, j)];
+        const float px = clampf((float)j - g.dt * ui, 0.f, (float)W);
+        const float py = clampf((float)i - g.dt * vi, 0.f, (float)(H - 1));
+        const float val = gather_cell(vs, i0 - 1, j0 - 1, UR, UC, UC, v2, g.pv, H, W + 1, py, px);
+        vn[idx] = val;
+        if (i < i1 && (j < j1 || j == W)) vo[(size_t)i * g.pv + j] = val;
+    };
+#pragma unroll 3
+    for (int r = ty; r < NR; r += 4) adv_v(r, tx);
+    if (tid < NR && j0 + TW == W) adv_v(tid, TW);             // column j0+TW is needed only as the field's last column
+    __syncthreads();
+    // 3. density <- adv(d2; u, v) * 0.995 (+ frame emit) on the tile; u, v = the advected fields in LDS
+#pragma unroll 4
+    for (int r = ty; r < TH; r += 4) {
+        const int c = tx, i = i0 + r, j = j0 + c;
+        if (i >= i1 || j >= j1) continue;
+        const int n = r * NC + c;
+        float ui = 0.f, vi = 0.f;
+        if (j <= W - 2) ui = 0.5f * un[n] + 0.5f * un[n + 1];
+        if (i <= H - 2) vi = 0.5f * vn[n] + 0.5f * vn[n + NC];
+        const float px = clampf((float)j - g.dt * ui, 0.f, (float)(W - 1));
+        const float py = clampf((float)i - g.dt * vi, 0.f, (float)(H - 1));
+        float val = gather_cell(ds, i0 - 1, j0 - 1, UR, UC, UC, d2, g.pc, H, W, py, px);
+        val = val * 0.995f;                                           // :171
+        if (frames) {
+            float fr = val;
+            if (fractal) {                                            // fractal_generator.py:62 (F is [W][H], square)
+                float t = fint * fractal[(size_t)i * W + j];
+                t = t * val;
+                fr = val + t;
+            }
+            frames[(size_t)b * fsb + (size_t)i * W + j] = fr;
+        }
+        out.d[b * g.sc + (size_t)i * g.pc + j] = val;
+    }
+}
+
+hipError_t launch_advect_fused(const Geom &g, StateView in, StateView out, float *frames, int64_t fsb, const float *fractal, float fint,
+                               hipStream_t st) {
+    dim3 grid(cdiv(g.W, AF_TW), cdiv(g.H, AF_TH), g.B), block(AF_THREADS);
+    hipLaunchKernelGGL(k_advect_fused, grid, block, 0, st, g, in, out, frames, fsb, fractal, fint);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- the public interpolation helpers (navier_stokes.py:97-131)
 // bilinear_interpolate / interpolate_velocity_u / interpolate_velocity_v as pure gathers on caller-given coordinates (any float:
 // the reference floors to int64 and clamps, so coordinates far outside the field are legal).  floor() is saturated in float
