@@ -458,7 +458,7 @@ def main(argv=None):
         stencil_bytes = B * N * N * 4.0 * (27 + 3 * J)          # algorithmic bytes per stencil pass
         enc_flops = B * 153728.0 * N * N                         # algorithmic flop per encoder launch
         sten_gbs = stencil_bytes / (ms_sim * 1e-3) / 1e9
-        plan = sim.ns_solver.jacobi_plan() if hasattr(sim.ns_solver, "jacobi_plan") else None
+        plan = sim.ns_solver.jacobi_plan()["projection"]
         roof_stencil = {"bound": "hbm", "kernel": "stencil pass (all kernels of one time step, B grids)",
                         "achieved": sten_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sten_gbs / HBM_PEAK_GBS,
                         "traffic": None, "ms_per_launch": ms_sim,

@@ -105,6 +105,11 @@ int smk_sim_backtrace(smk_sim *sim, int32_t which, int32_t *x0, int32_t *y0, voi
  * kind 0 = perlin, 1 = mandelbrot escape counts/100, 2 = 0.7*perlin+0.3*mandelbrot. Square grids only. */
 int smk_sim_fractal(smk_sim *sim, int32_t kind, const float **dev_ptr);
 
+/* Diagnostic: a JSON object (NUL-terminated, written into buf[capacity]) describing how this handle's step is launched -- the
+ * projection's kernel, bands per grid, launches and sweeps per launch.  No reference counterpart (the reference runs 20 separate
+ * sweeps, navier_stokes.py:139-145); bench.py reports it beside the stencil roofline. */
+int smk_sim_describe(smk_sim *sim, char *buf, int64_t capacity);
+
 /* Stand-alone stateless ops (pure functions of the reference) -------------------------------------- */
 /* NavierStokesSimulator.diffusion_step(field, viscosity) (navier_stokes.py:50-72) on [B][R][pitch]. */
 int smk_diffuse(const float *in, float *out, int32_t B, int32_t R, int32_t C, int32_t pitch, double dt,

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "smk_sim_divergence": [C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_sim_backtrace": [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_sim_fractal": [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)],
+    "smk_sim_describe": [C.c_void_p, C.c_char_p, C.c_int64],
     "smk_diffuse": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                     C.c_void_p],
     "smk_apply_fractal": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p],

@@ -1,6 +1,8 @@
 // C ABI of libsmokehip.so (see include/smokehip.h for the contract and the reference interfaces replaced).
 #include <stdlib.h>
 
+#include <string.h>
+
 #include <map>
 #include <mutex>
 #include <vector>
@@ -16,6 +18,47 @@
 namespace smk {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
+
+namespace {
+std::mutex g_dev_mu;
+std::map<int, int> g_num_cu;                                  // device -> CU count
+std::map<std::pair<int, const void *>, int> g_dev_int;        // (device, key) -> cached value / "seen" marker
+int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev;
+}
+}  // namespace
+
+int device_num_cu() {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_num_cu.find(dev);
+    if (it != g_num_cu.end()) return it->second;
+    hipDeviceProp_t prop;
+    int n = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    g_num_cu[dev] = n;
+    return n;
+}
+
+bool first_use_on_device(const void *key) {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    return g_dev_int.emplace(std::make_pair(dev, key), 1).second;
+}
+
+int device_cached_int(const void *key, int (*compute)()) {
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        auto it = g_dev_int.find(std::make_pair(dev, key));
+        if (it != g_dev_int.end()) return it->second;
+    }
+    const int v = compute();                                  // (occupancy queries etc.: outside the lock)
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    return g_dev_int.emplace(std::make_pair(dev, key), v).first->second;
+}
 }  // namespace smk
 
 using namespace smk;
@@ -54,10 +97,23 @@ struct smk_encoder {
 
 namespace {
 
-int set_device(int dev) {
-    SMK_HIP_TRY(hipSetDevice(dev));
-    return SMK_OK;
-}
+// Every entry point runs on its handle's device and leaves the CALLER's current device as it found it (PyTorch tracks its own).
+struct DeviceGuard {
+    int prev = -1, rc = SMK_OK;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) {
+            set_error("hipSetDevice failed for the handle's device");
+            rc = SMK_ERR_HIP;
+        }
+        if (prev == dev) prev = -1;                           // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 int check_launch(hipError_t e, const char *what) {
     if (e != hipSuccess) {
@@ -109,7 +165,8 @@ int smk_sim_create(const smk_sim_desc *d, smk_sim **out) {
         set_error("no HIP device visible");
         return SMK_ERR_NO_DEVICE;
     }
-    int rc = set_device(d->device_id);
+    DeviceGuard guard(d->device_id);
+    int rc = guard.rc;
     if (rc) return rc;
     smk_sim *sim = new smk_sim();
     Geom &g = sim->g;
@@ -145,7 +202,7 @@ int smk_sim_create(const smk_sim_desc *d, smk_sim **out) {
 
 int smk_sim_destroy(smk_sim *sim) {
     if (!sim) return SMK_OK;
-    (void)hipSetDevice(sim->device);
+    DeviceGuard guard(sim->device);              // frees run on the handle's device; the caller's device is restored
     float *ptrs[] = {sim->t.u, sim->t.v, sim->t.p, sim->t.d, sim->div, sim->perlin, sim->mandel, sim->fractal};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (sim->dev_mask) (void)hipFree(sim->dev_mask);
@@ -158,7 +215,8 @@ int smk_sim_destroy(smk_sim *sim) {
 int smk_sim_reset(smk_sim *sim, const uint8_t *grid_mask, void *stream) {
     SMK_REQUIRE(sim, "null sim");
     hipStream_t st = (hipStream_t)stream;
-    int rc = set_device(sim->device);
+    DeviceGuard guard(sim->device);
+    int rc = guard.rc;
     if (rc) return rc;
     const uint8_t *dm = nullptr;
     if (grid_mask) {
@@ -172,7 +230,8 @@ int smk_sim_add_sources(smk_sim *sim, const smk_source *src, int32_t n, void *st
     SMK_REQUIRE(sim && (src || n == 0) && n >= 0, "null sim/sources");
     if (n == 0) return SMK_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = set_device(sim->device);
+    DeviceGuard guard(sim->device);
+    int rc = guard.rc;
     if (rc) return rc;
     const int B = sim->g.B;
     std::vector<int> first(B + 1, 0);
@@ -212,7 +271,8 @@ int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t fsb, int6
         return SMK_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = set_device(sim->device);
+    DeviceGuard guard(sim->device);
+    int rc = guard.rc;
     if (rc) return rc;
     const float *fr = (add_fractal && frames) ? sim->fractal : nullptr;
     for (int t = 0; t < n_steps; ++t) {
@@ -233,7 +293,8 @@ int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t fsb, int6
 int smk_sim_run_stage(smk_sim *sim, int32_t stage, void *stream) {
     SMK_REQUIRE(sim, "null sim");
     hipStream_t st = (hipStream_t)stream;
-    int rc = set_device(sim->device);
+    DeviceGuard guard(sim->device);
+    int rc = guard.rc;
     if (rc) return rc;
     const Geom &g = sim->g;
     const size_t B = g.B;
@@ -271,7 +332,8 @@ int smk_sim_run_stage(smk_sim *sim, int32_t stage, void *stream) {
 
 int smk_sim_divergence(smk_sim *sim, float *out, void *stream) {
     SMK_REQUIRE(sim && out, "null sim/out");
-    int rc = set_device(sim->device);
+    DeviceGuard guard(sim->device);
+    int rc = guard.rc;
     if (rc) return rc;
     const Geom &g = sim->g;
     return check_launch(launch_divergence(g, sim->s.u, sim->s.v, out, g.W, (size_t)g.H * g.W, (hipStream_t)stream),
@@ -280,7 +342,8 @@ int smk_sim_divergence(smk_sim *sim, float *out, void *stream) {
 
 int smk_sim_backtrace(smk_sim *sim, int32_t which, int32_t *x0, int32_t *y0, void *stream) {
     SMK_REQUIRE(sim && x0 && y0 && which >= 0 && which <= 2, "null sim/x0/y0 or which not in 0..2");
-    int rc = set_device(sim->device);
+    DeviceGuard guard(sim->device);
+    int rc = guard.rc;
     if (rc) return rc;
     const StateView &s = sim->s;
     const float *field = which == 0 ? s.u : (which == 1 ? s.v : s.d);
@@ -295,6 +358,20 @@ int smk_sim_fractal(smk_sim *sim, int32_t kind, const float **dev_ptr) {
         return SMK_ERR_UNSUPPORTED;
     }
     *dev_ptr = kind == 0 ? sim->perlin : (kind == 1 ? sim->mandel : sim->fractal);
+    return SMK_OK;
+}
+
+int smk_sim_describe(smk_sim *sim, char *buf, int64_t capacity) {
+    SMK_REQUIRE(sim && buf && capacity > 0, "null sim / buf or no capacity");
+    DeviceGuard guard(sim->device);
+    if (guard.rc) return guard.rc;
+    const std::string d = "{\"projection\": " + describe_projection(sim->g, sim->jacobi_iters) +
+                          ", \"advection\": \"k_advect_fused (u, v, density + frame in one LDS-tiled launch)\", \"launches_per_step\": null}";
+    if ((int64_t)d.size() + 1 > capacity) {
+        set_error("smk_sim_describe: buffer too small");
+        return SMK_ERR_INVALID;
+    }
+    memcpy(buf, d.c_str(), d.size() + 1);
     return SMK_OK;
 }
 
@@ -398,7 +475,8 @@ int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *st
     SMK_REQUIRE(w && out, "null weights/out");
     const float *const *pp = (const float *const *)w;
     for (size_t k = 0; k < sizeof(*w) / sizeof(float *); ++k) SMK_REQUIRE(pp[k], "null weight pointer");
-    int rc = set_device(device_id);
+    DeviceGuard guard(device_id);
+    int rc = guard.rc;
     if (rc) return rc;
     smk_encoder *enc = new smk_encoder();
     enc->device = device_id;
@@ -437,7 +515,7 @@ int smk_encoder_create(const smk_encoder_weights *w, int32_t device_id, void *st
 
 int smk_encoder_destroy(smk_encoder *enc) {
     if (!enc) return SMK_OK;
-    (void)hipSetDevice(enc->device);
+    DeviceGuard guard(enc->device);              // frees run on the handle's device; the caller's device is restored
     if (enc->blob) (void)hipFree(enc->blob);
     if (enc->blob16) (void)hipFree(enc->blob16);
     delete enc;
@@ -463,7 +541,8 @@ int smk_encoder_forward(smk_encoder *enc, const float *frames, int64_t frame_str
     SMK_REQUIRE(frame_stride >= (int64_t)H * W, "frame_stride >= H*W");
     int rc = encoder_shape_ok(B, H, W, input_dim);
     if (rc) return rc;
-    rc = set_device(enc->device);
+    DeviceGuard guard(enc->device);
+    rc = guard.rc;
     if (rc) return rc;
     if (dtype == SMK_F32)
         return check_launch(launch_encoder_f32(frames, frame_stride, B, H, W, enc->e, features, (hipStream_t)stream), "encoder_f32");
@@ -483,7 +562,8 @@ int smk_encoder_forward_tokens(smk_encoder *enc, const float *frames, int64_t fr
     SMK_REQUIRE(frame_stride >= (int64_t)H * W, "frame_stride >= H*W");
     int rc = encoder_shape_ok(B, H, W, input_dim);
     if (rc) return rc;
-    rc = set_device(enc->device);
+    DeviceGuard guard(enc->device);
+    rc = guard.rc;
     if (rc) return rc;
     if (dtype == SMK_I8X3)
         return check_launch(launch_encoder_i8(frames, frame_stride, B, H, W, enc->e, tokens, true, (hipStream_t)stream),
@@ -499,7 +579,8 @@ int smk_encoder_forward_tokens(smk_encoder *enc, const float *frames, int64_t fr
 int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_stride, int32_t B, int32_t H, int32_t W,
                       float *act, void *stream) {
     SMK_REQUIRE(enc && frames && act && B >= 1 && H >= 1 && W >= 1, "null enc/frames/act or bad shape");
-    int rc = set_device(enc->device);
+    DeviceGuard guard(enc->device);
+    int rc = guard.rc;
     if (rc) return rc;
     return check_launch(launch_conv1_only(frames, frame_stride, B, H, W, enc->e, act, (hipStream_t)stream), "conv1");
 }
@@ -513,7 +594,8 @@ int smk_linear_create(const float *weight, const float *bias, int32_t out_featur
         set_error("linear: HIP path is built for in_features % 64 == 0, out_features % 32 == 0, at most 2^28 weights");
         return SMK_ERR_UNSUPPORTED;
     }
-    int rc = set_device(device_id);
+    DeviceGuard guard(device_id);
+    int rc = guard.rc;
     if (rc) return rc;
     smk_linear *lin = new smk_linear();
     lin->device = device_id;
@@ -536,7 +618,7 @@ int smk_linear_create(const float *weight, const float *bias, int32_t out_featur
 
 int smk_linear_destroy(smk_linear *lin) {
     if (!lin) return SMK_OK;
-    (void)hipSetDevice(lin->device);
+    DeviceGuard guard(lin->device);              // frees run on the handle's device; the caller's device is restored
     if (lin->l.wq) (void)hipFree(lin->l.wq);
     if (lin->l.bias) (void)hipFree(lin->l.bias);
     delete lin;
@@ -546,7 +628,8 @@ int smk_linear_destroy(smk_linear *lin) {
 int smk_linear_update(smk_linear *lin, const float *weight, int32_t transposed, const float *bias, void *stream) {
     SMK_REQUIRE(lin && weight, "null lin/weight");
     SMK_REQUIRE(transposed == 0 || transposed == 1, "transposed is 0 or 1");
-    int rc = set_device(lin->device);
+    DeviceGuard guard(lin->device);
+    int rc = guard.rc;
     if (rc) return rc;
     return check_launch(launch_split_linear_weights(weight, bias, lin->l, (hipStream_t)stream, transposed), "split_linear_weights");
 }
@@ -592,7 +675,8 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
     if (periodic_add)
         SMK_REQUIRE(period >= 1 && rows_per_group >= 32 && rows_per_group % 32 == 0 && rows % rows_per_group == 0,
                     "periodic_add: period >= 1, rows_per_group a multiple of 32 that divides rows");
-    int rc = set_device(lin->device);
+    DeviceGuard guard(lin->device);
+    int rc = guard.rc;
     if (rc) return rc;
     LinearCall c;
     c.x = (const float *)x; c.ldx = ldx;
@@ -778,7 +862,8 @@ int smk_decoder_create(const smk_decoder_weights *w, int32_t device_id, void *st
     SMK_REQUIRE(w && out, "null weights/out");
     const float *const *pp = (const float *const *)w;
     for (size_t k = 0; k < sizeof(*w) / sizeof(float *); ++k) SMK_REQUIRE(pp[k], "null weight pointer");
-    int rc = set_device(device_id);
+    DeviceGuard guard(device_id);
+    int rc = guard.rc;
     if (rc) return rc;
     smk_decoder *dec = new smk_decoder();
     dec->device = device_id;
@@ -804,7 +889,7 @@ int smk_decoder_create(const smk_decoder_weights *w, int32_t device_id, void *st
 
 int smk_decoder_destroy(smk_decoder *dec) {
     if (!dec) return SMK_OK;
-    (void)hipSetDevice(dec->device);
+    DeviceGuard guard(dec->device);              // frees run on the handle's device; the caller's device is restored
     if (dec->blob) (void)hipFree(dec->blob);
     delete dec;
     return SMK_OK;
@@ -819,7 +904,8 @@ int smk_decoder_forward(smk_decoder *dec, const float *tokens, int32_t B, int32_
         return SMK_ERR_UNSUPPORTED;
     }
     SMK_REQUIRE(((uintptr_t)tokens & 15) == 0 && ((uintptr_t)tmp1 & 7) == 0 && ((uintptr_t)tmp2 & 7) == 0, "alignment");
-    int rc = set_device(dec->device);
+    DeviceGuard guard(dec->device);
+    int rc = guard.rc;
     if (rc) return rc;
     return check_launch(launch_decoder(dec->d, tokens, B, S, tmp1, tmp2, recon, (hipStream_t)stream), "decoder");
 }

@@ -44,4 +44,10 @@ struct StateView {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Launch-time state is PER DEVICE (a process may hold handles on several GPUs): the CU count, and "has this kernel's dynamic-LDS
+// limit been raised / what did the occupancy query say" keyed by (kernel, current device).  Thread-safe (api.hip).
+int device_num_cu();                                         // CUs of the CURRENT device (cached)
+bool first_use_on_device(const void *key);                   // true exactly once per (key, current device)
+int device_cached_int(const void *key, int (*compute)());    // compute() once per (key, current device), then the cached value
+
 }  // namespace smk

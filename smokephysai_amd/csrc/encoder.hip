@@ -287,12 +287,10 @@ hipError_t launch_encoder_f32(const float *frames, int64_t fstride, int B, int H
     const int PS = H / 32;
     dim3 grid(W / ENC_TW, H / ENC_TH, B), block(512);
     size_t lds_bytes = sizeof(float) * (size_t)(LDS_F32_TOTAL > 256 * A2_PITCH ? LDS_F32_TOTAL : 256 * A2_PITCH);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (first_use_on_device((const void *)k_encoder_f32<8>)) {
         (void)hipFuncSetAttribute((const void *)k_encoder_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute((const void *)k_encoder_f32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute((const void *)k_encoder_f32<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
     }
     switch (PS) {
         case 2: hipLaunchKernelGGL(k_encoder_f32<2>, grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
@@ -960,6 +958,22 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
     }
 }
 
+// Diagnostic switches, read once per process: SMK_ENC_STAGGER (s_sleep units of the second workgroup wave, default 1),
+// SMK_ENC_WGS_PER_CU (override the occupancy query), SMK_ENC_SHAPE=32 (split-bf16 on the 32x32x16 kernel instead of 16x16x32).
+struct EncoderKnobs {
+    int stagger, wgs_per_cu, shape;
+    EncoderKnobs() {
+        const char *sv = getenv("SMK_ENC_STAGGER"), *ov = getenv("SMK_ENC_WGS_PER_CU"), *sh = getenv("SMK_ENC_SHAPE");
+        stagger = sv ? atoi(sv) : 1;
+        wgs_per_cu = ov && atoi(ov) > 0 ? atoi(ov) : 0;
+        shape = sh && atoi(sh) == 32 ? 32 : 16;
+    }
+};
+static const EncoderKnobs &enc_knobs() {
+    static const EncoderKnobs k;
+    return k;
+}
+
 template <bool TOKENS>
 static hipError_t launch_b16_t(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e, float *features,
                                hipStream_t st) {
@@ -969,23 +983,16 @@ static hipError_t launch_b16_t(const float *frames, int64_t fstride, int B, int 
     while ((1 << lg_tx) < tiles_x) ++lg_tx;
     while ((1 << lg_tpf) < tiles_per_frame) ++lg_tpf;
     if ((1 << lg_tx) != tiles_x || (1 << lg_tpf) != tiles_per_frame) return hipErrorInvalidValue;
-    static int stagger = -1;
-    if (stagger < 0) { const char *sv = getenv("SMK_ENC_STAGGER"); stagger = sv ? atoi(sv) : 1; }
-    static int wgs_per_cu = 0, num_cu = 0;
-    if (!wgs_per_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        num_cu = prop.multiProcessorCount;
-        int n = 0;
+    const int stagger = enc_knobs().stagger;
+    const int num_cu = device_num_cu();
+    const int wgs_per_cu = device_cached_int((const void *)k_encoder_b16<8, TOKENS>, [] {
         (void)hipFuncSetAttribute((const void *)k_encoder_b16<8, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS);
         (void)hipFuncSetAttribute((const void *)k_encoder_b16<4, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS);
         (void)hipFuncSetAttribute((const void *)k_encoder_b16<2, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS);
+        int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_encoder_b16<8, TOKENS>, 256, S16_LDS) != hipSuccess || n < 1) n = 2;
-        const char *ov = getenv("SMK_ENC_WGS_PER_CU");
-        if (ov && atoi(ov) > 0) n = atoi(ov);
-        wgs_per_cu = n;
-    }
+        return enc_knobs().wgs_per_cu ? enc_knobs().wgs_per_cu : n;
+    });
     int nwg = num_cu * wgs_per_cu;
     if (nwg > ntiles) nwg = ntiles;
     dim3 grid(nwg), block(256);
@@ -1013,24 +1020,18 @@ static hipError_t launch_bf16_t(const float *frames, int64_t fstride, int B, int
     while ((1 << lg_tx) < tiles_x) ++lg_tx;
     while ((1 << lg_tpf) < tiles_per_frame) ++lg_tpf;
     if ((1 << lg_tx) != tiles_x || (1 << lg_tpf) != tiles_per_frame) return hipErrorInvalidValue;   // H = W in {64,128,256}
-    static int stagger = -1;
-    if (stagger < 0) { const char *sv = getenv("SMK_ENC_STAGGER"); stagger = sv ? atoi(sv) : 1; }
+    const int stagger = enc_knobs().stagger;
     constexpr size_t lds_bytes = b3_lds_total<X3>();
-    static int wgs_per_cu = 0, num_cu = 0;
-    if (!wgs_per_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        num_cu = prop.multiProcessorCount;
+    const int num_cu = device_num_cu();
+    const int wgs_per_cu = device_cached_int((const void *)k_encoder_bf16<X3, 8, TOKENS>, [] {
+        constexpr size_t lb = b3_lds_total<X3>();
+        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 8, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 4, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 2, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
         int n = 0;
-        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 8, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 4, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void *)k_encoder_bf16<X3, 2, TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_encoder_bf16<X3, 8, TOKENS>, 256, lds_bytes) != hipSuccess || n < 1) n = 2;
-        const char *ov = getenv("SMK_ENC_WGS_PER_CU");
-        if (ov && atoi(ov) > 0) n = atoi(ov);
-        wgs_per_cu = n;
-    }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_encoder_bf16<X3, 8, TOKENS>, 256, lb) != hipSuccess || n < 1) n = 2;
+        return enc_knobs().wgs_per_cu ? enc_knobs().wgs_per_cu : n;
+    });
     int nwg = num_cu * wgs_per_cu;
     if (nwg > ntiles) nwg = ntiles;
     dim3 grid(nwg), block(256);
@@ -1047,8 +1048,7 @@ hipError_t launch_encoder_bf16(const float *frames, int64_t fstride, int B, int 
                                float *features, bool x3, bool tokens, hipStream_t st) {
     // split-bf16 runs on the 16x16x32 shape (k_encoder_b16: -7 % time, interleaved A/B); SMK_ENC_SHAPE=32 selects the
     // 32x32x16 kernel (k_encoder_bf16<true>) for comparison
-    static int shape = 0;
-    if (!shape) { const char *sv = getenv("SMK_ENC_SHAPE"); shape = sv && atoi(sv) == 32 ? 32 : 16; }
+    const int shape = enc_knobs().shape;
     if (x3 && shape == 16) return launch_encoder_b16(frames, fstride, B, H, W, e, features, tokens, st);
     if (x3) return tokens ? launch_bf16_t<true, true>(frames, fstride, B, H, W, e, features, st)
                           : launch_bf16_t<true, false>(frames, fstride, B, H, W, e, features, st);
@@ -1404,18 +1404,12 @@ static hipError_t launch_i8_t(const float *frames, int64_t fstride, int B, int H
     while ((1 << lg_tpf) < tiles_per_frame) ++lg_tpf;
     if ((1 << lg_tx) != tiles_x || (1 << lg_tpf) != tiles_per_frame) return hipErrorInvalidValue;
     constexpr size_t lds_bytes = I8_LDS_BYTES;
-    static int wgs_per_cu = 0, num_cu = 0;
-    if (!wgs_per_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        num_cu = prop.multiProcessorCount;
+    const int num_cu = device_num_cu();
+    const int wgs_per_cu = device_cached_int((const void *)k_encoder_i8<8, TOKENS>, [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_encoder_i8<8, TOKENS>, 256, lds_bytes) != hipSuccess || n < 1) n = 2;
-        const char *ov = getenv("SMK_ENC_WGS_PER_CU");
-        if (ov && atoi(ov) > 0) n = atoi(ov);
-        wgs_per_cu = n;
-    }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_encoder_i8<8, TOKENS>, 256, I8_LDS_BYTES) != hipSuccess || n < 1) n = 2;
+        return enc_knobs().wgs_per_cu ? enc_knobs().wgs_per_cu : n;
+    });
     int nwg = num_cu * wgs_per_cu;
     if (nwg > ntiles) nwg = ntiles;
     dim3 grid(nwg), block(256);

@@ -508,11 +508,8 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
 template <int MB, int NW, bool AS, int KS = 1>
 static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     constexpr int lds = KS * ln_lds_bytes<MB, NW>() + (KS - 1) * NW * 64 * MB * 16 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (first_use_on_device((const void *)k_linear_x3<MB, NW, AS, KS>))
         (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
     const int nseg = a.c.nseg;
     const int nwg_max = (NW == 8 || KS > 1 ? 1 : 2) * a.num_cu / nseg;     // 8 waves per CU either way (split-K: one workgroup per CU)
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
@@ -534,13 +531,7 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
 }
 
 hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t st) {
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        num_cu = prop.multiProcessorCount;
-    }
+    const int num_cu = device_num_cu();
     LinearArgs a;
     a.l = l;
     a.c = c;

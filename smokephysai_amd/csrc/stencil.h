@@ -17,6 +17,8 @@ hipError_t launch_divergence(const Geom &g, const float *u, const float *v, floa
 hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, int iters, hipStream_t st);
 // divergence + `iters` Jacobi sweeps + gradient subtraction on (u, v, p); p2 and div are scratch.
 hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st);
+// JSON description of what launch_project does for this geometry (kernel, bands, launches, sweeps per launch, on-chip estimates).
+std::string describe_projection(const Geom &g, int iters);
 hipError_t launch_grad_subtract(const Geom &g, float *u, float *v, const float *p, hipStream_t st);
 // kind 0: field=u (H+1 x W), 1: field=v (H x W+1), 2: density (H x W) with *0.995 decay and optional frame emit.
 hipError_t launch_advect(const Geom &g, int kind, const float *field, float *out, const float *u, const float *v,

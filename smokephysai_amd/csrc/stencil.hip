@@ -504,6 +504,32 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
     return hipGetLastError();                                 // L is even: the result is back in p
 }
 
+// What one projection launches for this geometry, as a JSON object (bench.py reports it as the stencil pass's on-chip bound: the
+// Jacobi sweeps never touch HBM, so what limits them is sweeps x rows per workgroup x vector-issue time, not bytes).
+std::string describe_projection(const Geom &g, int iters) {
+    JacobiPlan pl;
+    char buf[1024];
+    if (iters < 2 || !plan_jacobi(g, pl, iters) || pl.halo < 3 || knobs().unfused) {
+        snprintf(buf, sizeof buf, "{\"kernel\": \"k_jacobi_sweep\", \"launches\": %d, \"sweeps\": %d, \"bound\": \"hbm (one pass over p and div per sweep)\"}",
+                 iters + 2, iters);
+        return buf;
+    }
+    const int cap = pl.halo - 1, L = 2 * ((iters + 2 * cap - 1) / (2 * cap)), TR = JB_NW * pl.rpw;
+    const double wgs = (double)pl.nb * g.B, rounds = ceil(wgs / device_num_cu());
+    // measured (tools/probes/valu_probe, 4 waves per SIMD): a sweep row of 64 VEC-cell lanes = ~18 vector instructions of which 2 are DPP
+    // wave shifts, ~2.6 cycles per instruction and SIMD -> TR rows on 4 SIMDs; plus the publish -> s_barrier -> read round trip per sweep
+    const double valu_us_per_sweep = rounds * (TR / 4.0) * 18.0 * 2.6 / 2100.0;
+    snprintf(buf, sizeof buf,
+             "{\"kernel\": \"k_jacobi_band<%d,%d>\", \"bands_per_grid\": %d, \"rows_per_workgroup\": %d, \"halo_rows\": %d, \"workgroups\": %d, "
+             "\"launches\": %d, \"sweeps\": %d, \"sweeps_per_launch\": %d, \"redundant_row_factor\": %.3f, "
+             "\"vector_issue_us_per_sweep_estimate\": %.3f, \"vector_issue_us_total_estimate\": %.1f, "
+             "\"bound\": \"on-chip: sweeps x (vector issue of rows_per_workgroup rows + one LDS publish/barrier/read round trip); p and div are "
+             "register-resident within a launch\"}",
+             pl.vec, pl.rpw, pl.nb, TR, pl.halo, (int)wgs, L, iters, (iters + L - 1) / L, (double)pl.nb * TR / g.H, valu_us_per_sweep,
+             valu_us_per_sweep * iters);
+    return buf;
+}
+
 // u[1:-1,:] -= dt*(p[1:]-p[:-1]);  v[:,1:-1] -= dt*(p[:,1:]-p[:,:-1])   (:148-149)
 __global__ void k_grad_subtract(Geom g, float *u, float *v, const float *p) {
     int b = blockIdx.z;

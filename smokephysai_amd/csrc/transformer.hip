@@ -338,12 +338,8 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
 }
 
 hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        num_cu = prop.multiProcessorCount;
+    const int num_cu = device_num_cu();
+    if (first_use_on_device((const void *)k_attention_x3<1>)) {
         (void)hipFuncSetAttribute((const void *)k_attention_x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
         (void)hipFuncSetAttribute((const void *)k_attention_x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS);
     }
@@ -586,11 +582,9 @@ __global__ __launch_bounds__(256, 2) void k_attention_bwd_x3(const AttnBwdArgs a
 }
 
 hipError_t launch_attention_bwd_x3(const AttnBwdArgs &a, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (first_use_on_device((const void *)k_attention_bwd_x3<false>)) {
         (void)hipFuncSetAttribute((const void *)k_attention_bwd_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_DQ);
         (void)hipFuncSetAttribute((const void *)k_attention_bwd_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_DKV);
-        attr_done = true;
     }
     const int nwg = a.B * a.H * (a.L / 128);
     hipLaunchKernelGGL(k_attention_bwd_x3<true>, dim3(nwg), dim3(256), AB_LDS_DKV, st, a);

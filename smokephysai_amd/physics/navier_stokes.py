@@ -184,6 +184,13 @@ class NavierStokesSimulator(nn.Module):
         _lib.check(self._L.smk_sim_backtrace(self._handle, which, x0.data_ptr(), y0.data_ptr(), self._st()))
         return (x0, y0) if self.batch_size is not None else (x0[0], y0[0])
 
+    def jacobi_plan(self) -> dict:
+        """How libsmokehip launches this simulator's pressure projection (kernel, bands per grid, launches, sweeps per launch)."""
+        import json
+        buf = C.create_string_buffer(4096)
+        _lib.check(self._L.smk_sim_describe(self._handle, buf, 4096))
+        return json.loads(buf.value.decode())
+
     def step(self) -> torch.Tensor:
         """navier_stokes.py:151-173 -- one time step; returns a copy of the density."""
         out = torch.empty(self._B, self.h, self.w, device=self._dev)
