@@ -245,6 +245,19 @@ int smk_bn_relu_pool_backward(const float *z, const float *dout, int32_t B, int3
                               const float *beta, const float *mean, const float *rstd, int32_t pool, float *dz, float *dgamma,
                               float *dbeta, void *workspace, void *stream);
 
+/* The passes of the two calls above one at a time, for BatchNorm statistics that span several processes: data-parallel training
+ * (train.py under DistributedDataParallel) gives every process a shard of the batch, while the reference's BatchNorm2d layers see the
+ * whole batch of ONE process (smokephys_net.py:26,29; train.py:59-93).  The host all-reduces the per-channel statistics between the
+ * phases (models/sync_bn.py).  Unused pointers may be NULL.
+ *   SMK_BN_STATS     z -> mean / var (biased) / rstd [C] of THIS process's batch (workspace as above);
+ *   SMK_BN_APPLY     out = blockmean(relu(bn(z))) from the GIVEN mean / rstd;
+ *   SMK_BN_BWD_SUMS  dout, z, given mean / rstd -> this process's dgamma = sum dy * zhat and dbeta = sum dy (workspace);
+ *   SMK_BN_BWD_DZ    dz from the GIVEN (all-reduced) dgamma / dbeta and count = elements per channel of the GLOBAL batch. */
+enum smk_bn_phase { SMK_BN_STATS = 0, SMK_BN_APPLY = 1, SMK_BN_BWD_SUMS = 2, SMK_BN_BWD_DZ = 3 };
+int smk_bn_relu_pool_phase(int32_t phase, const float *z, const float *dout, int32_t B, int32_t C, int32_t H, int32_t W, const float *gamma,
+                           const float *beta, double eps, float *mean, float *var, float *rstd, int32_t pool, float *out, float *dz,
+                           float *dgamma, float *dbeta, double count, void *workspace, void *stream);
+
 /* The chaos term of one ChaosAttention layer folded into Q (chaos_attention.py:39-66 lorenz_system + generate_chaos_field,
  * :85-100 chaos_proj / chaos_gate / chaos_strength): noise [3][B] = the three randn(B,1) draws (before the 0.1 scale),
  * proj_w [D][3], proj_b [D], gate_w [D], gate_b [1] (PyTorch layouts) -> addend [B][5][ld_addend] (columns 0..D-1

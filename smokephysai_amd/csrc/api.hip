@@ -820,6 +820,42 @@ int smk_bn_relu_pool_backward(const float *z, const float *dout, int32_t B, int3
     return check_launch(launch_bn_relu_pool_backward(a, (hipStream_t)stream), "bn_relu_pool_backward");
 }
 
+// The passes of smk_bn_relu_pool_forward / _backward one at a time, for BatchNorm statistics that span several processes
+// (models/sync_bn.py all-reduces the per-channel statistics between them).  phase:
+//   SMK_BN_STATS        z -> mean / var (biased) / rstd of THIS process's batch                      (needs workspace)
+//   SMK_BN_APPLY        out = blockmean(relu(bn(z))) from the GIVEN mean / rstd
+//   SMK_BN_BWD_SUMS     dout, z, given mean / rstd -> this process's dgamma = sum dy * zhat, dbeta = sum dy   (needs workspace)
+//   SMK_BN_BWD_DZ       dz from the GIVEN (all-reduced) dgamma / dbeta and `count` = elements per channel of the global batch
+int smk_bn_relu_pool_phase(int32_t phase, const float *z, const float *dout, int32_t B, int32_t C, int32_t H, int32_t W, const float *gamma,
+                           const float *beta, double eps, float *mean, float *var, float *rstd, int32_t pool, float *out, float *dz,
+                           float *dgamma, float *dbeta, double count, void *workspace, void *stream) {
+    SMK_REQUIRE(z && gamma && beta && mean && rstd, "null pointer");
+    int rc = bn_check(B, C, H, W, pool);
+    if (rc) return rc;
+    SMK_REQUIRE(((uintptr_t)z & 15) == 0, "16-byte aligned z");
+    BnTrainArgs a = {};
+    a.z = z; a.gamma = gamma; a.beta = beta; a.B = B; a.C = C; a.H = H; a.W = W; a.pool = pool; a.eps = (float)eps;
+    a.part = (float *)workspace; a.mean = mean; a.var = var; a.rstd = rstd;
+    a.out = out; a.dout = dout; a.dz = dz; a.dgamma = dgamma; a.dbeta = dbeta; a.count = (float)count;
+    hipStream_t st = (hipStream_t)stream;
+    switch (phase) {
+        case SMK_BN_STATS:
+            SMK_REQUIRE(var && workspace && ((uintptr_t)workspace & 15) == 0, "stats: var and an aligned workspace");
+            return check_launch(launch_bn_stats(a, st), "bn_stats");
+        case SMK_BN_APPLY:
+            SMK_REQUIRE(out && ((uintptr_t)out & 15) == 0, "apply: aligned out");
+            return check_launch(launch_bn_relu_pool_apply(a, st), "bn_relu_pool_apply");
+        case SMK_BN_BWD_SUMS:
+            SMK_REQUIRE(dout && dgamma && dbeta && workspace && (((uintptr_t)dout | (uintptr_t)workspace) & 15) == 0, "sums: dout, dgamma, dbeta, workspace");
+            return check_launch(launch_bn_relu_pool_backward_sums(a, st), "bn_relu_pool_backward_sums");
+        case SMK_BN_BWD_DZ:
+            SMK_REQUIRE(dout && dz && dgamma && dbeta && count > 0 && (((uintptr_t)dout | (uintptr_t)dz) & 15) == 0, "dz: dout, dz, dgamma, dbeta, count > 0");
+            return check_launch(launch_bn_relu_pool_backward_dz(a, st), "bn_relu_pool_backward_dz");
+    }
+    set_error("bn_relu_pool_phase: unknown phase");
+    return SMK_ERR_INVALID;
+}
+
 // ------------------------------------------------------------------ LayerNorm
 int smk_layernorm(const float *x, int64_t rows, int32_t D, int64_t ldx, const float *weight, const float *bias, double eps,
                   void *y, int64_t ldy, int32_t y_format, void *stream) {

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_pool_bwd(const BnTrainArgs a) {
     }
     float k1 = 0.f, k2 = 0.f;
     if (MODE == 1) {
-        const float n = (float)a.B * (float)a.H * (float)a.W;
+        const float n = a.count > 0.f ? a.count : (float)a.B * (float)a.H * (float)a.W;
         k1 = a.dbeta[c] / n;
         k2 = a.dgamma[c] / n;
     }
@@ -177,6 +177,54 @@ hipError_t launch_bn_relu_pool_forward(const BnTrainArgs &a, hipStream_t st) {
         case 1: hipLaunchKernelGGL(k_bn_relu_pool_fwd<1>, grid, block, 0, st, a); break;
         case 4: hipLaunchKernelGGL(k_bn_relu_pool_fwd<4>, grid, block, 0, st, a); break;
         case 8: hipLaunchKernelGGL(k_bn_relu_pool_fwd<8>, grid, block, 0, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_stats(const BnTrainArgs &a, hipStream_t st) {
+    const int nch = bn_chunks(a);
+    dim3 grid(nch, a.C), block(256);
+    switch (a.pool) {
+        case 1: hipLaunchKernelGGL(k_bn_stats<1>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(k_bn_stats<4>, grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL(k_bn_stats<8>, grid, block, 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k_bn_finish, dim3(a.C), block, 0, st, a, nch, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_pool_apply(const BnTrainArgs &a, hipStream_t st) {
+    dim3 grid(bn_chunks(a), a.C), block(256);
+    switch (a.pool) {
+        case 1: hipLaunchKernelGGL(k_bn_relu_pool_fwd<1>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(k_bn_relu_pool_fwd<4>, grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL(k_bn_relu_pool_fwd<8>, grid, block, 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_pool_backward_sums(const BnTrainArgs &a, hipStream_t st) {
+    const int nch = bn_chunks(a);
+    dim3 grid(nch, a.C), block(256);
+    switch (a.pool) {
+        case 1: hipLaunchKernelGGL((k_bn_relu_pool_bwd<1, 0>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_bn_relu_pool_bwd<4, 0>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_bn_relu_pool_bwd<8, 0>), grid, block, 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k_bn_finish, dim3(a.C), block, 0, st, a, nch, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_pool_backward_dz(const BnTrainArgs &a, hipStream_t st) {
+    dim3 grid(bn_chunks(a), a.C), block(256);
+    switch (a.pool) {
+        case 1: hipLaunchKernelGGL((k_bn_relu_pool_bwd<1, 1>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_bn_relu_pool_bwd<4, 1>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_bn_relu_pool_bwd<8, 1>), grid, block, 0, st, a); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

@@ -24,7 +24,8 @@ from .decoder import HipDecoder, decoder_weight_dict, hip_decoder_supported
 from .encoder import HipEncoder, encoder_weight_dict
 from .hip_body import HipBody
 from .linear import TrainableHipLinear, hip_linear_supported
-from .norm import hip_bn_relu_pool
+from .norm import hip_bn_relu_pool, hip_sync_bn_relu_pool
+from .sync_bn import SyncBatchNorm2d
 from .physics_regularizer import PhysicsRegularizer
 
 
@@ -51,10 +52,16 @@ def _avg_pool_to(t: torch.Tensor, size) -> torch.Tensor:
 
 
 def _hip_bn_ok(bn) -> bool:
-    """The fused libsmokehip BatchNorm + ReLU + pool block implements exactly a training-mode affine nn.BatchNorm2d with running
-    statistics and a fixed momentum.  Anything else -- SyncBatchNorm (cross-rank statistics), a frozen block (bn.eval() inside
-    model.train()), momentum=None (cumulative average), track_running_stats=False, affine=False -- runs the PyTorch modules."""
-    return (type(bn) is nn.BatchNorm2d and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None)
+    """The fused libsmokehip BatchNorm + ReLU + pool block implements exactly a training-mode affine nn.BatchNorm2d (or this package's
+    SyncBatchNorm2d: the same passes with the statistics all-reduced in between) with running statistics and a fixed momentum.
+    Anything else -- torch.nn.SyncBatchNorm, a frozen block (bn.eval() inside model.train()), momentum=None (cumulative average),
+    track_running_stats=False, affine=False -- runs the PyTorch modules."""
+    return (type(bn) in (nn.BatchNorm2d, SyncBatchNorm2d) and bn.training and bn.affine and bn.track_running_stats
+            and bn.momentum is not None)
+
+
+def _bn_relu_pool(z, bn, pool):
+    return hip_sync_bn_relu_pool(z, bn, pool) if isinstance(bn, SyncBatchNorm2d) else hip_bn_relu_pool(z, bn, pool)
 
 
 def _mlp(din: int, dhid: int, dout: int, linear=nn.Linear) -> nn.Sequential:
@@ -162,8 +169,8 @@ class SmokePhysNet(nn.Module):
                     and pool.output_size[0] == pool.output_size[1] and H % mid == 0 and mid % 32 == 0):
                 # libsmokehip: BatchNorm (batch statistics) + ReLU as two passes over the conv output, and for the second block
                 # the two average pools (one P x P block mean) in the same pass -- the 256 x 256 x 128 maps are never written
-                a1 = hip_bn_relu_pool(conv1(x), bn1, 1)
-                return hip_bn_relu_pool(conv2(a1), bn2, P)
+                a1 = _bn_relu_pool(conv1(x), bn1, 1)
+                return _bn_relu_pool(conv2(a1), bn2, P)
             encoded = x
             for m in self.input_encoder:
                 encoded = _avg_pool_to(encoded, m.output_size) if isinstance(m, nn.AdaptiveAvgPool2d) else m(encoded)

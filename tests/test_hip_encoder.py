@@ -220,3 +220,69 @@ def test_training_encoder_path_on_hip_norm_blocks_matches_the_pytorch_path():
             assert float(p.grad.abs().max()) < 1e-3 * scale, n
     for k in ("1.running_mean", "1.running_var", "4.running_mean", "4.running_var"):
         assert err(hip.input_encoder.state_dict()[k], ref.input_encoder.state_dict()[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("pool,shape", [(1, (3, 8, 64, 64)), (8, (2, 16, 128, 256)), (4, (4, 8, 64, 128))])
+def test_sync_bn_relu_pool_phases_equal_the_fused_call_and_full_batch_statistics(pool, shape):
+    """SyncBatchNorm2d on libsmokehip (smk_bn_relu_pool_phase: statistics / apply / gradient sums / dz as separate passes with the
+    host's all-reduce in between).  One process: identical to the fused training BatchNorm call.  Two shards of one batch processed
+    with the COMBINED statistics (what the all-gather yields on two ranks): outputs, dz and the summed dgamma / dbeta equal the
+    single-process full-batch result."""
+    from smokephysai_amd.models import norm as N
+    from smokephysai_amd.models.sync_bn import SyncBatchNorm2d
+    torch.manual_seed(pool)
+    B, C, H, W = shape
+    z = (torch.randn(B, C, H, W, device="cuda") * 1.5 + 0.3).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    sbn = SyncBatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        sbn.weight.copy_(bn.weight); sbn.bias.copy_(bn.bias)
+    go = torch.randn(B, C, H // pool, W // pool, device="cuda")
+    ref = N.hip_bn_relu_pool(z, bn, pool)
+    ref.backward(go)
+    gz_ref, gw_ref, gb_ref = z.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()
+    z.grad = None
+    out = N.hip_sync_bn_relu_pool(z, sbn, pool)                      # no process group: world size 1
+    out.backward(go)
+    assert torch.equal(out, ref) and torch.equal(z.grad, gz_ref)
+    assert torch.equal(sbn.weight.grad, gw_ref) and torch.equal(sbn.bias.grad, gb_ref)
+    assert torch.allclose(sbn.running_var, bn.running_var, rtol=1e-6) and torch.allclose(sbn.running_mean, bn.running_mean, rtol=1e-6, atol=1e-8)
+    # two "ranks": shards [0:h] and [h:B]; statistics combined as _combine_stats does after the all-gather
+    L = N._lib.load()
+    dev = z.device
+    h = B // 2 if B > 2 else 1
+    shards = [z.detach()[:h].contiguous(), z.detach()[h:].contiguous()]
+    gos = [go[:h].contiguous(), go[h:].contiguous()]
+    w, b = bn.weight.detach(), bn.bias.detach()
+    st = []
+    for zs in shards:
+        s = torch.empty(3, C, device=dev)
+        ws = torch.empty(int(L.smk_bn_train_workspace(zs.shape[0], C, H, W, pool)), device=dev, dtype=torch.uint8)
+        N._phase(L, N.BN_STATS, zs, None, w, b, bn.eps, s[0], s[1], s[2], pool, None, None, None, None, 0.0, ws, dev)
+        st.append(s)
+    n = torch.tensor([float(zs.shape[0] * H * W) for zs in shards], device=dev, dtype=torch.float64)[:, None]
+    means = torch.stack([s[0] for s in st]).double(); vars_ = torch.stack([s[1] for s in st]).double()
+    gmean = (means * n).sum(0) / n.sum()
+    gvar = ((vars_ + (means - gmean) ** 2) * n).sum(0) / n.sum()
+    gm, gr = gmean.float().contiguous(), torch.rsqrt(gvar.float() + bn.eps).contiguous()
+    outs, sums = [], []
+    for zs, g in zip(shards, gos):
+        o = torch.empty(zs.shape[0], C, H // pool, W // pool, device=dev)
+        N._phase(L, N.BN_APPLY, zs, None, w, b, bn.eps, gm, None, gr, pool, o, None, None, None, 0.0, None, dev)
+        outs.append(o)
+        d = torch.empty(2, C, device=dev)
+        ws = torch.empty(int(L.smk_bn_train_workspace(zs.shape[0], C, H, W, pool)), device=dev, dtype=torch.uint8)
+        N._phase(L, N.BN_BWD_SUMS, zs, g, w, b, 0.0, gm, None, gr, pool, None, None, d[0], d[1], 0.0, ws, dev)
+        sums.append(d)
+    tot = sums[0] + sums[1]
+    dzs = []
+    for zs, g in zip(shards, gos):
+        dz = torch.empty_like(zs)
+        N._phase(L, N.BN_BWD_DZ, zs, g, w, b, 0.0, gm, None, gr, pool, None, dz, tot[0], tot[1], float(n.sum()), None, dev)
+        dzs.append(dz)
+    scale = float(gz_ref.abs().max())
+    assert float((torch.cat(outs) - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert float((torch.cat(dzs) - gz_ref).abs().max()) <= 2e-5 * scale
+    assert torch.allclose(tot[0], gw_ref, rtol=1e-4, atol=1e-4 * float(gw_ref.abs().max()))
+    assert torch.allclose(tot[1], gb_ref, rtol=1e-4, atol=1e-4 * float(gb_ref.abs().max()))
