@@ -109,7 +109,8 @@ class _HipSyncBnReluPoolFn(torch.autograd.Function):
         ws = torch.empty(int(L.smk_bn_train_workspace(B, C, H, W, pool)), device=dev, dtype=torch.uint8)
         _phase(L, BN_STATS, z, None, w, b, eps, stats[0], stats[1], stats[2], pool, None, None, None, None, 0.0, ws, dev)
         gmean, gvar, N = _combine_stats(stats[0], stats[1], B * H * W, group)
-        grstd = torch.rsqrt(gvar + eps)
+        # one process: the kernel's own 1 / sqrtf(var + eps) (bit-identical to the fused call); several: the same expression on the combined variance
+        grstd = stats[2] if gvar is stats[1] else 1.0 / torch.sqrt(gvar + eps)
         out = torch.empty(B, C, H // pool, W // pool, device=dev, dtype=torch.float32)
         gm, gr = gmean.contiguous(), grstd.contiguous()
         _phase(L, BN_APPLY, z, None, w, b, eps, gm, None, gr, pool, out, None, None, None, 0.0, None, dev)
