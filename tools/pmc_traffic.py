@@ -24,10 +24,20 @@ def read_counters(d):
     return out
 
 
+def build_stamp():
+    """What the counters were taken on: hash of the kernel sources + ABI header (bench.py compares it with its own build)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.source_stamp()
+
+
 def main():
     root, steps = sys.argv[1], int(sys.argv[2])
+    dtype = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
     cal_bytes = 1536 * 256 * 256 * 4.0
-    res = {"units": "bytes per launch (stencil: per time step of 64 grids)", "calibration": {}}
+    res = {"units": "bytes per launch (stencil: per time step of 64 grids)", "stamp": build_stamp(), "encoder_dtype": dtype,
+           "source": "tools/profile.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), fetch x calibration factor",
+           "calibration": {}}
     factors = {}
     for name, sub in (("fetch", "cal_fetch"), ("write", "cal_write")):
         c = read_counters(os.path.join(root, sub))

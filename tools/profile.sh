@@ -12,13 +12,13 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$R/bench.py --steps $STEPS --warmup 2 --cpu-frames 0 --no-inference --no-alt --encoder-dtype $DTYPE"
+ARGS="$R/bench.py --steps $STEPS --warmup 2 --cpu-frames 0 --no-inference --no-alt --no-config1 --encoder-dtype $DTYPE"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || echo "fetch pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1 || echo "write pass failed"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- python3 $R/tools/pmc_calibrate.py > $OUT/cal_fetch.log 2>&1 || echo "cal fetch failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- python3 $R/tools/pmc_calibrate.py > $OUT/cal_write.log 2>&1 || echo "cal write failed"
 cd $R
-python3 tools/pmc_traffic.py $OUT $STEPS > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
+python3 tools/pmc_traffic.py $OUT $STEPS $DTYPE > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
 cat $OUT/pmc_traffic.json
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
