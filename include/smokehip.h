@@ -208,10 +208,11 @@ int smk_linear_update(smk_linear *lin, const float *weight, int32_t transposed, 
  * The reduction runs over the token rows, cut into segments that share one launch; the partial sums are added in segment order
  * (deterministic).  `workspace`: smk_linear_wgrad_workspace(rows, out, in) bytes of device memory, 16-byte aligned, owned by the
  * caller and free for reuse once the enqueued work has run.  Requires in_features % 32 == 0, out_features % 4 == 0,
- * (out_features + 256) * (rows + 4096) < 2^30 (longer inputs: call per row chunk and add).  Enqueued on `stream`. */
+ * (out_features + 256) * (rows + 4096) < 2^30 (longer inputs: call per row chunk and add).  db (may be NULL): the bias gradient
+ * [out_features] = column sums of dy, taken from the transposed copy the call makes anyway.  Enqueued on `stream`. */
 int64_t smk_linear_wgrad_workspace(int64_t rows, int32_t out_features, int32_t in_features);
 int smk_linear_wgrad(const float *dy, int64_t ld_dy, const float *x, int64_t ldx, int64_t rows, int32_t out_features,
-                     int32_t in_features, float *dw, void *workspace, int64_t workspace_bytes, void *stream);
+                     int32_t in_features, float *dw, float *db, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* y = act(x W^T + b + addend) + residual over `rows` token rows:
  *   x [rows][in_features], row pitch ldx floats; y [rows][out_features], row pitch ldy (all row starts 16-byte aligned);

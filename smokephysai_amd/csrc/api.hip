@@ -640,7 +640,7 @@ int64_t smk_linear_wgrad_workspace(int64_t rows, int32_t out_features, int32_t i
 }
 
 int smk_linear_wgrad(const float *dy, int64_t ld_dy, const float *x, int64_t ldx, int64_t rows, int32_t out_features,
-                     int32_t in_features, float *dw, void *workspace, int64_t workspace_bytes, void *stream) {
+                     int32_t in_features, float *dw, float *db, void *workspace, int64_t workspace_bytes, void *stream) {
     SMK_REQUIRE(dy && x && dw && workspace, "null dy/x/dw/workspace");
     SMK_REQUIRE(rows >= 1 && out_features >= 1 && in_features >= 1, "positive sizes");
     if (in_features % 32 != 0 || out_features % 4 != 0) {
@@ -651,7 +651,7 @@ int smk_linear_wgrad(const float *dy, int64_t ld_dy, const float *x, int64_t ldx
     SMK_REQUIRE((int64_t)(out_features + 256) * (rows + 4096) < (1LL << 30), "(out_features + 256) * (rows + 4096) < 2^30: chunk the rows");
     SMK_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dw & 15) == 0, "workspace / dw 16-byte aligned");
     SMK_REQUIRE(workspace_bytes >= smk_linear_wgrad_workspace(rows, out_features, in_features), "workspace too small");
-    return check_launch(launch_linear_wgrad(dy, ld_dy, x, ldx, rows, out_features, in_features, dw, workspace, (hipStream_t)stream),
+    return check_launch(launch_linear_wgrad(dy, ld_dy, x, ldx, rows, out_features, in_features, dw, db, workspace, (hipStream_t)stream),
                         "linear_wgrad");
 }
 

@@ -33,6 +33,6 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
 struct WgradPlan { int nseg; long long rows_pad; size_t off_wq, off_part, bytes; };
 WgradPlan plan_linear_wgrad(long long rows, int out_features, int in_features);
 hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x, long long ldx, long long rows, int out_features,
-                               int in_features, float *dw, void *workspace, hipStream_t st);
+                               int in_features, float *dw, float *db, void *workspace, hipStream_t st);
 
 }  // namespace smk

@@ -646,6 +646,28 @@ __global__ __launch_bounds__(256) void k_sum_segments(const float *__restrict__ 
     }
 }
 
+// db[o] = sum over the token rows of dY[:, o]: one workgroup per output feature sums its row of the transposed copy dY^T (contiguous, still in
+// the Infinity Cache right after k_transpose_pad; zero-padded, so no tail handling), 8 floats per thread and step, fixed-order tree.
+__global__ __launch_bounds__(256) void k_row_sums(const float *__restrict__ dyt, int rows_pad, float *__restrict__ db) {
+    const float4 *row = reinterpret_cast<const float4 *>(dyt + (size_t)blockIdx.x * rows_pad);
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < rows_pad / 4; i += 512) {
+        const float4 v = row[i];
+        a += (v.x + v.y) + (v.z + v.w);
+        if (i + 256 < rows_pad / 4) {
+            const float4 w = row[i + 256];
+            b += (w.x + w.y) + (w.z + w.w);
+        }
+    }
+    float s = a + b;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 WgradPlan plan_linear_wgrad(long long rows, int out_f, int in_f) {
     WgradPlan p;
     const long long tiles = (long long)cdiv(out_f, 128) * cdiv(in_f, 128);
@@ -661,7 +683,7 @@ WgradPlan plan_linear_wgrad(long long rows, int out_f, int in_f) {
 }
 
 hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x, long long ldx, long long rows, int out_f, int in_f,
-                               float *dw, void *workspace, hipStream_t st) {
+                               float *dw, float *db, void *workspace, hipStream_t st) {
     const WgradPlan p = plan_linear_wgrad(rows, out_f, in_f);
     float *dyt = reinterpret_cast<float *>(workspace);
     LinearDev l;
@@ -672,6 +694,7 @@ hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x,
     float *part = p.nseg > 1 ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(workspace) + p.off_part) : dw;
     hipLaunchKernelGGL(k_transpose_pad, dim3((unsigned)(p.rows_pad / 32), cdiv(out_f, 32)), dim3(256), 0, st, dy, ld_dy, (int)rows, out_f, dyt,
                        (int)p.rows_pad);
+    if (db) hipLaunchKernelGGL(k_row_sums, dim3(out_f), dim3(256), 0, st, dyt, (int)p.rows_pad, db);      // the bias gradient, from the same copy
     hipError_t e = launch_split_linear_weights(x, nullptr, l, st, 1, ldx, (int)rows);
     if (e != hipSuccess) return e;
     l.K = (int)(p.rows_pad / p.nseg);                       // segment length

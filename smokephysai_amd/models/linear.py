@@ -152,8 +152,9 @@ def hip_linear_wgrad_supported(in_features: int, out_features: int) -> bool:
 MAX_WGRAD_ROWS = 1 << 17     # rows per smk_linear_wgrad call ((out + 256) * (rows + 4096) < 2^30 holds up to out = 7,680); more: chunk + add
 
 
-def hip_linear_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW [out, in] = dy^T x over the token rows (dy [rows, out], x [rows, in], fp32 on one ROCm device) -- smk_linear_wgrad."""
+def hip_linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_db: bool = False):
+    """dW [out, in] = dy^T x over the token rows (dy [rows, out], x [rows, in], fp32 on one ROCm device) -- smk_linear_wgrad.
+    want_db: also return the bias gradient db [out] = dy.sum(0) (from the transposed copy of dy the call makes anyway)."""
     dev = _lib.require_cuda(dy.device, "hip_linear_wgrad")
     L = _lib.load()
     if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0] or dy.dtype != torch.float32 or x.dtype != torch.float32 or x.device != dev:
@@ -164,19 +165,22 @@ def hip_linear_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         x = x.contiguous()
     rows, out_f, in_f = dy.shape[0], dy.shape[1], x.shape[1]
     dw = torch.empty(out_f, in_f, device=dev, dtype=torch.float32)
-    total = None
+    db = torch.empty(out_f, device=dev, dtype=torch.float32) if want_db else None
     r0 = 0
     while r0 < rows:
         n = min(MAX_WGRAD_ROWS, rows - r0)
         nbytes = int(L.smk_linear_wgrad_workspace(n, out_f, in_f))
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)      # torch's caching allocator: stream-ordered reuse
         tgt = dw if r0 == 0 else torch.empty_like(dw)
+        tgb = None if db is None else (db if r0 == 0 else torch.empty_like(db))
         _lib.check(L.smk_linear_wgrad(dy[r0:].data_ptr(), dy.stride(0), x[r0:].data_ptr(), x.stride(0), n, out_f, in_f,
-                                      tgt.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr(dev)))
+                                      tgt.data_ptr(), None if tgb is None else tgb.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr(dev)))
         if r0:
             dw += tgt
+            if db is not None:
+                db += tgb
         r0 += n
-    return dw
+    return (dw, db) if want_db else dw
 
 
 class _HipLinearFn(torch.autograd.Function):
@@ -204,10 +208,13 @@ class _HipLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, mod.in_features)
             if mod.hip_wgrad and hip_linear_wgrad_supported(mod.in_features, mod.out_features):
-                dw = hip_linear_wgrad(dy2, x2)
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    dw, db = hip_linear_wgrad(dy2, x2, want_db=True)      # db rides on the transposed copy of dy
+                else:
+                    dw = hip_linear_wgrad(dy2, x2)
             else:
                 dw = dy2.t().mm(x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(0)
         return dx, dw, db, None
 

@@ -171,6 +171,11 @@ def test_weight_gradient_matches_fp64(rows, out_f, in_f):
     e_hip = rel_err(dw.cpu().numpy(), ref.cpu().numpy())
     assert dw.shape == (out_f, in_f) and e_hip < TOL and e_hip < 2e-5, e_hip
     assert torch.equal(dw, hip_linear_wgrad(dy, x))
+    # the bias gradient rides on the call's transposed copy of dY
+    dw2, db = hip_linear_wgrad(dy, x, want_db=True)
+    assert torch.equal(dw2, dw) and db.shape == (out_f,)
+    ref_b = dy.double().sum(0)
+    assert float((db.double() - ref_b).abs().max()) <= 2e-6 * float(dy.abs().sum(0).max())
 
 
 def test_weight_gradient_row_chunking(monkeypatch):
@@ -183,3 +188,5 @@ def test_weight_gradient_row_chunking(monkeypatch):
     parts = hl.hip_linear_wgrad(dy, x)
     ref = dy.double().t() @ x.double()
     assert rel_err(parts.cpu().numpy(), ref.cpu().numpy()) < 2e-5 and rel_err(whole.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+    _, db = hl.hip_linear_wgrad(dy, x, want_db=True)                # chunked: per-chunk column sums added
+    assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-3
