@@ -229,6 +229,17 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream);
 
+/* The element-wise chain of ChaosTransformerLayer's FFN under autograd (smokephys_net.py:153-159 Linear -> GELU -> Dropout -> Linear ->
+ * Dropout, :165-167 x = x + ffn(norm2(x)); train.py:88-89) as one read + one write per tensor, n contiguous fp32 elements (n % 4 == 0):
+ *   SMK_ELT_GELU_DROPOUT_FWD   out = dropout_p(gelu(a))                      a = the first Linear's output h
+ *   SMK_ELT_GELU_DROPOUT_BWD   out = b * mask / (1 - p) * gelu'(a)           a = h, b = gradient of the dropout's output
+ *   SMK_ELT_DROPOUT_ADD_FWD    out = b + dropout_p(a)                        a = the second Linear's output, b = the residual stream
+ *   SMK_ELT_DROPOUT_BWD        out = a * mask / (1 - p)                      a = gradient of the sum (the residual's gradient is a itself)
+ * GELU is the exact-erf form (nn.GELU() default).  The keep mask of element i is a pure function of (seed, i): the backward call
+ * passes the forward's seed and p and no mask tensor exists (p is applied in units of 2^-16; p = 0 keeps every element). */
+enum smk_elt_op { SMK_ELT_GELU_DROPOUT_FWD = 0, SMK_ELT_GELU_DROPOUT_BWD = 1, SMK_ELT_DROPOUT_ADD_FWD = 2, SMK_ELT_DROPOUT_BWD = 3 };
+int smk_ffn_elementwise(int32_t op, const float *a, const float *b, float *out, int64_t n, double p, uint64_t seed, void *stream);
+
 /* Training-mode BatchNorm2d (batch statistics) + ReLU + pool x pool mean pooling of an NCHW fp32 convolution output -- the
  * norm / activation / pool blocks of SmokePhysNet.input_encoder under autograd (smokephys_net.py:24-32 Conv -> BatchNorm2d -> ReLU,
  * :87-91 the two adaptive average pools as one block mean; train.py:88-89).

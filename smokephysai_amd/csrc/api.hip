@@ -9,6 +9,7 @@
 
 #include "chaos.h"
 #include "decoder.h"
+#include "elementwise.h"
 #include "encoder.h"
 #include "linear.h"
 #include "norm.h"
@@ -700,6 +701,28 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
     a.B = B; a.D = D; a.ld = (int)ld_addend;
     a.strength = (float)strength; a.sigma = (float)sigma; a.rho = (float)rho; a.beta = (float)beta; a.dt = (float)dt;
     return check_launch(launch_chaos_addend(a, (hipStream_t)stream), "chaos_addend");
+}
+
+// ------------------------------------------------------------------ element-wise chain of the FFN block in training
+int smk_ffn_elementwise(int32_t op, const float *a, const float *b, float *out, int64_t n, double p, uint64_t seed, void *stream) {
+    SMK_REQUIRE(a && out && n >= 0, "null a / out or negative n");
+    SMK_REQUIRE(op >= SMK_ELT_GELU_DROPOUT_FWD && op <= SMK_ELT_DROPOUT_BWD, "op: smk_elt_op");
+    SMK_REQUIRE((op != SMK_ELT_GELU_DROPOUT_BWD && op != SMK_ELT_DROPOUT_ADD_FWD) || b, "this op needs the second operand");
+    SMK_REQUIRE(p >= 0.0 && p < 1.0, "0 <= p < 1");
+    if (n % 4 != 0) {
+        set_error("ffn_elementwise: HIP path is built for element counts that are multiples of 4");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    SMK_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "16-byte aligned tensors");
+    if (n == 0) return SMK_OK;
+    EltArgs e{a, b, out, (long long)n, (float)p, (unsigned long long)seed};
+    hipStream_t st = (hipStream_t)stream;
+    switch (op) {
+        case SMK_ELT_GELU_DROPOUT_FWD: return check_launch(launch_gelu_dropout_fwd(e, st), "gelu_dropout_fwd");
+        case SMK_ELT_GELU_DROPOUT_BWD: return check_launch(launch_gelu_dropout_bwd(e, st), "gelu_dropout_bwd");
+        case SMK_ELT_DROPOUT_ADD_FWD: return check_launch(launch_dropout_add_fwd(e, st), "dropout_add_fwd");
+        default: return check_launch(launch_dropout_bwd(e, st), "dropout_bwd");
+    }
 }
 
 // ------------------------------------------------------------------ softmax attention (chaos term folded into Q)

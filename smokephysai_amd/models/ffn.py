@@ -1,0 +1,65 @@
+"""Host side of libsmokehip's fused element-wise FFN kernels (smk_ffn_elementwise) under autograd: GELU + dropout and dropout + residual
+add of ChaosTransformerLayer (smokephys_net.py:153-159,165-167), one read and one write per tensor, no mask tensors (the keep mask is
+recomputed in the backward from the call's seed)."""
+import torch
+
+from .. import _lib
+
+GELU_DROPOUT_FWD, GELU_DROPOUT_BWD, DROPOUT_ADD_FWD, DROPOUT_BWD = 0, 1, 2, 3
+
+_counter = [0]
+
+
+def _next_seed() -> int:
+    """A fresh 64-bit seed per call, deterministic under torch.manual_seed (no device synchronisation: host arithmetic only)."""
+    _counter[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def hip_ffn_elementwise_supported(t: torch.Tensor) -> bool:
+    return t.is_cuda and t.dtype == torch.float32 and t.numel() % 4 == 0
+
+
+def _run(op, a, b, p, seed):
+    dev = _lib.require_cuda(a.device, "hip_ffn_elementwise")
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().smk_ffn_elementwise(op, a.data_ptr(), None if b is None else b.data_ptr(), out.data_ptr(), a.numel(), float(p),
+                                               seed, _lib.stream_ptr(dev)))
+    return out
+
+
+class _GeluDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, p, seed):
+        h = h.contiguous()
+        ctx.save_for_backward(h)
+        ctx.p, ctx.seed = p, seed
+        return _run(GELU_DROPOUT_FWD, h, None, p, seed)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h,) = ctx.saved_tensors
+        return _run(GELU_DROPOUT_BWD, h, dout.contiguous(), ctx.p, ctx.seed), None, None
+
+
+class _DropoutAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, residual, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return _run(DROPOUT_ADD_FWD, y.contiguous(), residual.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        dy = _run(DROPOUT_BWD, dout, None, ctx.p, ctx.seed) if ctx.needs_input_grad[0] else None
+        return dy, (dout if ctx.needs_input_grad[1] else None), None, None
+
+
+def hip_gelu_dropout(h: torch.Tensor, p: float, training: bool = True) -> torch.Tensor:
+    """dropout_p(gelu(h)) (exact-erf GELU); p is ignored (0) when not training."""
+    return _GeluDropoutFn.apply(h, float(p) if training else 0.0, _next_seed())
+
+
+def hip_dropout_add(y: torch.Tensor, residual: torch.Tensor, p: float, training: bool = True) -> torch.Tensor:
+    """residual + dropout_p(y)."""
+    return _DropoutAddFn.apply(y, residual, float(p) if training else 0.0, _next_seed())

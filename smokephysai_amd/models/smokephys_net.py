@@ -23,6 +23,7 @@ from .chaos_attention import ChaosAttention
 from .decoder import HipDecoder, decoder_weight_dict, hip_decoder_supported
 from .encoder import HipEncoder, encoder_weight_dict
 from .hip_body import HipBody
+from .ffn import hip_dropout_add, hip_ffn_elementwise_supported, hip_gelu_dropout
 from .linear import TrainableHipLinear, hip_linear_supported
 from .norm import hip_bn_relu_pool, hip_sync_bn_relu_pool
 from .sync_bn import SyncBatchNorm2d
@@ -315,7 +316,19 @@ class ChaosTransformerLayer(nn.Module):
             return hip_layernorm_train(x, ln)
         return ln(x)
 
+    def _ffn_fused_ok(self, x: torch.Tensor) -> bool:
+        lin0, act, drop0, lin1, drop1 = self.ffn
+        return (self.hip_train and torch.is_grad_enabled() and hip_ffn_elementwise_supported(x) and type(act) is nn.GELU
+                and getattr(act, "approximate", "none") == "none" and type(drop0) is nn.Dropout and type(drop1) is nn.Dropout
+                and drop0.p < 1.0 and drop1.p < 1.0 and not drop0.inplace and not drop1.inplace)
+
     def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = x + self.chaos_attention(self._norm(self.norm1, x), noise=noise)
+        if self._ffn_fused_ok(x):
+            # GELU + dropout and dropout + residual add as one libsmokehip pass each (forward and backward): the reference's five modules
+            # and the add move 12 full tensors of [B, L, 4D] / [B, L, D] per layer through HBM, these four calls 7, and no mask is stored
+            lin0, _, drop0, lin1, drop1 = self.ffn
+            h = hip_gelu_dropout(lin0(self._norm(self.norm2, x)), drop0.p, drop0.training)
+            return hip_dropout_add(lin1(h), x, drop1.p, drop1.training)
         x = x + self.ffn(self._norm(self.norm2, x))
         return x

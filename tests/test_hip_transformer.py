@@ -285,3 +285,75 @@ def test_layernorm_backward_matches_fp64_autograd(rows, D):
     ln.zero_grad()
     hip_layernorm_train(x, ln).backward(dy)
     assert torch.equal(x.grad, g1[0]) and torch.equal(ln.weight.grad, g1[1])
+
+
+def test_ffn_elementwise_kernels_vs_fp64_autograd():
+    """smk_ffn_elementwise: dropout(gelu(h)) and residual + dropout(y) with their backward passes.  p = 0: forward and gradients against
+    fp64 autograd of the exact-erf GELU; p = 0.1: the keep mask is a function of (seed, index) -- the same mask in forward and backward,
+    keep rate 0.9 +- 0.5 %, kept elements scaled by 1 / (1 - p), and a different seed gives a different mask."""
+    from smokephysai_amd.models import ffn
+    g = torch.Generator(device="cuda").manual_seed(5)
+    h = (torch.randn(257, 512, device="cuda", generator=g) * 2.5).requires_grad_(True)
+    go = torch.randn(257, 512, device="cuda", generator=g)
+    out = ffn.hip_gelu_dropout(h, 0.0)
+    out.backward(go)
+    h64 = h.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.gelu(h64)
+    ref.backward(go.double())
+    assert float((out.double() - ref).abs().max()) < 2e-6 and float((h.grad.double() - h64.grad).abs().max()) < 5e-6 * float(go.abs().max())
+    # dropout: same mask both ways
+    h2 = h.detach().clone().requires_grad_(True)
+    seed = 1234567
+    a = ffn._GeluDropoutFn.apply(h2, 0.1, seed)
+    a.backward(torch.ones_like(a))
+    keep = a != 0
+    dense = torch.nn.functional.gelu(h2.detach())
+    nz = dense.abs() > 1e-6
+    rate = float(keep[nz].float().mean())
+    assert abs(rate - 0.9) < 5e-3, rate
+    assert torch.allclose(a[keep], dense[keep] / 0.9, rtol=1e-5, atol=1e-6)
+    assert bool(((h2.grad != 0) == keep)[nz & (h2.detach().abs() > 1e-3)].all())               # backward used the forward's mask
+    b = ffn._GeluDropoutFn.apply(h2.detach(), 0.1, seed + 1)
+    assert not torch.equal(b != 0, keep) and torch.equal(ffn._GeluDropoutFn.apply(h2.detach(), 0.1, seed), a.detach())
+    # residual + dropout(y)
+    y = torch.randn(64, 1024, 512, device="cuda", generator=g).requires_grad_(True)
+    res = torch.randn(64, 1024, 512, device="cuda", generator=g).requires_grad_(True)
+    o0 = ffn.hip_dropout_add(y, res, 0.0)
+    assert torch.equal(o0, y.detach() + res.detach())
+    o = ffn._DropoutAddFn.apply(y, res, 0.1, 99)
+    gout = torch.randn_like(o)
+    o.backward(gout)
+    m = (o.detach() - res.detach()) != 0
+    assert abs(float(m.float().mean()) - 0.9) < 2e-3
+    assert torch.equal(res.grad, gout) and torch.allclose(y.grad, gout * m / 0.9, rtol=1e-6, atol=0)
+    # off-GPU / odd sizes are refused, not silently computed elsewhere
+    assert not ffn.hip_ffn_elementwise_supported(torch.zeros(3)) and not ffn.hip_ffn_elementwise_supported(torch.zeros(6, device="cuda"))
+
+
+def test_transformer_layer_training_ffn_route_matches_the_module_chain():
+    """ChaosTransformerLayer in train mode with the fused GELU / dropout / residual kernels (dropout p = 0 so that both routes are
+    deterministic) against the same layer forced through the reference's module chain: outputs and every gradient agree."""
+    from smokephysai_amd.models import ChaosTransformerLayer
+    torch.manual_seed(0)
+    layer = ChaosTransformerLayer(512, 8).cuda().train()
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "hip_train"):
+            m.hip_train = True
+    x = torch.randn(2, 1024, 512, device="cuda")
+    noise = torch.randn(3, 2, 1, device="cuda")
+    assert layer._ffn_fused_ok(x)
+    outs, grads = [], []
+    for fused in (True, False):
+        layer.zero_grad()
+        layer._ffn_fused_ok = (lambda t: True) if fused else (lambda t: False)
+        xin = x.clone().requires_grad_(True)
+        y = layer(xin, noise=noise)
+        y.square().mean().backward()
+        outs.append(y.detach())
+        grads.append([xin.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
+    del layer._ffn_fused_ok
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5 * float(outs[1].abs().max())
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-12)
