@@ -311,7 +311,7 @@ def test_ffn_elementwise_kernels_vs_fp64_autograd():
     nz = dense.abs() > 1e-6
     rate = float(keep[nz].float().mean())
     assert abs(rate - 0.9) < 5e-3, rate
-    assert torch.allclose(a[keep], dense[keep] / 0.9, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(a[keep], dense[keep] / 0.9, rtol=2e-5, atol=1e-6)
     assert bool(((h2.grad != 0) == keep)[nz & (h2.detach().abs() > 1e-3)].all())               # backward used the forward's mask
     b = ffn._GeluDropoutFn.apply(h2.detach(), 0.1, seed + 1)
     assert not torch.equal(b != 0, keep) and torch.equal(ffn._GeluDropoutFn.apply(h2.detach(), 0.1, seed), a.detach())
@@ -325,7 +325,7 @@ def test_ffn_elementwise_kernels_vs_fp64_autograd():
     o.backward(gout)
     m = (o.detach() - res.detach()) != 0
     assert abs(float(m.float().mean()) - 0.9) < 2e-3
-    assert torch.equal(res.grad, gout) and torch.allclose(y.grad, gout * m / 0.9, rtol=1e-6, atol=0)
+    assert torch.equal(res.grad, gout) and torch.allclose(y.grad, gout * m / 0.9, rtol=2e-5, atol=0)    # p is applied in units of 2^-16
     # off-GPU / odd sizes are refused, not silently computed elsewhere
     assert not ffn.hip_ffn_elementwise_supported(torch.zeros(3)) and not ffn.hip_ffn_elementwise_supported(torch.zeros(6, device="cuda"))
 
