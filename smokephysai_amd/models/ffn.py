@@ -7,13 +7,12 @@ from .. import _lib
 
 GELU_DROPOUT_FWD, GELU_DROPOUT_BWD, DROPOUT_ADD_FWD, DROPOUT_BWD = 0, 1, 2, 3
 
-_counter = [0]
-
-
-def _next_seed() -> int:
-    """A fresh 64-bit seed per call, deterministic under torch.manual_seed (no device synchronisation: host arithmetic only)."""
-    _counter[0] += 1
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+def _next_seed(p: float) -> int:
+    """A fresh 62-bit seed per call from torch's CPU generator: deterministic under torch.manual_seed, a host-side draw (no device
+    synchronisation).  p == 0 keeps every element whatever the seed: no draw, so deterministic runs leave the RNG stream untouched."""
+    if p == 0.0:
+        return 0
+    return int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
 
 
 def hip_ffn_elementwise_supported(t: torch.Tensor) -> bool:
@@ -57,9 +56,11 @@ class _DropoutAddFn(torch.autograd.Function):
 
 def hip_gelu_dropout(h: torch.Tensor, p: float, training: bool = True) -> torch.Tensor:
     """dropout_p(gelu(h)) (exact-erf GELU); p is ignored (0) when not training."""
-    return _GeluDropoutFn.apply(h, float(p) if training else 0.0, _next_seed())
+    p = float(p) if training else 0.0
+    return _GeluDropoutFn.apply(h, p, _next_seed(p))
 
 
 def hip_dropout_add(y: torch.Tensor, residual: torch.Tensor, p: float, training: bool = True) -> torch.Tensor:
     """residual + dropout_p(y)."""
-    return _DropoutAddFn.apply(y, residual, float(p) if training else 0.0, _next_seed())
+    p = float(p) if training else 0.0
+    return _DropoutAddFn.apply(y, residual, p, _next_seed(p))
