@@ -323,7 +323,7 @@ def test_ffn_elementwise_kernels_vs_fp64_autograd():
     o = ffn._DropoutAddFn.apply(y, res, 0.1, 99)
     gout = torch.randn_like(o)
     o.backward(gout)
-    m = ffn._DropoutAddFn.apply(y.detach(), torch.zeros_like(res), 0.1, 99) != 0       # the same (seed, index) mask, read off a zero residual
+    m = ffn._DropoutAddFn.apply(torch.ones_like(res), torch.zeros_like(res), 0.1, 99) != 0   # the same (seed, index) mask, read off ones + 0
     assert abs(float(m.float().mean()) - 0.9) < 2e-3
     scale = 1.0 / (1.0 - round(0.1 * 65536) / 65536)                                       # p is applied in units of 2^-16
     assert torch.allclose(o.detach(), res.detach() + y.detach() * m * scale, rtol=1e-5, atol=2e-6)
