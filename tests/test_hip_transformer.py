@@ -357,5 +357,6 @@ def test_transformer_layer_training_ffn_route_matches_the_module_chain():
         grads.append([xin.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
     del layer._ffn_fused_ok
     assert float((outs[0] - outs[1]).abs().max()) < 2e-5 * float(outs[1].abs().max())
+    gscale = max(float(b.abs().max()) for b in grads[1])              # (k_proj.bias has an exactly-zero gradient: softmax ignores a key bias)
     for a, b in zip(*grads):
-        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-12)
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-3 * gscale)
