@@ -251,7 +251,7 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4):
            "collective_backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None,
            "grad_bytes_fp32": nparam * 4,
            "note": "forward + backward + gradient all-reduce (DDP, overlapped) + clip + AdamW; linear GEMMs, attention, LayerNorm and the "
-                   "encoder's BatchNorm/ReLU/pool on libsmokehip, convolutions / GELU / dropout on PyTorch-ROCm"}
+                   "encoder's BatchNorm/ReLU/pool, GELU/dropout/residual of the FFN on libsmokehip; convolutions on PyTorch-ROCm (MIOpen)"}
     if dist is not None:
         res["ms_per_step_no_allreduce"] = timed(steps, sync=False)          # same step under ddp.no_sync(): what the exchange costs
         res["ddp_buckets"] = ddp_bucket_report(ddp)
@@ -320,11 +320,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-alt", action="store_true", help="time only --encoder-dtype (profiling runs)")
     ap.add_argument("--no-inference", action="store_true", help="skip the per-frame inference-ms measurement (metric M2)")
     ap.add_argument("--no-config1", action="store_true", help="skip the secondary configs[1] block (128^2 x 32, Jacobi-20, fp32 encoder)")
-    ap.add_argument("--train-step", dest="train_step", action="store_true", default=None,
+    ap.add_argument("--train-step", dest="train_step", action="store_true", default=True,
                     help="time train.py's optimisation step (BASELINE configs[3]'s per-GPU shape: --batch frames of --grid^2, full model; "
-                         "under DistributedDataParallel when N > 1). Default: on when N > 1 (that is where the RCCL gradient all-reduce "
-                         "runs), off at N = 1 (adds about a minute: MIOpen tunes its convolutions on first use)")
-    ap.add_argument("--no-train-step", dest="train_step", action="store_false")
+                         "under DistributedDataParallel when N > 1: the RCCL gradient all-reduce).  On by default at every N, so that the "
+                         "1 -> N curve of the DDP step has its N = 1 point (adds about a minute: MIOpen tunes its convolutions on first use)")
+    ap.add_argument("--no-train-step", dest="train_step", action="store_false", help="skip the train-step leg (profiling runs)")
     ap.add_argument("--train-step-limit", type=float, default=420.0,
                     help="seconds after which a stuck train-step leg is abandoned: rank 0 prints the headline line without it")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
@@ -509,8 +509,7 @@ def main(argv=None):
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
 
-    want_train = args.train_step if args.train_step is not None else world > 1
-    if want_train:
+    if args.train_step:
         # a collective that never completes on one rank would hang every rank: a watchdog on each rank abandons the leg
         # at the same deadline, rank 0 printing the headline line it already holds
         import threading

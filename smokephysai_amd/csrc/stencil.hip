@@ -283,6 +283,38 @@ __device__ __forceinline__ float wave_shl1(float x) {   // lane i <- lane i+1 (l
 
 constexpr int JB_NW = 16;
 
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<8> { using type = float4; };
+// VEC consecutive floats of a lane as vector loads / stores (rows are 128-byte aligned and a lane's cells start at a multiple of VEC)
+template <int VEC>
+__device__ __forceinline__ void ldv(float (&dst)[VEC], const float *src) {
+    using V = typename VecT<VEC>::type;
+    constexpr int N = sizeof(V) / 4;
+#pragma unroll
+    for (int q = 0; q < VEC / N; ++q) {
+        const V t = reinterpret_cast<const V *>(src)[q];
+        const float *f = reinterpret_cast<const float *>(&t);
+#pragma unroll
+        for (int c = 0; c < N; ++c) dst[q * N + c] = f[c];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float *dst, const float (&src)[VEC]) {
+    using V = typename VecT<VEC>::type;
+    constexpr int N = sizeof(V) / 4;
+#pragma unroll
+    for (int q = 0; q < VEC / N; ++q) {
+        V t;
+        float *f = reinterpret_cast<float *>(&t);
+#pragma unroll
+        for (int c = 0; c < N; ++c) f[c] = src[q * N + c];
+        reinterpret_cast<V *>(dst)[q] = t;
+    }
+}
+
 // MODE bit 0 (FIRST launch of a projection): the divergence of (u, v) is computed here for all tile rows (navier_stokes.py:136,
 //   same expression tree as k_divergence) and stored for the owned rows so that later launches can read it;
 // MODE bit 1 (LAST launch): after the final sweep the gradient subtraction (navier_stokes.py:148-149, as k_grad_subtract)
@@ -430,21 +462,25 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
             const int gi = row0 + k;
             const float lin = wave_shr1(pv[k][VEC - 1]);
             if (gi >= own0 && gi < own1) {
+                // whole-row read-modify-write (VEC cells per lane as one load / one store; the untouched cells -- row 0 of u, column 0
+                // of v -- are written back unchanged)
+                float un[VEC], vn[VEC];
+                ldv<VEC>(un, ub + (size_t)k * g.pc);
+                ldv<VEC>(vn, vb + (size_t)k * g.pv);
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) {
                     if (gi >= 1) {                            // gi == row0 == 0 only in the first wave of band 0: skipped
                         const float pu = k > 0 ? pv[k - 1][c] : above[c];
                         const float gr = pv[k][c] - pu;
-                        float *cell = ub + (size_t)k * g.pc + c;
-                        *cell = *cell - g.dt * gr;
+                        un[c] = un[c] - g.dt * gr;
                     }
-                    if (!(c == 0 && first_col)) {             // j >= 1 (j <= W-1 always holds here)
-                        const float pl = c > 0 ? pv[k][c - 1] : lin;
-                        const float gr = pv[k][c] - pl;
-                        float *cell = vb + (size_t)k * g.pv + c;
-                        *cell = *cell - g.dt * gr;
-                    }
+                    const float pl = c > 0 ? pv[k][c - 1] : lin;
+                    const float gr = pv[k][c] - pl;
+                    const float nv = vn[c] - g.dt * gr;
+                    vn[c] = (c == 0 && first_col) ? vn[c] : nv;   // j >= 1 (j <= W-1 always holds here)
                 }
+                if (gi >= 1) stv<VEC>(ub + (size_t)k * g.pc, un);
+                stv<VEC>(vb + (size_t)k * g.pv, vn);
             }
         }
     }
