@@ -152,3 +152,78 @@ def hip_layernorm_train(x: torch.Tensor, ln: torch.nn.LayerNorm) -> torch.Tensor
         raise ValueError("hip_layernorm_train: an affine LayerNorm over the last dimension")
     return _HipLayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
 
+
+
+# ---------------------------------------------------------------- training: fused q|k|v projection + attention as ONE autograd node
+class _HipQKVAttentionFn(torch.autograd.Function):
+    """ChaosAttention's q / k / v projections, the chaos term folded into q, and the softmax attention (chaos_attention.py:77-112) as one
+    node.  Forward: ONE [3D, D] linear launch (x read once; the [B, 5, D] chaos addend rides in the epilogue on the q columns, as in the
+    eval body) + the flash attention on strided slices of its output.  Backward: the attention backward writes dq | dk | dv into ONE
+    [B, L, 3D] buffer, so dX is one GEMM over K = 3D (instead of three GEMMs and two adds), dW / db one weight-gradient call with
+    out = 3D (x split once instead of three times), and the addend's gradient five strided row sums of the dq columns."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, add5, mod, num_heads, scale):
+        dev = _lib.require_cuda(x.device, "hip_qkv_attention_train")
+        L_ = _lib.load()
+        B, L, D = x.shape
+        x = x.contiguous()
+        fwd, _ = mod._hip_qkv_handles()
+        add15 = None
+        if add5 is not None:
+            add15 = torch.zeros(B, 5, 3 * D, device=dev, dtype=torch.float32)
+            add15[:, :, :D] = add5
+        qkv = fwd(x, periodic_add=add15, rows_per_group=L)                      # [B, L, 3D]
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        out = torch.empty(B, L, D, device=dev, dtype=torch.float32)
+        lse = torch.empty(B, L, num_heads, device=dev, dtype=torch.float32)
+        bmax = max(1, (MAX_QKV_ELEMS - 1) // (L * 3 * D))
+        for b0 in range(0, B, bmax):
+            nb = min(bmax, B - b0)
+            _lib.check(L_.smk_attention_forward_lse(q[b0:].data_ptr(), k[b0:].data_ptr(), v[b0:].data_ptr(), out[b0:].data_ptr(),
+                                                    lse[b0:].data_ptr(), nb, L, num_heads, D // num_heads, 3 * D, 3 * D, 3 * D, D,
+                                                    float(scale), _lib.stream_ptr(dev)))
+        ctx.save_for_backward(x, qkv, out, lse)
+        ctx.mod, ctx.num_heads, ctx.scale, ctx.has_add = mod, num_heads, float(scale), add5 is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .linear import hip_linear_wgrad
+        x, qkv, out, lse = ctx.saved_tensors
+        L_ = _lib.load()
+        B, L, D = x.shape
+        H = ctx.num_heads
+        dev = x.device
+        dout = dout.contiguous()
+        delta = (dout * out).view(B, L, H, D // H).sum(-1)                      # [B, L, H]
+        dqkv = torch.empty(B, L, 3 * D, device=dev, dtype=torch.float32)
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+        bmax = max(1, (MAX_QKV_ELEMS - 1) // (L * 3 * D))
+        for b0 in range(0, B, bmax):
+            nb = min(bmax, B - b0)
+            _lib.check(L_.smk_attention_backward(q[b0:].data_ptr(), k[b0:].data_ptr(), v[b0:].data_ptr(), dout[b0:].data_ptr(),
+                                                 lse[b0:].data_ptr(), delta[b0:].data_ptr(), dq[b0:].data_ptr(), dk[b0:].data_ptr(),
+                                                 dv[b0:].data_ptr(), nb, L, H, D // H, 3 * D, 3 * D, 3 * D, D, 3 * D, 3 * D, 3 * D,
+                                                 ctx.scale, _lib.stream_ptr(dev)))
+        dy2, x2 = dqkv.view(-1, 3 * D), x.view(-1, D)
+        need = ctx.needs_input_grad
+        dx = None
+        if need[0]:
+            _, bwd = ctx.mod._hip_qkv_handles()
+            dx = bwd(dy2).view(B, L, D)
+        dw = db = None
+        if any(need[1:7]):
+            dw, db = hip_linear_wgrad(dy2, x2, want_db=True)                    # [3D, D], [3D]
+        dadd5 = None
+        if ctx.has_add and need[7]:
+            dadd5 = torch.stack([dq[:, r::5].sum(1) for r in range(5)], dim=1)  # row l of the sequence received addend row l % 5
+        g = lambda t, i: None if t is None else t[i * D:(i + 1) * D]
+        return (dx, g(dw, 0), g(db, 0), g(dw, 1), g(db, 1), g(dw, 2), g(db, 2), dadd5, None, None, None)
+
+
+def hip_qkv_attention_train(mod, x: torch.Tensor, add5: Optional[torch.Tensor], num_heads: int, scale: float) -> torch.Tensor:
+    """`mod`: a ChaosAttention (q_proj / k_proj / v_proj with biases).  x [B, L, D] float32 on a ROCm device; add5 [B, 5, D] or None."""
+    return _HipQKVAttentionFn.apply(x, mod.q_proj.weight, mod.q_proj.bias, mod.k_proj.weight, mod.k_proj.bias, mod.v_proj.weight,
+                                    mod.v_proj.bias, add5, mod, num_heads, scale)

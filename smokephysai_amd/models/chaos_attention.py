@@ -7,14 +7,15 @@ The Lorenz chaos field has period 5 along the sequence (chaos_attention.py:61-65
 distinct row and tiled.
 """
 import math
+import os
 from typing import Optional
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .attention import hip_attention_supported, hip_attention_train
-from .linear import TrainableHipLinear
+from .attention import hip_attention_supported, hip_attention_train, hip_qkv_attention_train
+from .linear import HipLinear, TrainableHipLinear, hip_linear_supported, hip_linear_wgrad_supported
 
 
 class ChaosAttention(nn.Module):
@@ -37,6 +38,35 @@ class ChaosAttention(nn.Module):
         self.register_buffer("lorenz_beta", torch.tensor(8.0 / 3.0))
         self._lorenz_host = None
         self.hip_train = False      # set by SmokePhysNet(linear_dtype="bf16x3"): attention forward + backward on libsmokehip in training
+
+    # ---- training: q | k | v as one [3D, D] layer (device mirrors of the concatenated weights, re-split when a parameter changes)
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k in ("_hip_qkv", "_hip_qkv_fp"):
+            d.pop(k, None)
+        return d
+
+    def _hip_qkv_handles(self):
+        mods = (self.q_proj, self.k_proj, self.v_proj)
+        fp = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
+        h = self.__dict__.get("_hip_qkv")
+        if h is None or self.__dict__.get("_hip_qkv_fp") != fp:
+            w = torch.cat([m.weight.detach() for m in mods])                    # [3D, D]
+            b = torch.cat([m.bias.detach() for m in mods])
+            if h is None:
+                h = (HipLinear(w, b), HipLinear(w.t().contiguous(), None))      # forward; dX = dY W (out = D, in = 3D)
+                self.__dict__["_hip_qkv"] = h
+            else:
+                h[0].update(w, b)
+                h[1].update(w, None, transposed=True)
+            self.__dict__["_hip_qkv_fp"] = fp
+        return h
+
+    def _hip_qkv_ok(self, x: torch.Tensor) -> bool:
+        D = self.dim
+        return (all(m.bias is not None and m.weight.requires_grad == self.q_proj.weight.requires_grad for m in (self.q_proj, self.k_proj, self.v_proj))
+                and hip_linear_supported(D, 3 * D) and hip_linear_supported(3 * D, D) and hip_linear_wgrad_supported(D, 3 * D)
+                and x.shape[1] % 32 == 0 and os.environ.get("SMK_TRAIN_QKV_FUSED", "1") == "1")
 
     def lorenz_system(self, x, y, z, dt: float = 0.01):
         """chaos_attention.py:39-45 (explicit Euler)."""
@@ -105,6 +135,12 @@ class ChaosAttention(nn.Module):
     def forward(self, x: torch.Tensor, mask: torch.Tensor = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, L, D = x.shape
         H, d = self.num_heads, self.head_dim
+        if (self.hip_train and mask is None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and hip_attention_supported(L, d) and self._hip_qkv_ok(x)):
+            # training on a ROCm device: q | k | v projection (+ chaos addend on the q columns) and the flash attention as one autograd node
+            add5 = self.chaos_addend(B, x.device, x.dtype, noise)                    # [B,5,D]: through chaos_proj / chaos_gate (autograd)
+            out = hip_qkv_attention_train(self, x, add5, H, 1.0 / (math.sqrt(d) * self.temperature))
+            return self.out_proj(out)
         q = self.q_proj(x)
         add5 = self.chaos_addend(B, x.device, x.dtype, noise)                        # [B,5,D]
         reps = (L + 4) // 5

@@ -229,6 +229,10 @@ class SmokePhysNet(nn.Module):
             h.close()
         body.linears.clear(); body.sources.clear()
         for m in self.modules():
+            if isinstance(m, ChaosAttention):
+                for h in m.__dict__.pop("_hip_qkv", None) or ():
+                    h.close()
+                m.__dict__.pop("_hip_qkv_fp", None)
             if isinstance(m, TrainableHipLinear):
                 for k in ("_hip_fwd", "_hip_bwd"):
                     h = m.__dict__.pop(k, None)

@@ -360,3 +360,41 @@ def test_transformer_layer_training_ffn_route_matches_the_module_chain():
     gscale = max(float(b.abs().max()) for b in grads[1])              # (k_proj.bias has an exactly-zero gradient: softmax ignores a key bias)
     for a, b in zip(*grads):
         assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-3 * gscale)
+
+
+def test_fused_qkv_attention_training_node_matches_the_three_projection_route(monkeypatch):
+    """ChaosAttention in train mode: q | k | v projection + chaos addend + attention as one autograd node (one [3D, D] launch, dq | dk | dv in
+    one buffer, one dX GEMM, one weight-gradient call) against the route with three TrainableHipLinear projections: output and every
+    gradient (x, the three weights and biases, chaos_proj / chaos_gate through the addend) agree; a parameter update is seen."""
+    from smokephysai_amd.models.chaos_attention import ChaosAttention
+    torch.manual_seed(1)
+    att = ChaosAttention(512, 8).cuda().train()
+    att.hip_train = True
+    for m in att.modules():
+        if hasattr(m, "hip_train"):
+            m.hip_train = True
+    x = torch.randn(2, 1024, 512, device="cuda")
+    noise = torch.randn(3, 2, 1, device="cuda")
+    go = torch.randn(2, 1024, 512, device="cuda")
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SMK_TRAIN_QKV_FUSED", fused)
+        att.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        y = att(xin, noise=noise)
+        y.backward(go)
+        res[fused] = (y.detach(), [xin.grad.clone()] + [p.grad.clone() for p in att.parameters()])
+    assert "_hip_qkv" in att.__dict__
+    names = ["x"] + [n for n, _ in att.named_parameters()]
+    assert float((res["1"][0] - res["0"][0]).abs().max()) < 2e-5 * float(res["0"][0].abs().max())
+    gscale = max(float(b.abs().max()) for b in res["0"][1])
+    for n, a, b in zip(names, res["1"][1], res["0"][1]):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-3 * gscale), n
+    # an in-place parameter update re-splits the concatenated mirror
+    monkeypatch.setenv("SMK_TRAIN_QKV_FUSED", "1")
+    with torch.no_grad():
+        att.k_proj.weight.mul_(1.5)
+    y2 = att(x, noise=noise)
+    monkeypatch.setenv("SMK_TRAIN_QKV_FUSED", "0")
+    y3 = att(x, noise=noise)
+    assert float((y2 - y3).abs().max()) < 2e-5 * float(y3.abs().max()) and not torch.allclose(y2, res["1"][0], rtol=1e-3, atol=1e-4)
