@@ -251,6 +251,7 @@ def test_short_training_run_tracks_the_all_pytorch_path():
             opt.step()
             losses.append(float(total.detach()))
         used = sum("_hip_fwd" in m.__dict__ for m in model.modules() if isinstance(m, TrainableHipLinear))
+        used += 3 * sum("_hip_qkv" in m.__dict__ for m in model.modules() if isinstance(m, ChaosAttention))   # q | k | v run as one fused layer
         return losses, used
     hip, used = run(True)
     ref, unused = run(False)
