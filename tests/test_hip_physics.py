@@ -132,10 +132,12 @@ def test_batched_equals_oracle_per_grid():
     assert float(sim.ns_solver.density[0].abs().sum()) > 0
 
 
-@pytest.mark.parametrize("H,W,J", [(512, 512, 37), (128, 256, 45), (320, 64, 100), (192, 128, 21), (256, 256, 7), (64, 64, 100)])
+@pytest.mark.parametrize("H,W,J", [(512, 512, 37), (128, 256, 45), (320, 64, 100), (192, 128, 21), (256, 256, 7), (64, 64, 100), (33, 50, 20), (70, 131, 9)])
 def test_band_plans_at_other_shapes_and_sweep_counts_equal_the_oracle(H, W, J):
     """The register-resident Jacobi picks its band plan (rows per wave, unequal band ranges, halo, launch count) from the grid shape and
-    splits J sweeps into launches: 3 time steps at shapes / sweep counts beyond the fixtures stay bit-identical to the oracle."""
+    splits J sweeps into launches: 3 time steps at shapes / sweep counts beyond the fixtures stay bit-identical to the oracle.  The two odd
+    shapes (W not a multiple of 4 / of 64, partial advection tiles) take the one-cell-per-thread diffusion, the per-sweep Jacobi and
+    ragged tiles of the fused advection."""
     B = 2
     rng = np.random.RandomState(H + W + J)
     sim = SmokeSimulator((H, W), batch_size=B, jacobi_iters=J)
