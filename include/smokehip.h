@@ -306,6 +306,10 @@ int smk_attention_backward(const float *q, const float *k, const float *v, const
                            const float *delta, float *dq, float *dk, float *dv, int32_t B, int32_t L, int32_t H,
                            int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk,
                            int64_t lddv, double scale, void *stream);
+/* delta [rows][H] = sum_d dout[row][64 h + d] * out[row][64 h + d] -- the `delta` input of smk_attention_backward (rowsum(dout * out) per head)
+ * as one pass over the two tensors (row pitches ld_dout / ld_out floats). */
+int smk_attention_delta(const float *dout, const float *out, int64_t rows, int32_t H, int32_t head_dim, int64_t ld_dout, int64_t ld_out,
+                        float *delta, void *stream);
 
 /* nn.LayerNorm over the last dimension (smokephys_net.py:149-150, applied at :161,:165; biased variance, eps as given):
  * x [rows][ldx] -> y [rows][ldy], weight / bias [D].  D % 4 == 0, D <= 2048 (else SMK_ERR_UNSUPPORTED).

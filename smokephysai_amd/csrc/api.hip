@@ -773,6 +773,19 @@ int smk_attention_forward_lse(const float *q, const float *k, const float *v, fl
     return check_launch(launch_attention_x3(a, (hipStream_t)stream), "attention_x3");
 }
 
+int smk_attention_delta(const float *dout, const float *out, int64_t rows, int32_t H, int32_t head_dim, int64_t ld_dout, int64_t ld_out,
+                        float *delta, void *stream) {
+    SMK_REQUIRE(dout && out && delta && rows >= 0 && H >= 1, "null pointer / rows < 0 / H < 1");
+    if (head_dim != 64) {
+        set_error("attention_delta: HIP path is built for head_dim 64");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    SMK_REQUIRE(ld_dout >= (int64_t)H * 64 && ld_out >= (int64_t)H * 64 && ld_dout % 4 == 0 && ld_out % 4 == 0, "row pitches >= H * 64, multiples of 4");
+    SMK_REQUIRE((((uintptr_t)dout | (uintptr_t)out) & 15) == 0, "16-byte aligned tensors");
+    if (rows == 0) return SMK_OK;
+    return check_launch(launch_attn_delta(dout, out, rows, H, ld_dout, ld_out, delta, (hipStream_t)stream), "attn_delta");
+}
+
 int smk_attention_backward(const float *q, const float *k, const float *v, const float *dout, const float *lse,
                            const float *delta, float *dq, float *dk, float *dv, int32_t B, int32_t L, int32_t H,
                            int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk,

@@ -36,6 +36,10 @@ struct AttnBwdArgs {
 };
 hipError_t launch_attention_bwd_x3(const AttnBwdArgs &a, hipStream_t st);
 
+// delta [rows][H] = per-head row dot products of dout and out (head_dim 64), the row term of the attention backward
+hipError_t launch_attn_delta(const float *dout, const float *out, long long rows, int H, long long ldd, long long ldo, float *delta,
+                             hipStream_t st);
+
 struct LayerNormArgs {
     const float *x; float *y;            // [rows][ld*]
     const float *w, *b;                  // [D]

@@ -786,6 +786,37 @@ hipError_t launch_layernorm_bwd(const LayerNormBwdArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// delta[row][h] = sum_d dout[row][64 h + d] * out[row][64 h + d] (the softmax-backward row term of chaos_attention.py:108-112 under autograd):
+// one wave per token row per 8 heads -- lane l holds 8 consecutive columns, so a head is 8 lanes -- one read of both tensors.
+__global__ __launch_bounds__(256) void k_attn_delta(const float *__restrict__ dout, const float *__restrict__ out, long long rows, int H,
+                                                    long long ldd, long long ldo, float *__restrict__ delta) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hb = blockIdx.y * 8;                              // this wave's 8 heads: columns 64 hb .. 64 hb + 511
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+        const int h = hb + (lane >> 3);
+        float s = 0.f;
+        if (h < H) {
+            const float4 *a = reinterpret_cast<const float4 *>(dout + row * ldd + 64 * hb + 8 * lane);
+            const float4 *b = reinterpret_cast<const float4 *>(out + row * ldo + 64 * hb + 8 * lane);
+            const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+            s = ((a0.x * b0.x + a0.y * b0.y) + (a0.z * b0.z + a0.w * b0.w)) + ((a1.x * b1.x + a1.y * b1.y) + (a1.z * b1.z + a1.w * b1.w));
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if ((lane & 7) == 0 && h < H) delta[row * H + h] = s;
+    }
+}
+
+hipError_t launch_attn_delta(const float *dout, const float *out, long long rows, int H, long long ldd, long long ldo, float *delta,
+                             hipStream_t st) {
+    long long blocks = (rows + 3) / 4;
+    const long long cap = (long long)device_num_cu() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_attn_delta, dim3((unsigned)blocks, (H + 7) / 8), dim3(256), 0, st, dout, out, rows, H, ldd, ldo, delta);
+    return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const LayerNormArgs &a, hipStream_t st) {
     const dim3 grid((a.rows + 3) / 4), block(256);
     const int nv = (a.D + 255) / 256;

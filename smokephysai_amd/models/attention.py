@@ -42,6 +42,21 @@ def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: 
     return out
 
 
+def hip_attention_delta(dout: torch.Tensor, out: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """delta [B, L, H] = (dout * out).view(B, L, H, 64).sum(-1) as one libsmokehip pass (smk_attention_delta)."""
+    dev = _lib.require_cuda(dout.device, "hip_attention_delta")
+    B, L, D = out.shape
+    d2, o2 = dout.reshape(B * L, D), out.reshape(B * L, D)
+    if d2.stride(1) != 1 or d2.stride(0) % 4 != 0 or d2.data_ptr() % 16 != 0:
+        d2 = d2.contiguous()
+    if o2.stride(1) != 1 or o2.stride(0) % 4 != 0 or o2.data_ptr() % 16 != 0:
+        o2 = o2.contiguous()
+    delta = torch.empty(B, L, num_heads, device=dev, dtype=torch.float32)
+    _lib.check(_lib.load().smk_attention_delta(d2.data_ptr(), o2.data_ptr(), B * L, num_heads, D // num_heads, d2.stride(0), o2.stride(0),
+                                               delta.data_ptr(), _lib.stream_ptr(dev)))
+    return delta
+
+
 class _HipAttentionFn(torch.autograd.Function):
     """softmax(q k^T * scale) v over token-major [B, L, H*64] tensors with forward AND backward on libsmokehip
     (smk_attention_forward_lse / smk_attention_backward)."""
@@ -70,7 +85,7 @@ class _HipAttentionFn(torch.autograd.Function):
         B, L, D = q.shape
         H = ctx.num_heads
         dout = dout.contiguous()
-        delta = (dout * out).view(B, L, H, D // H).sum(-1)                      # [B, L, H]
+        delta = hip_attention_delta(dout, out, H)                               # [B, L, H] = rowsum(dout * out) per head
         dq, dk, dv = torch.empty_like(out), torch.empty_like(out), torch.empty_like(out)
         dev = q.device
         bmax = max(1, (MAX_QKV_ELEMS - 1) // (L * max(q.stride(1), k.stride(1), v.stride(1), D)))
@@ -196,7 +211,7 @@ class _HipQKVAttentionFn(torch.autograd.Function):
         H = ctx.num_heads
         dev = x.device
         dout = dout.contiguous()
-        delta = (dout * out).view(B, L, H, D // H).sum(-1)                      # [B, L, H]
+        delta = hip_attention_delta(dout, out, H)                               # [B, L, H] = rowsum(dout * out) per head
         dqkv = torch.empty(B, L, 3 * D, device=dev, dtype=torch.float32)
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]

@@ -132,7 +132,10 @@ class ChaosAttention(nn.Module):
                                                0.01, out.data_ptr(), out.shape[2], _lib.stream_ptr(dev)))
         return out
 
-    def forward(self, x: torch.Tensor, mask: torch.Tensor = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, mask: torch.Tensor = None, noise: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """residual (optional): returns attention(x) + residual (the block's `x + attn(norm1(x))`, smokephys_net.py:161-163) with the add
+        in out_proj's epilogue."""
         B, L, D = x.shape
         H, d = self.num_heads, self.head_dim
         if (self.hip_train and mask is None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
@@ -140,7 +143,7 @@ class ChaosAttention(nn.Module):
             # training on a ROCm device: q | k | v projection (+ chaos addend on the q columns) and the flash attention as one autograd node
             add5 = self.chaos_addend(B, x.device, x.dtype, noise)                    # [B,5,D]: through chaos_proj / chaos_gate (autograd)
             out = hip_qkv_attention_train(self, x, add5, H, 1.0 / (math.sqrt(d) * self.temperature))
-            return self.out_proj(out)
+            return self.out_proj(out, residual=residual)
         q = self.q_proj(x)
         add5 = self.chaos_addend(B, x.device, x.dtype, noise)                        # [B,5,D]
         reps = (L + 4) // 5
@@ -151,7 +154,7 @@ class ChaosAttention(nn.Module):
             # training on a ROCm device: flash attention forward + backward on libsmokehip, token-major in and out
             # (no head transposes, no merge-heads copy)
             out = hip_attention_train(q, self.k_proj(x), self.v_proj(x), H, scale)
-            return self.out_proj(out)
+            return self.out_proj(out, residual=residual)
         k = self.k_proj(x).view(B, L, H, d).transpose(1, 2)
         v = self.v_proj(x).view(B, L, H, d).transpose(1, 2)
         q = q.view(B, L, H, d).transpose(1, 2)
@@ -160,4 +163,4 @@ class ChaosAttention(nn.Module):
             attn_mask = (mask != 0)[:, None, None, :]
         out = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, scale=scale)
         out = out.transpose(1, 2).contiguous().view(B, L, D)
-        return self.out_proj(out)
+        return self.out_proj(out, residual=residual)

@@ -189,11 +189,11 @@ class _HipLinearFn(torch.autograd.Function):
     the token rows as K-segments of one launch)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mod):
+    def forward(ctx, x, weight, bias, mod, residual=None):
         ctx.mod = mod
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return mod._hip_forward_handle()(x)
+        return mod._hip_forward_handle()(x, residual=residual)          # residual (the pre-LN block's `x + sublayer(x)`) rides in the epilogue
 
     @staticmethod
     def backward(ctx, dy):
@@ -216,7 +216,8 @@ class _HipLinearFn(torch.autograd.Function):
                 dw = dy2.t().mm(x2)
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(0)
-        return dx, dw, db, None
+        dres = dy if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4] else None      # d(y + residual) / d residual = identity
+        return dx, dw, db, None, dres
 
 
 class TrainableHipLinear(nn.Linear):
@@ -263,7 +264,9 @@ class TrainableHipLinear(nn.Linear):
         self.__dict__["_hip_bwd_fp"] = fp
         return h
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
+        """residual (optional, same shape as the result): returns linear(x) + residual -- on the libsmokehip route as the GEMM's epilogue."""
         if self._hip_ok(x):
-            return _HipLinearFn.apply(x, self.weight, self.bias, self)
-        return nn.functional.linear(x, self.weight, self.bias)
+            return _HipLinearFn.apply(x, self.weight, self.bias, self, residual)
+        y = nn.functional.linear(x, self.weight, self.bias)
+        return y if residual is None else y + residual

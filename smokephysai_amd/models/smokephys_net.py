@@ -327,7 +327,7 @@ class ChaosTransformerLayer(nn.Module):
                 and drop0.p < 1.0 and drop1.p < 1.0 and not drop0.inplace and not drop1.inplace)
 
     def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        x = x + self.chaos_attention(self._norm(self.norm1, x), noise=noise)
+        x = self.chaos_attention(self._norm(self.norm1, x), noise=noise, residual=x)      # x + attn(norm1(x)): the add in out_proj's epilogue
         if self._ffn_fused_ok(x):
             # GELU + dropout and dropout + residual add as one libsmokehip pass each (forward and backward): the reference's five modules
             # and the add move 12 full tensors of [B, L, 4D] / [B, L, D] per layer through HBM, these four calls 7, and no mask is stored

@@ -398,3 +398,17 @@ def test_fused_qkv_attention_training_node_matches_the_three_projection_route(mo
     monkeypatch.setenv("SMK_TRAIN_QKV_FUSED", "0")
     y3 = att(x, noise=noise)
     assert float((y2 - y3).abs().max()) < 2e-5 * float(y3.abs().max()) and not torch.allclose(y2, res["1"][0], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 128, 8), (3, 256, 2), (1, 384, 11)])
+def test_attention_delta_kernel(B, L, H):
+    """smk_attention_delta: rowsum(dout * out) per head (the softmax-backward row term), dense and row-strided inputs."""
+    from smokephysai_amd.models.attention import hip_attention_delta
+    g = torch.Generator(device="cuda").manual_seed(B * L + H)
+    D = 64 * H
+    dout = torch.randn(B, L, D, device="cuda", generator=g)
+    wide = torch.randn(B, L, D + 64, device="cuda", generator=g)
+    out = wide[..., :D]                                              # row pitch > H * 64
+    ref = (dout.double() * out.double()).view(B, L, H, 64).sum(-1)
+    got = hip_attention_delta(dout, out, H)
+    assert got.shape == (B, L, H) and float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
