@@ -229,6 +229,10 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream);
 
+/* ChaosAttention.generate_chaos_field's five explicit-Euler Lorenz states (chaos_attention.py:39-59) for noise [3][B] (the three
+ * randn(B,1) draws before the 0.1 scale): states [B][5][3].  The gradient-free part of the chaos term, for the training path. */
+int smk_lorenz_states(const float *noise, int32_t B, double sigma, double rho, double beta, double dt, float *states, void *stream);
+
 /* The element-wise chain of ChaosTransformerLayer's FFN under autograd (smokephys_net.py:153-159 Linear -> GELU -> Dropout -> Linear ->
  * Dropout, :165-167 x = x + ffn(norm2(x)); train.py:88-89) as one read + one write per tensor, n contiguous fp32 elements (n % 4 == 0):
  *   SMK_ELT_GELU_DROPOUT_FWD   out = dropout_p(gelu(a))                      a = the first Linear's output h

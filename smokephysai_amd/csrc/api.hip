@@ -703,6 +703,11 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
     return check_launch(launch_chaos_addend(a, (hipStream_t)stream), "chaos_addend");
 }
 
+int smk_lorenz_states(const float *noise, int32_t B, double sigma, double rho, double beta, double dt, float *states, void *stream) {
+    SMK_REQUIRE(noise && states && B >= 1, "null noise / states or B < 1");
+    return check_launch(launch_lorenz_states(noise, B, (float)sigma, (float)rho, (float)beta, (float)dt, states, (hipStream_t)stream), "lorenz_states");
+}
+
 // ------------------------------------------------------------------ element-wise chain of the FFN block in training
 int smk_ffn_elementwise(int32_t op, const float *a, const float *b, float *out, int64_t n, double p, uint64_t seed, void *stream) {
     SMK_REQUIRE(a && out && n >= 0, "null a / out or negative n");

@@ -12,6 +12,8 @@ struct ChaosAddendArgs {
     float strength, sigma, rho, beta, dt;
 };
 hipError_t launch_chaos_addend(const ChaosAddendArgs &a, hipStream_t st);
+// the five Lorenz states [B][5][3] of the same noise (no projection / gate)
+hipError_t launch_lorenz_states(const float *noise, int B, float sigma, float rho, float beta, float dt, float *states, hipStream_t st);
 
 struct AttnArgs {
     const float *q, *k, *v;              // [B][L][ld*]: head h = columns 64h .. 64h+63 of a token row

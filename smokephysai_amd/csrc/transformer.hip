@@ -51,6 +51,31 @@ __global__ __launch_bounds__(256) void k_chaos_addend(const ChaosAddendArgs a) {
     }
 }
 
+// The five Lorenz states alone ([B][5][3]; chaos_attention.py:39-59): the part of the chaos term that carries no gradient, for the
+// training path (chaos_proj / chaos_gate then run under autograd on a [B, 5, 3] tensor instead of behind ~75 one-element launches).
+__global__ __launch_bounds__(64) void k_lorenz_states(const float *__restrict__ noise, int B, float sigma, float rho, float beta, float dt,
+                                                     float *__restrict__ states) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float x = noise[b] * 0.1f, y = noise[B + b] * 0.1f, z = noise[2 * B + b] * 0.1f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const float dx = sigma * (y - x);
+        const float dy = x * (rho - z) - y;
+        const float dz = x * y - beta * z;
+        x = x + dt * dx;
+        y = y + dt * dy;
+        z = z + dt * dz;
+        float *o = states + ((size_t)b * 5 + t) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+
+hipError_t launch_lorenz_states(const float *noise, int B, float sigma, float rho, float beta, float dt, float *states, hipStream_t st) {
+    hipLaunchKernelGGL(k_lorenz_states, dim3((B + 63) / 64), dim3(64), 0, st, noise, B, sigma, rho, beta, dt, states);
+    return hipGetLastError();
+}
+
 hipError_t launch_chaos_addend(const ChaosAddendArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_chaos_addend, dim3(a.B), dim3(256), 0, st, a);
     return hipGetLastError();

@@ -91,6 +91,23 @@ class ChaosAttention(nn.Module):
             seq.append(torch.cat([x, y, z], dim=-1))
         return torch.stack(seq, dim=1)
 
+    def chaos_states_hip(self, batch_size: int, device, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """chaos_states as ONE libsmokehip launch (smk_lorenz_states): the reference's three randn(B,1) draws in its order, then the five
+        Euler steps on the device -- the states carry no gradient (noise and the Lorenz constants are not parameters)."""
+        from .. import _lib
+        dev = _lib.require_cuda(device, "ChaosAttention.chaos_states_hip")
+        if noise is None:
+            noise = torch.empty(3, batch_size, 1, device=dev, dtype=torch.float32)
+            for i in range(3):
+                torch.randn(batch_size, 1, device=dev, out=noise[i])
+        n3 = noise.detach().to(dev, torch.float32).reshape(3, batch_size).contiguous()
+        if self._lorenz_host is None:
+            self._lorenz_host = (float(self.lorenz_sigma), float(self.lorenz_rho), float(self.lorenz_beta))
+        sg, rh, bt = self._lorenz_host
+        states = torch.empty(batch_size, 5, 3, device=dev, dtype=torch.float32)
+        _lib.check(_lib.load().smk_lorenz_states(n3.data_ptr(), batch_size, sg, rh, bt, 0.01, states.data_ptr(), _lib.stream_ptr(dev)))
+        return states
+
     def generate_chaos_field(self, seq_len: int, batch_size: int, device, noise=None) -> torch.Tensor:
         """chaos_attention.py:47-66."""
         field = self.chaos_states(batch_size, device, noise)
@@ -100,7 +117,11 @@ class ChaosAttention(nn.Module):
     def chaos_addend(self, batch_size: int, device, dtype, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The chaos term folded into Q, on the 5 distinct rows of the tiled Lorenz field: chaos_strength * gate(C) * C with
         C = chaos_proj(field) (chaos_attention.py:85-100).  [B,5,D]; row l of the sequence receives row l % 5."""
-        c5 = self.chaos_proj(self.chaos_states(batch_size, device, noise).to(dtype))
+        if self.hip_train and torch.device(device).type == "cuda" and dtype == torch.float32 and torch.is_grad_enabled():
+            states = self.chaos_states_hip(batch_size, device, noise)            # one launch instead of ~75 one-element launches
+        else:
+            states = self.chaos_states(batch_size, device, noise).to(dtype)
+        c5 = self.chaos_proj(states)
         return self.chaos_strength * torch.sigmoid(self.chaos_gate(c5)) * c5
 
     def chaos_addend_hip(self, batch_size: int, device, noise: Optional[torch.Tensor] = None,

@@ -412,3 +412,18 @@ def test_attention_delta_kernel(B, L, H):
     ref = (dout.double() * out.double()).view(B, L, H, 64).sum(-1)
     got = hip_attention_delta(dout, out, H)
     assert got.shape == (B, L, H) and float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_lorenz_states_kernel_matches_the_torch_chain():
+    """smk_lorenz_states: the five Euler states of generate_chaos_field for given noise, against the module's own torch op chain
+    (same operation order, fp32; no FMA contraction on either side)."""
+    from smokephysai_amd.models.chaos_attention import ChaosAttention
+    att = ChaosAttention(128, 2).cuda()
+    noise = torch.randn(3, 37, 1, device="cuda")
+    ref = att.chaos_states(37, "cuda", noise)
+    got = att.chaos_states_hip(37, "cuda", noise)
+    assert got.shape == (37, 5, 3) and float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    # drawn noise: the same three generator calls in the same order
+    torch.manual_seed(11); a = att.chaos_states(5, "cuda")
+    torch.manual_seed(11); b = att.chaos_states_hip(5, "cuda")
+    assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
