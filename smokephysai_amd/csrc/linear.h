@@ -30,7 +30,7 @@ hipError_t launch_split_linear_weights(const float *w, const float *bias, const 
 hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t st);
 
 // dW = dY^T X (linear.hip): workspace layout and segment count for a problem size
-struct WgradPlan { int nseg; long long rows_pad; size_t off_wq, off_part, bytes; };
+struct WgradPlan { int nseg; long long rows_pad; size_t off_wq, off_part, off_col, bytes; };
 WgradPlan plan_linear_wgrad(long long rows, int out_features, int in_features);
 hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x, long long ldx, long long rows, int out_features,
                                int in_features, float *dw, float *db, void *workspace, hipStream_t st);

@@ -617,8 +617,10 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
 // GEMM).  On the layer kernel it is "x' = dY^T [out][rows], w' = X^T [in][rows]": dY is transposed (zero-padded to whole segments) and
 // X is split straight into the weight layout with its k index = the token row; the row range is cut into nseg K-segments that run as
 // one launch (LinearCall::nseg) and the nseg partial [out][in] slabs are added in segment order (deterministic, no atomics).
+// colpart (may be NULL): [rows_pad / 32][cols] partial column sums of the source over this block's 32 rows -- the bias gradient's first
+// stage, taken while the tile sits in LDS (k_col_finish adds the row blocks in a fixed order)
 __global__ __launch_bounds__(256) void k_transpose_pad(const float *__restrict__ src, long long ld, int rows, int cols, float *__restrict__ dst,
-                                                       int rows_pad) {
+                                                       int rows_pad, float *__restrict__ colpart) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                 // 32 x 8
     const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -633,6 +635,30 @@ __global__ __launch_bounds__(256) void k_transpose_pad(const float *__restrict__
         const int c = c0 + ty + 8 * j, r = r0 + tx;
         if (c < cols && r < rows_pad) dst[(long long)c * rows_pad + r] = tile[tx][ty + 8 * j];
     }
+    if (colpart && ty == 0 && c0 + tx < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += tile[k][tx];
+        colpart[(size_t)blockIdx.x * cols + c0 + tx] = s;
+    }
+}
+
+// db[c] = sum over the row blocks of colpart[.][c]: 16 columns x 16 lanes per workgroup, lane kl adds blocks kl, kl + 16, ...; then lane order
+__global__ __launch_bounds__(256) void k_col_finish(const float *__restrict__ colpart, int nblocks, int cols, float *__restrict__ db) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float acc = 0.f;
+    if (c < cols)
+        for (int k = kl; k < nblocks; k += 16) acc += colpart[(size_t)k * cols + c];
+    red[kl][cl] = acc;
+    __syncthreads();
+    if (kl == 0 && c < cols) {
+        float s = red[0][cl];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) s += red[j][cl];
+        db[c] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sum_segments(const float *__restrict__ part, int nseg, long long n4, float *__restrict__ out) {
@@ -646,28 +672,6 @@ __global__ __launch_bounds__(256) void k_sum_segments(const float *__restrict__ 
     }
 }
 
-// db[o] = sum over the token rows of dY[:, o]: one workgroup per output feature sums its row of the transposed copy dY^T (contiguous, still in
-// the Infinity Cache right after k_transpose_pad; zero-padded, so no tail handling), 8 floats per thread and step, fixed-order tree.
-__global__ __launch_bounds__(256) void k_row_sums(const float *__restrict__ dyt, int rows_pad, float *__restrict__ db) {
-    const float4 *row = reinterpret_cast<const float4 *>(dyt + (size_t)blockIdx.x * rows_pad);
-    float a = 0.f, b = 0.f;
-    for (int i = threadIdx.x; i < rows_pad / 4; i += 512) {
-        const float4 v = row[i];
-        a += (v.x + v.y) + (v.z + v.w);
-        if (i + 256 < rows_pad / 4) {
-            const float4 w = row[i + 256];
-            b += (w.x + w.y) + (w.z + w.w);
-        }
-    }
-    float s = a + b;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-    __shared__ float red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) db[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 WgradPlan plan_linear_wgrad(long long rows, int out_f, int in_f) {
     WgradPlan p;
     const long long tiles = (long long)cdiv(out_f, 128) * cdiv(in_f, 128);
@@ -678,7 +682,8 @@ WgradPlan plan_linear_wgrad(long long rows, int out_f, int in_f) {
     p.rows_pad = (rows + unit - 1) / unit * unit;
     p.off_wq = (size_t)out_f * p.rows_pad * sizeof(float);                                // after dY^T
     p.off_part = p.off_wq + (size_t)p.rows_pad * in_f * 2 * sizeof(unsigned short);
-    p.bytes = p.off_part + (nseg > 1 ? (size_t)nseg * out_f * in_f * sizeof(float) : 0);
+    p.off_col = p.off_part + (nseg > 1 ? (size_t)nseg * out_f * in_f * sizeof(float) : 0);      // bias-gradient partials [rows_pad / 32][out]
+    p.bytes = p.off_col + (size_t)(p.rows_pad / 32) * out_f * sizeof(float);
     return p;
 }
 
@@ -692,9 +697,10 @@ hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x,
     l.N = in_f;
     l.K = (int)p.rows_pad;
     float *part = p.nseg > 1 ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(workspace) + p.off_part) : dw;
+    float *colpart = db ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(workspace) + p.off_col) : nullptr;
     hipLaunchKernelGGL(k_transpose_pad, dim3((unsigned)(p.rows_pad / 32), cdiv(out_f, 32)), dim3(256), 0, st, dy, ld_dy, (int)rows, out_f, dyt,
-                       (int)p.rows_pad);
-    if (db) hipLaunchKernelGGL(k_row_sums, dim3(out_f), dim3(256), 0, st, dyt, (int)p.rows_pad, db);      // the bias gradient, from the same copy
+                       (int)p.rows_pad, colpart);
+    if (db) hipLaunchKernelGGL(k_col_finish, dim3(cdiv(out_f, 16)), dim3(256), 0, st, colpart, (int)(p.rows_pad / 32), out_f, db);   // the bias gradient
     hipError_t e = launch_split_linear_weights(x, nullptr, l, st, 1, ldx, (int)rows);
     if (e != hipSuccess) return e;
     l.K = (int)(p.rows_pad / p.nseg);                       // segment length
