@@ -76,6 +76,7 @@ struct smk_sim {
     int src_cap = 0;
     int jacobi_iters = 20;
     int device = 0;
+    ProjectSync psync;    // hand-off flags / status word of the single-launch projection
 };
 
 struct smk_decoder {
@@ -131,7 +132,15 @@ int run_stage(smk_sim *sim, int stage, float *frames, int64_t fsb, const float *
         case SMK_STAGE_BUOY_DIFFUSE:   // s -> t (u2, v2, d2)
             return check_launch(launch_buoy_diffuse(g, s, t, st), "buoy_diffuse");
         case SMK_STAGE_PROJECT: {      // on t.u, t.v with s.p
-            return check_launch(launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st), "project");
+            const hipError_t e = launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st, &sim->psync);
+            if (e == hipErrorLaunchTimeOut) {
+                set_error("project: a band of an earlier persistent projection waited longer than 0.5 s for its neighbour (its workgroups were "
+                          "not all resident at once -- is another kernel holding compute units?); the state since that step is invalid. "
+                          "Reset the simulator; later projections of this handle use the multi-launch form (SMK_JACOBI_PERSIST=0 selects it "
+                          "from the start)");
+                return SMK_ERR_HIP;
+            }
+            return check_launch(e, "project");
         }
         case SMK_STAGE_ADVECT_U:       // u <- adv(u2; u2, v2)
             return check_launch(launch_advect(g, 0, t.u, s.u, t.u, t.v, nullptr, 0, nullptr, 0.f, nullptr, nullptr, st),
@@ -184,6 +193,7 @@ int smk_sim_create(const smk_sim_desc *d, smk_sim **out) {
     auto alloc = [&](float **p, size_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, n * sizeof(float)); };
     alloc(&sim->t.u, B * g.su); alloc(&sim->t.v, B * g.sv); alloc(&sim->t.p, B * g.sc); alloc(&sim->t.d, B * g.sc);
     alloc(&sim->div, B * g.sc);
+    if (e == hipSuccess) e = project_sync_create(sim->psync, g.B);
     if (e == hipSuccess) e = hipMalloc((void **)&sim->dev_mask, B);
     if (e == hipSuccess) e = hipMalloc((void **)&sim->dev_first, (B + 1) * sizeof(int));
     if (g.H == g.W && e == hipSuccess) {
@@ -206,6 +216,7 @@ int smk_sim_destroy(smk_sim *sim) {
     DeviceGuard guard(sim->device);              // frees run on the handle's device; the caller's device is restored
     float *ptrs[] = {sim->t.u, sim->t.v, sim->t.p, sim->t.d, sim->div, sim->perlin, sim->mandel, sim->fractal};
     for (float *p : ptrs) if (p) (void)hipFree(p);
+    project_sync_destroy(sim->psync);
     if (sim->dev_mask) (void)hipFree(sim->dev_mask);
     if (sim->dev_first) (void)hipFree(sim->dev_first);
     if (sim->dev_src) (void)hipFree(sim->dev_src);
@@ -366,7 +377,7 @@ int smk_sim_describe(smk_sim *sim, char *buf, int64_t capacity) {
     SMK_REQUIRE(sim && buf && capacity > 0, "null sim / buf or no capacity");
     DeviceGuard guard(sim->device);
     if (guard.rc) return guard.rc;
-    const std::string d = "{\"projection\": " + describe_projection(sim->g, sim->jacobi_iters) +
+    const std::string d = "{\"projection\": " + describe_projection(sim->g, sim->jacobi_iters, &sim->psync) +
                           ", \"advection\": \"k_advect_fused (u, v, density + frame in one LDS-tiled launch)\", \"launches_per_step\": null}";
     if ((int64_t)d.size() + 1 > capacity) {
         set_error("smk_sim_describe: buffer too small");

@@ -15,10 +15,24 @@ hipError_t launch_divergence(const Geom &g, const float *u, const float *v, floa
                              hipStream_t st);
 // `iters` Jacobi sweeps; result ends in p. p2 is scratch of the same layout as p.
 hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, int iters, hipStream_t st);
-// divergence + `iters` Jacobi sweeps + gradient subtraction on (u, v, p); p2 and div are scratch.
-hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st);
+// Per-handle state of the single-launch (persistent) projection: hand-off flags of the bands (device), a host-visible status word
+// the kernel sets when a bounded wait times out, and the running hand-off count the flags are compared with.
+struct ProjectSync {
+    unsigned *flags = nullptr;
+    volatile unsigned *status = nullptr;
+    unsigned seq = 0;
+    int flags_len = 0;
+    bool disabled = false;
+};
+hipError_t project_sync_create(ProjectSync &ps, int B);
+void project_sync_destroy(ProjectSync &ps);
+// divergence + `iters` Jacobi sweeps + gradient subtraction on (u, v, p); p2 and div are scratch.  With `ps` the projection runs as one
+// persistent launch where the plan allows (stencil.hip: k_jacobi_band<..., PERSIST>); returns hipErrorLaunchTimeOut once if an earlier
+// persistent launch reported a timed-out wait, and uses the multi-launch form afterwards.
+hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st,
+                          ProjectSync *ps = nullptr);
 // JSON description of what launch_project does for this geometry (kernel, bands, launches, sweeps per launch, on-chip estimates).
-std::string describe_projection(const Geom &g, int iters);
+std::string describe_projection(const Geom &g, int iters, const ProjectSync *ps = nullptr);
 hipError_t launch_grad_subtract(const Geom &g, float *u, float *v, const float *p, hipStream_t st);
 // kind 0: field=u (H+1 x W), 1: field=v (H x W+1), 2: density (H x W) with *0.995 decay and optional frame emit.
 hipError_t launch_advect(const Geom &g, int kind, const float *field, float *out, const float *u, const float *v,

@@ -320,22 +320,99 @@ __device__ __forceinline__ void stv(float *dst, const float (&src)[VEC]) {
 // MODE bit 1 (LAST launch): after the final sweep the gradient subtraction (navier_stokes.py:148-149, as k_grad_subtract)
 //   is applied to the owned rows of u and v from the p held in registers (needs iters <= halo - 1: the row above the
 //   owned range must still be exact).
-template <int VEC, int RPW, int MODE>
+// PERSIST (with MODE 3): the whole projection in ONE launch.  p and div stay in registers for all `iters` sweeps; after each chunk of
+//   at most `halo` sweeps a band hands the `halo` owned rows next to each inner boundary to its neighbour band through HBM (exchange
+//   buffers x0 / x1 alternate, so a band never overwrites rows its neighbour may still be reading) and refreshes its own halo rows
+//   from the neighbours'.  Hand-off as MI355X_MICROARCH.md "inter-workgroup visibility" prescribes for one workgroup per CU: every
+//   payload store and load is a 16-byte `sc1` access, every storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup
+//   barrier, one lane then stores the band's flag `sc1`, the consumer's lane 0 polls the two neighbour flags with `sc1` loads and joins
+//   a workgroup barrier before any wave loads.  Every spin is bounded (JacobiSync::timeout_ticks of the 100 MHz wall clock): a band
+//   whose neighbour never arrives sets *status and the abort word and runs on, so the grid always drains; the host reports it on the
+//   next call.  All bands x grids of one launch must be co-resident (the launcher sizes the grid to the CU count).
+struct JacobiSync {
+    unsigned *flags;          // [B * nb + 1]: per band the number of hand-offs it has published (monotonic over the handle's life); last = abort
+    unsigned *status;         // host-visible word, set non-zero when a wait timed out
+    float *x0, *x1;           // exchange buffers, laid out like p (div and p2 of the handle)
+    unsigned base;            // flag value before this projection's first hand-off
+    int chunks, nb, grid0, ngrids, abort_slot, fault;
+    long long timeout_ticks;
+};
+
+template <int VEC>
+__device__ __forceinline__ void ldv_sc1(float (&dst)[VEC], __amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (VEC >= 4) {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 16 * q, 0, 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[4 * q + c] = __uint_as_float(t[c]);
+        }
+    } else if constexpr (VEC == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16);
+        dst[0] = __uint_as_float(t[0]);
+        dst[1] = __uint_as_float(t[1]);
+    } else {
+        dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 16));
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, const float (&src)[VEC]) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (VEC >= 4) {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            u32x4 t;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[c] = __float_as_uint(src[4 * q + c]);
+            __builtin_amdgcn_raw_buffer_store_b128(t, rs, byte_off + 16 * q, 0, 16);
+        }
+    } else if constexpr (VEC == 2) {
+        u32x2 t;
+        t[0] = __float_as_uint(src[0]);
+        t[1] = __float_as_uint(src[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(t, rs, byte_off, 0, 16);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(src[0]), rs, byte_off, 0, 16);
+    }
+}
+
+template <int VEC, int RPW, int MODE, bool PERSIST = false>
 __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float *__restrict__ p_in,
                                                             float *__restrict__ p_out, float *__restrict__ div,
                                                             float *__restrict__ u, float *__restrict__ v,
-                                                            int iters, int BR) {
+                                                            int iters, int BR, JacobiSync sy) {
     constexpr int TR = JB_NW * RPW, ROWF = 64 * VEC;
     __shared__ float edge[2][JB_NW][2][ROWF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Bands own unequal row ranges: the first and last band of a grid need a halo only on their inner side (the other side is the
     // physical boundary), so they own TR - HALO rows and the middle bands TR - 2 HALO (HALO = BR here).  One band: the whole grid.
-    const int b = blockIdx.y, nb = gridDim.x, halo = BR;
+    int band_, grid_, nb_;
+    if constexpr (PERSIST) {
+        // 1-D launch.  Blocks i and i + 8 share an XCD (round-robin dispatch: observed, not promised -- only the hand-off's speed depends
+        // on it): when the grids divide by 8, the bands of one grid take consecutive slots of one XCD.
+        nb_ = sy.nb;
+        const int id = blockIdx.x;
+        if ((sy.ngrids & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3;
+            grid_ = (slot / nb_) * 8 + xcd;
+            band_ = slot % nb_;
+        } else {
+            grid_ = id / nb_;
+            band_ = id % nb_;
+        }
+        grid_ += sy.grid0;
+    } else {
+        band_ = blockIdx.x; grid_ = blockIdx.y; nb_ = gridDim.x;
+    }
+    const int band = band_, b = grid_, nb = nb_, halo = BR;
     const int e_rows = TR - halo, m_rows = TR - 2 * halo;
-    const int own0 = blockIdx.x == 0 ? 0 : e_rows + ((int)blockIdx.x - 1) * m_rows;
-    int own1 = (int)blockIdx.x == nb - 1 ? g.H : e_rows + (int)blockIdx.x * m_rows;
+    const int own0 = band == 0 ? 0 : e_rows + (band - 1) * m_rows;
+    int own1 = band == nb - 1 ? g.H : e_rows + band * m_rows;
     own1 = own1 < g.H ? own1 : g.H;
-    int r0 = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == nb - 1 ? g.H - TR : own0 - halo);
+    int r0 = band == 0 ? 0 : (band == nb - 1 ? g.H - TR : own0 - halo);
     if (r0 > g.H - TR) r0 = g.H - TR;
     if (r0 < 0) r0 = 0;
     const int row0 = r0 + wave * RPW, j0 = lane * VEC;
@@ -360,7 +437,7 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
                 dv[k][c] = __fdiv_rn(a, g.dt);
             }
             const int gi = row0 + k;
-            if (gi >= own0 && gi < own1) {
+            if (!PERSIST && gi >= own0 && gi < own1) {        // (a persistent launch keeps div in registers to the end)
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) div[base + (size_t)k * g.pc + c] = dv[k][c];
             }
@@ -427,17 +504,75 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
         }
     };
     float pw[RPW][VEC];
-    int it = 0;
-    for (; it + 2 <= iters; it += 2) {
-        sweep(pv, pw, 0);
-        sweep(pw, pv, 1);
-    }
-    if (it < iters) {
-        sweep(pv, pw, 0);
+    auto run = [&](int n) {                                   // n sweeps, result in pv
+        int it = 0;
+        for (; it + 2 <= n; it += 2) {
+            sweep(pv, pw, 0);
+            sweep(pw, pv, 1);
+        }
+        if (it < n) {
+            sweep(pv, pw, 0);
 #pragma unroll
-        for (int k = 0; k < RPW; ++k)
+            for (int k = 0; k < RPW; ++k)
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) pv[k][c] = pw[k][c];
+                for (int c = 0; c < VEC; ++c) pv[k][c] = pw[k][c];
+        }
+    };
+    if constexpr (!PERSIST) {
+        run(iters);
+    } else {
+        const int me = b * nb + band;
+        const unsigned row_off = (unsigned)(base * sizeof(float));          // byte offset of this lane's cells of tile row row0 in x0 / x1
+        const unsigned pitch_b = (unsigned)(g.pc * sizeof(float));
+        const unsigned xbytes = (unsigned)((size_t)(sy.grid0 + sy.ngrids) * g.sc * sizeof(float));
+        const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(sy.x0, 0, xbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(sy.x1, 0, xbytes, 0x00020000);
+        int done = 0;
+        for (int c = 0; c < sy.chunks; ++c) {
+            const int n = (iters - done + (sy.chunks - c) - 1) / (sy.chunks - c);
+            run(n);
+            done += n;
+            if (c == sy.chunks - 1) break;
+            const __amdgpu_buffer_rsrc_t rx = (c & 1) ? rx1 : rx0;
+            // publish: the `halo` owned rows next to each inner boundary
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const int gi = row0 + k;
+                const bool pub = (band > 0 && gi >= own0 && gi < own0 + halo) || (band < nb - 1 && gi >= own1 - halo && gi < own1);
+                if (pub) stv_sc1<VEC>(rx, row_off + k * pitch_b, pv[k]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores before the barrier
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned tgt = sy.base + (unsigned)c + 1u;
+                if (!(sy.fault && me == sy.grid0 * nb))       // (fault injection for the time-out test: one band never publishes)
+                    __hip_atomic_store(sy.flags + me, tgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    const bool up = band == 0 ||
+                        (int)(__hip_atomic_load(sy.flags + me - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tgt) >= 0;
+                    const bool dn = band == nb - 1 ||
+                        (int)(__hip_atomic_load(sy.flags + me + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tgt) >= 0;
+                    if (up && dn) break;
+                    if (__hip_atomic_load(sy.flags + sy.abort_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    if (wall_clock64() - t0 > sy.timeout_ticks) {
+                        __hip_atomic_store(sy.flags + sy.abort_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(sy.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+            // refresh: the halo rows (the neighbours' published rows; rows of the tile beyond them stay stale, which `halo` sweeps
+            // cannot carry into the owned range)
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const int gi = row0 + k;
+                const bool need = (gi >= own0 - halo && gi < own0) || (gi >= own1 && gi < own1 + halo);
+                if (need) ldv_sc1<VEC>(pv[k], rx, row_off + k * pitch_b);
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
@@ -489,8 +624,10 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
 // Diagnostic switches of the projection, read ONCE per process (never on the per-step path):
 //   SMK_JACOBI_GENERIC=1   one launch per sweep (k_jacobi_sweep)        SMK_PROJECT_UNFUSED=1  divergence / gradient as own launches
 //   SMK_JACOBI_RPW, SMK_JACOBI_BANDS   pin the band plan of k_jacobi_band   SMK_STENCIL_DEBUG=1    print the chosen plan
+//   SMK_JACOBI_PERSIST=0   one launch per chunk of sweeps instead of the single persistent launch
+//   SMK_JACOBI_FAULT=1     (test only) one band never publishes its hand-off: exercises the bounded wait and the error report
 struct StencilKnobs {
-    bool generic, unfused, debug;
+    bool generic, unfused, debug, persist, fault;
     int rpw, bands;
     StencilKnobs() {
         auto flag = [](const char *n, bool dflt) { const char *v = getenv(n); return v ? v[0] == '1' : dflt; };
@@ -498,6 +635,8 @@ struct StencilKnobs {
         generic = flag("SMK_JACOBI_GENERIC", false);
         unfused = flag("SMK_PROJECT_UNFUSED", false);
         debug = flag("SMK_STENCIL_DEBUG", false);
+        persist = flag("SMK_JACOBI_PERSIST", true);
+        fault = flag("SMK_JACOBI_FAULT", false);
         rpw = num("SMK_JACOBI_RPW");
         bands = num("SMK_JACOBI_BANDS");
     }
@@ -509,7 +648,8 @@ static const StencilKnobs &knobs() {
 
 // Band plan for the register-resident kernel; false -> use the generic per-sweep kernel.
 struct JacobiPlan { int vec, rpw, br, nb, halo; };
-static bool plan_jacobi(const Geom &g, JacobiPlan &pl, int iters = 100) {
+// persist: cost the plan for the single-launch form (a hand-off between chunks instead of a relaunch)
+static bool plan_jacobi(const Geom &g, JacobiPlan &pl, int iters = 100, bool persist = false) {
     if (g.W % 64 != 0 || g.W / 64 > 8 || (g.W / 64 & (g.W / 64 - 1)) || g.pc % 4 != 0) return false;
     if (knobs().generic) return false;
     pl.vec = g.W / 64;
@@ -534,12 +674,19 @@ static bool plan_jacobi(const Geom &g, JacobiPlan &pl, int iters = 100) {
                 if (halo > (TR - 1) / 2) halo = (TR - 1) / 2;          // middle bands keep at least one owned row
                 if ((TR - halo) + (nb - 2) * (TR - 2 * halo) >= g.H) continue;   // a smaller halo than the cover needs: the last band would own nothing
             }
+            if (persist && nb > 1) {                          // every band must own more rows than the halo (persist_chunks)
+                const int e_rows = TR - halo, m_rows = TR - 2 * halo, last = g.H - (e_rows + (nb - 2) * m_rows);
+                if (e_rows <= halo || last <= halo || (nb > 2 && m_rows <= halo) || nb > 64) continue;
+            }
             const int br = halo;                              // handed to the kernel (it derives the owned ranges from it)
             const double wgs = (double)nb * g.B, rounds = ceil(wgs / 256.0);
             // measured on MI355X (256^2 x 64, profiles/r01): ~6 us fixed per launch, ~1.33 us per sweep at 96 rows per
             // workgroup (barrier + LDS round trip bound, roughly linear in the rows a CU owns)
             const double cost_per_sweep = rounds * TR * (1.33 / 96.0), launch = 6.0;
-            const double cost = 2 * ceil(0.5 * iters / halo) * launch + iters * cost_per_sweep;
+            // a relaunch reloads the band's p and div (~6 us with the boundary); a hand-off inside the persistent launch moves 2 * halo rows
+            // per band through sc1 stores / flag / sc1 loads (~3.5 us)
+            const double cost = persist ? launch + (ceil((double)iters / halo) - 1) * 3.5 + iters * cost_per_sweep
+                                        : 2 * ceil(0.5 * iters / halo) * launch + iters * cost_per_sweep;
             if (cost < best) { best = cost; pl.rpw = rpw; pl.br = br; pl.nb = nb; pl.halo = halo; ok = true; }
         }
     }
@@ -551,13 +698,46 @@ template <int VEC, int MODE>
 static void launch_band(const Geom &g, const JacobiPlan &pl, const float *pin, float *pout, float *div, float *u, float *v,
                         int iters, hipStream_t st) {
     dim3 grid(pl.nb, g.B), block(JB_NW * 64);
+    const JacobiSync none{};
     switch (pl.rpw) {
-        case 2: hipLaunchKernelGGL((k_jacobi_band<VEC, 2, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
-        case 3: hipLaunchKernelGGL((k_jacobi_band<VEC, 3, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
-        case 4: hipLaunchKernelGGL((k_jacobi_band<VEC, 4, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
-        case 6: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 6, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
-        case 8: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 8, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br); break;
+        case 2: hipLaunchKernelGGL((k_jacobi_band<VEC, 2, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br, none); break;
+        case 3: hipLaunchKernelGGL((k_jacobi_band<VEC, 3, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br, none); break;
+        case 4: hipLaunchKernelGGL((k_jacobi_band<VEC, 4, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br, none); break;
+        case 6: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 6, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br, none); break;
+        case 8: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 8, MODE>), grid, block, 0, st, g, pin, pout, div, u, v, iters, pl.br, none); break;
     }
+}
+
+// the whole projection as one persistent launch per group of co-resident grids
+template <int VEC>
+static void launch_persist(const Geom &g, const JacobiPlan &pl, float *p, float *u, float *v, int iters, const JacobiSync &sy, hipStream_t st) {
+    dim3 grid(pl.nb * sy.ngrids), block(JB_NW * 64);
+    switch (pl.rpw) {
+        case 2: hipLaunchKernelGGL((k_jacobi_band<VEC, 2, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 3: hipLaunchKernelGGL((k_jacobi_band<VEC, 3, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 4: hipLaunchKernelGGL((k_jacobi_band<VEC, 4, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 6: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 6, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 8: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 8, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+    }
+}
+
+// Can this plan run as one persistent launch, and in how many chunks?  Every band must own more rows than the halo (a band's halo rows
+// then lie in its direct neighbour's owned range, and the u / v rows a neighbour's divergence reads are not rewritten before it has
+// published once); chunk sizes are ceil / floor of iters / chunks: the largest <= halo, the last <= halo - 1 (the fused gradient needs
+// the row above the owned range exact); two or more bands need two or more chunks (the first hand-off orders the final stores
+// behind the neighbours' initial loads).
+static bool persist_chunks(const Geom &g, const JacobiPlan &pl, int iters, int &chunks) {
+    const int TR = JB_NW * pl.rpw;
+    if (pl.nb == 1) { chunks = 1; return true; }
+    if (pl.nb > 64 || (size_t)g.B * g.sc * sizeof(float) >= (1ull << 31)) return false;
+    const int e_rows = TR - pl.halo, m_rows = TR - 2 * pl.halo, last = g.H - (e_rows + (pl.nb - 2) * m_rows);
+    int min_owned = e_rows < last ? e_rows : last;
+    if (pl.nb > 2 && m_rows < min_owned) min_owned = m_rows;
+    if (min_owned < pl.halo + 1) return false;
+    chunks = (iters + pl.halo - 1) / pl.halo;
+    if (chunks < 2) chunks = 2;
+    while ((iters + chunks - 1) / chunks > pl.halo || iters / chunks > pl.halo - 1) ++chunks;
+    return chunks <= iters;
 }
 
 template <int MODE>
@@ -600,8 +780,60 @@ hipError_t launch_jacobi(const Geom &g, float *p, float *p2, const float *div, i
 
 // pressure_projection (navier_stokes.py:133-149) on (u, v, p): divergence, `iters` Jacobi sweeps, gradient subtraction.
 // With a band plan the divergence is computed inside the first Jacobi launch and the gradient subtraction inside the last.
-hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st) {
+hipError_t project_sync_create(ProjectSync &ps, int B) {
+    ps.flags_len = B * 64 + 1;
+    hipError_t e = hipMalloc((void **)&ps.flags, ps.flags_len * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(ps.flags, 0, ps.flags_len * sizeof(unsigned));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ps.status, sizeof(unsigned), hipHostMallocMapped);
+    if (e == hipSuccess) *ps.status = 0u;
+    return e;
+}
+void project_sync_destroy(ProjectSync &ps) {
+    if (ps.flags) (void)hipFree(ps.flags);
+    if (ps.status) (void)hipHostFree((void *)ps.status);
+    ps.flags = nullptr;
+    ps.status = nullptr;
+}
+
+static bool use_persist(const Geom &g, const ProjectSync *ps, int iters, JacobiPlan &pl, int &chunks) {
+    if (!ps || !ps->flags || ps->disabled || !knobs().persist || knobs().unfused || iters < 2) return false;
+    if (!plan_jacobi(g, pl, iters, true) || pl.halo < 3) return false;
+    if (pl.nb > device_num_cu()) return false;
+    return persist_chunks(g, pl, iters, chunks);
+}
+
+hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st, ProjectSync *ps) {
     JacobiPlan pl;
+    if (ps && ps->status && *ps->status != 0u && !ps->disabled) {
+        // a wait inside an earlier persistent launch timed out (its workgroups were not co-resident within the limit): that projection's
+        // result is invalid.  Say so once, loudly, and use the multi-launch form from here on.
+        ps->disabled = true;
+        return hipErrorLaunchTimeOut;
+    }
+    int chunks = 0;
+    if (use_persist(g, ps, iters, pl, chunks)) {
+        int per = device_num_cu() / pl.nb;                    // grids whose bands are all co-resident (one 1024-thread workgroup per CU)
+        if (per >= 8) per &= ~7;
+        if (knobs().debug)
+            fprintf(stderr, "[smk] project %dx%dx%d J=%d: persistent, vec=%d rpw=%d nb=%d halo=%d, %d chunks, %d grids per launch\n", g.B, g.H, g.W,
+                    iters, pl.vec, pl.rpw, pl.nb, pl.halo, chunks, per);
+        JacobiSync sy{};
+        sy.flags = ps->flags; sy.status = const_cast<unsigned *>(ps->status); sy.x0 = div; sy.x1 = p2;
+        sy.base = ps->seq; sy.chunks = chunks; sy.nb = pl.nb; sy.abort_slot = ps->flags_len - 1; sy.fault = knobs().fault ? 1 : 0;
+        sy.timeout_ticks = knobs().fault ? 200000ll : 50000000ll;      // 100 MHz wall clock: 2 ms under fault injection, 0.5 s otherwise
+        ps->seq += (unsigned)chunks;
+        for (int g0 = 0; g0 < g.B; g0 += per) {
+            sy.grid0 = g0;
+            sy.ngrids = g.B - g0 < per ? g.B - g0 : per;
+            switch (pl.vec) {
+                case 1: launch_persist<1>(g, pl, p, u, v, iters, sy, st); break;
+                case 2: launch_persist<2>(g, pl, p, u, v, iters, sy, st); break;
+                case 4: launch_persist<4>(g, pl, p, u, v, iters, sy, st); break;
+                case 8: launch_persist<8>(g, pl, p, u, v, iters, sy, st); break;
+            }
+        }
+        return hipGetLastError();
+    }
     if (iters < 2 || !plan_jacobi(g, pl, iters) || pl.halo < 3 || knobs().unfused) {
         hipError_t e = launch_divergence(g, u, v, div, g.pc, g.sc, st);
         if (e != hipSuccess) return e;
@@ -629,27 +861,33 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
 
 // What one projection launches for this geometry, as a JSON object (bench.py reports it as the stencil pass's on-chip bound: the
 // Jacobi sweeps never touch HBM, so what limits them is sweeps x rows per workgroup x vector-issue time, not bytes).
-std::string describe_projection(const Geom &g, int iters) {
+std::string describe_projection(const Geom &g, int iters, const ProjectSync *ps) {
     JacobiPlan pl;
-    char buf[1024];
-    if (iters < 2 || !plan_jacobi(g, pl, iters) || pl.halo < 3 || knobs().unfused) {
+    char buf[1280];
+    int chunks = 0;
+    const bool persist = use_persist(g, ps, iters, pl, chunks);
+    if (!persist && (iters < 2 || !plan_jacobi(g, pl, iters) || pl.halo < 3 || knobs().unfused)) {
         snprintf(buf, sizeof buf, "{\"kernel\": \"k_jacobi_sweep\", \"launches\": %d, \"sweeps\": %d, \"bound\": \"hbm (one pass over p and div per sweep)\"}",
                  iters + 2, iters);
         return buf;
     }
-    const int cap = pl.halo - 1, L = 2 * ((iters + 2 * cap - 1) / (2 * cap)), TR = JB_NW * pl.rpw;
+    const int cap = pl.halo - 1, TR = JB_NW * pl.rpw;
+    const int per = persist ? (device_num_cu() / pl.nb >= 8 ? (device_num_cu() / pl.nb) & ~7 : device_num_cu() / pl.nb) : 0;
+    const int L = persist ? (g.B + per - 1) / per : 2 * ((iters + 2 * cap - 1) / (2 * cap));
+    const int parts = persist ? chunks : L;                   // runs of sweeps between two refreshes of the halo rows
     const double wgs = (double)pl.nb * g.B, rounds = ceil(wgs / device_num_cu());
     // measured (tools/probes/valu_probe, 4 waves per SIMD): a sweep row of 64 VEC-cell lanes = ~18 vector instructions of which 2 are DPP
     // wave shifts, ~2.6 cycles per instruction and SIMD -> TR rows on 4 SIMDs; plus the publish -> s_barrier -> read round trip per sweep
     const double valu_us_per_sweep = rounds * (TR / 4.0) * 18.0 * 2.6 / 2100.0;
     snprintf(buf, sizeof buf,
-             "{\"kernel\": \"k_jacobi_band<%d,%d>\", \"bands_per_grid\": %d, \"rows_per_workgroup\": %d, \"halo_rows\": %d, \"workgroups\": %d, "
-             "\"launches\": %d, \"sweeps\": %d, \"sweeps_per_launch\": %d, \"redundant_row_factor\": %.3f, "
+             "{\"kernel\": \"k_jacobi_band<%d,%d>\", \"persistent\": %s, \"bands_per_grid\": %d, \"rows_per_workgroup\": %d, \"halo_rows\": %d, "
+             "\"workgroups\": %d, \"launches\": %d, \"halo_handoffs\": %d, \"sweeps\": %d, \"sweeps_per_chunk\": %d, \"redundant_row_factor\": %.3f, "
              "\"vector_issue_us_per_sweep_estimate\": %.3f, \"vector_issue_us_total_estimate\": %.1f, "
              "\"bound\": \"on-chip: sweeps x (vector issue of rows_per_workgroup rows + one LDS publish/barrier/read round trip); p and div are "
-             "register-resident within a launch\"}",
-             pl.vec, pl.rpw, pl.nb, TR, pl.halo, (int)wgs, L, iters, (iters + L - 1) / L, (double)pl.nb * TR / g.H, valu_us_per_sweep,
-             valu_us_per_sweep * iters);
+             "register-resident %s\"}",
+             pl.vec, pl.rpw, persist ? "true" : "false", pl.nb, TR, pl.halo, (int)wgs, L, persist ? chunks - 1 : 0, iters, (iters + parts - 1) / parts,
+             (double)pl.nb * TR / g.H, valu_us_per_sweep, valu_us_per_sweep * iters,
+             persist ? "for the whole projection; bands hand halo rows to their neighbours through HBM between chunks" : "within a launch");
     return buf;
 }
 
