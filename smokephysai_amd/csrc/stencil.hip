@@ -811,7 +811,10 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
         return hipErrorLaunchTimeOut;
     }
     int chunks = 0;
-    if (use_persist(g, ps, iters, pl, chunks)) {
+    // (a captured launch would replay with the hand-off count of capture time: under stream capture the multi-launch form is recorded)
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone;
+    if (!capturing && use_persist(g, ps, iters, pl, chunks)) {
         int per = device_num_cu() / pl.nb;                    // grids whose bands are all co-resident (one 1024-thread workgroup per CU)
         if (per >= 8) per &= ~7;
         if (knobs().debug)

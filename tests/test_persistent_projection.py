@@ -104,3 +104,30 @@ def test_a_band_that_never_publishes_times_out_and_is_reported():
     assert line[1] == "raised", line
     assert float(line[2]) < 30.0, line    # bounded: 2 ms per wait under fault injection (first call includes library start-up)
     assert line[3] == "True", line
+
+
+def test_time_steps_recorded_in_a_hip_graph_replay_bit_identically():
+    """The persistent launch compares hand-off flags with a per-call count, which a replayed graph would not advance: under stream
+    capture the library records the multi-launch form instead.  Three replays of one captured step == three eager steps."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from smokephysai_amd.physics import NavierStokesSimulator
+    B, N = 64, 256
+    srcs = [(b, 40 + 2 * b, 200 - b, 6 + b % 5, 1.0 + 0.01 * b) for b in range(B)]
+    eager = NavierStokesSimulator((N, N), batch_size=B, jacobi_iters=100)
+    graphed = NavierStokesSimulator((N, N), batch_size=B, jacobi_iters=100)
+    eager.add_smoke_sources(srcs)
+    graphed.add_smoke_sources(srcs)
+    assert eager.jacobi_plan()["projection"]["persistent"] is True
+    fa, fb = torch.empty(B, N, N, device="cuda"), torch.empty(B, N, N, device="cuda")
+    for _ in range(3):
+        eager.step_into(fa, 1)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step_into(fb, 1)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for k in ("u", "v", "p", "density"):
+        assert torch.equal(getattr(eager, k), getattr(graphed, k)), k
+    assert torch.equal(fa, fb)
