@@ -268,6 +268,33 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4):
         ar = (time.perf_counter() - t0) / 5
         res["allreduce_flat"] = {"bytes": nparam * 4, "ms": ar * 1e3, "algbw_GBs": nparam * 4 / ar / 1e9,
                                  "busbw_GBs": nparam * 4 / ar / 1e9 * 2 * (world - 1) / world}
+        # SURVEY 8f-3's alternative on the same bytes: all-to-all of the shards + ordered local sum + all-gather (every xGMI link busy
+        # for two hops instead of a ring's 2 (N-1) dependent hops) -- first as flat collectives, then as the DDP hook inside the step
+        shard = (nparam + world - 1) // world
+        send, recv = torch.zeros(world * shard, device=flat.device), torch.empty(world * shard, device=flat.device)
+        out = torch.empty(world * shard, device=flat.device)
+
+        def direct_once():
+            dist.all_to_all_single(recv, send)
+            mine = recv.view(world, shard).sum(0) / world
+            dist.all_gather_into_tensor(out, mine)
+        for _ in range(2):
+            direct_once()
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            direct_once()
+        torch.cuda.synchronize()
+        dr = (time.perf_counter() - t0) / 5
+        res["direct_exchange_flat"] = {"bytes": nparam * 4, "ms": dr * 1e3, "algbw_GBs": nparam * 4 / dr / 1e9,
+                                       "what": "all_to_all_single + local sum in rank order + all_gather_into_tensor"}
+        del ddp, send, recv, out, flat
+        import gc
+        gc.collect()                                         # (the first wrapper's reducer hooks go with it)
+        ddp = wrap_ddp(model, dev, grad_exchange="direct")
+        for _ in range(2):
+            step()
+        res["direct_exchange_step"] = {"ms_per_step": timed(steps), "ddp_buckets": ddp_bucket_report(ddp)}
     return res
 
 

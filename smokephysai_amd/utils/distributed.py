@@ -37,18 +37,80 @@ def init_distributed(backend: str = None):
     return rank, world, local_rank
 
 
-def wrap_ddp(model: torch.nn.Module, device, sync_bn: bool = False) -> torch.nn.Module:
-    """DistributedDataParallel around `model` when a process group exists (gradient all-reduce = mean over ranks)."""
+class DirectExchangeState:
+    """State of `direct_exchange_hook`: the process group, the wire dtype of the shards (None = the gradients' own fp32) and what the
+    hook has moved so far (for logging)."""
+
+    def __init__(self, process_group=None, wire_dtype=None):
+        self.process_group = process_group
+        self.wire_dtype = wire_dtype
+        self.calls = 0
+        self.bytes_sent = 0
+
+
+def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) -> torch.futures.Future[torch.Tensor]:
+    """DDP communication hook: the gradient mean as a DIRECT reduce-scatter + all-gather instead of a ring all-reduce.
+
+    xGMI is a full mesh of point-to-point links (7 per GPU), so a ring moves 2 (N-1)/N of the bucket over ONE link per hop in 2 (N-1)
+    dependent hops, while the mesh can carry every rank's shard to its owner at once: (1) all-to-all -- rank r receives shard r of every
+    rank's bucket, one hop, all links busy; (2) the owner adds its N copies in rank order (the same order on every run and for every
+    element: deterministic, unlike a ring whose summation order depends on the element's position) and divides by N; (3) all-gather of the
+    reduced shards, one hop.  Each rank sends and receives (N-1)/N of the bucket twice -- the ring's byte count, in 2 hops instead of 2 (N-1).
+    `state.wire_dtype = torch.bfloat16` halves the bytes on both hops (the sum itself stays fp32); off by default because the averaged
+    gradient is then rounded to 8 bits.  Collectives are the backend's all_to_all_single / all_gather_into_tensor (RCCL on ROCm; gloo on
+    CPU for the tests); the all-gather of one bucket overlaps the rest of backward."""
+    group = state.process_group if state.process_group is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    buf = bucket.buffer()
+    n = buf.numel()
+    shard = (n + world - 1) // world
+    wire = state.wire_dtype or buf.dtype
+    # (gloo moves host tensors only: a 1-GPU rehearsal of the multi-rank path stages the bucket through the host)
+    comm_dev = torch.device("cpu") if (buf.is_cuda and dist.get_backend(group) == "gloo") else buf.device
+    send = torch.zeros(world * shard, dtype=wire, device=comm_dev)
+    send[:n].copy_(buf)
+    recv = torch.empty_like(send)
+    state.calls += 1
+    state.bytes_sent += 2 * (world - 1) * shard * send.element_size()
+    # hop 1 is enqueued in call order (RCCL: stream-ordered, the host does not block; the bucket's own backward kernels have finished by
+    # the time DDP calls the hook); only hop 2 is returned as the future -- no callback ever waits on another collective, so backends that
+    # run callbacks on their worker threads (gloo) cannot deadlock with several buckets in flight
+    dist.all_to_all_single(recv, send, group=group)
+    parts = recv.view(world, shard)
+    mine = parts[0].to(torch.float32)
+    for r in range(1, world):                               # rank order, one add per source: the same sum on every rank and run
+        mine = mine + parts[r].to(torch.float32)
+    mine = (mine / world).to(wire)
+    out = torch.empty(world * shard, dtype=wire, device=comm_dev)
+    fut = dist.all_gather_into_tensor(out, mine, group=group, async_op=True).get_future()
+
+    def finish(_f):
+        buf.copy_(out[:n])
+        return buf
+
+    return fut.then(finish)
+
+
+def wrap_ddp(model: torch.nn.Module, device, sync_bn: bool = False, grad_exchange: str = "rccl") -> torch.nn.Module:
+    """DistributedDataParallel around `model` when a process group exists (gradient all-reduce = mean over ranks).
+    grad_exchange: "rccl" = the backend's bucketed all-reduce; "direct" / "direct_bf16" = `direct_exchange_hook`."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
+    if grad_exchange not in ("rccl", "direct", "direct_bf16"):
+        raise ValueError(f"grad_exchange must be 'rccl', 'direct' or 'direct_bf16', not {grad_exchange!r}")
     if sync_bn:      # reference semantics = one process, whole-batch statistics: exchange the per-channel sums (models/sync_bn.py)
         from ..models.sync_bn import convert_sync_batchnorm
         model = convert_sync_batchnorm(model)
     dev = torch.device(device)
     if dev.type == "cuda":
-        return torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], bucket_cap_mb=64,
-                                                         gradient_as_bucket_view=True)
-    return torch.nn.parallel.DistributedDataParallel(model)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], bucket_cap_mb=64,
+                                                        gradient_as_bucket_view=True)
+    else:
+        ddp = torch.nn.parallel.DistributedDataParallel(model)
+    if grad_exchange != "rccl":
+        ddp._smk_exchange_state = DirectExchangeState(None, torch.bfloat16 if grad_exchange == "direct_bf16" else None)
+        ddp.register_comm_hook(ddp._smk_exchange_state, direct_exchange_hook)
+    return ddp
 
 
 def ddp_bucket_report(ddp) -> dict:
@@ -62,7 +124,9 @@ def ddp_bucket_report(ddp) -> dict:
         log = {}
     sizes = [int(x) for x in str(log.get("bucket_sizes", "")).split(",") if x.strip()]
     total = sum(p.numel() * p.element_size() for p in ddp.parameters() if p.requires_grad)
-    return {"backend": log.get("backend_name", dist.get_backend()), "world_size": dist.get_world_size(),
+    st = getattr(ddp, "_smk_exchange_state", None)
+    exchange = "rccl all-reduce" if st is None else ("direct reduce-scatter + all-gather" + (" (bf16 wire)" if st.wire_dtype else ""))
+    return {"backend": log.get("backend_name", dist.get_backend()), "world_size": dist.get_world_size(), "grad_exchange": exchange,
             "bucket_cap_bytes": int(log.get("bucket_cap_bytes", 0)) or None, "bucket_bytes": sizes,
             "num_buckets": len(sizes) or None, "grad_bytes": int(total),
             "gradient_as_bucket_view": bool(log.get("gradient_as_bucket_view", False))}

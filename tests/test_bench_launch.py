@@ -66,7 +66,8 @@ def test_self_launched_two_ranks_gloo_rehearsal():
     """`python bench.py --gpus 2` with no torchrun environment, on ONE card (gloo, both ranks on cuda:0): the parent spawns the
     ranks, rank 0 prints one JSON line with n_gpus 2 and the DDP train-step block (2 ranks exchanged gradients)."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "128", "--batch", "4",
-                        "--jacobi", "20"], capture_output=True, text=True, env=_clean_env(SMK_BENCH_BACKEND="gloo"), timeout=900)
+                        "--jacobi", "20", "--train-step-limit", "240"], capture_output=True, text=True, env=_clean_env(SMK_BENCH_BACKEND="gloo"),
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -77,3 +78,6 @@ def test_self_launched_two_ranks_gloo_rehearsal():
     assert ts["ranks"] == 2 and ts["global_batch"] == 8 and ts["ms_per_step"] > 0
     assert ts["ddp_buckets"]["world_size"] == 2 and ts["ddp_buckets"]["grad_bytes"] == 27782890 * 4
     assert ts["allreduce_flat"]["bytes"] == 27782890 * 4
+    # the direct reduce-scatter + all-gather alternative is timed beside it: flat and as the DDP hook inside the step
+    assert ts["direct_exchange_flat"]["ms"] > 0
+    assert ts["direct_exchange_step"]["ms_per_step"] > 0 and "direct" in ts["direct_exchange_step"]["ddp_buckets"]["grad_exchange"]

@@ -160,7 +160,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _ddp_worker(rank, world, port, golden_path, out_path):
+def _ddp_worker(rank, world, port, golden_path, out_path, exchange="rccl"):
     import torch.distributed as dist
     from smokephysai_amd.utils.distributed import all_reduce_mean_scalars, init_distributed, wrap_ddp
     import train
@@ -174,7 +174,7 @@ def _ddp_worker(rank, world, port, golden_path, out_path):
     for m in model.modules():                       # per-sample-independent BN so that DDP == single-process full batch
         if isinstance(m, torch.nn.BatchNorm2d):
             m.eval()
-    ddp = wrap_ddp(model, "cpu")
+    ddp = wrap_ddp(model, "cpu", grad_exchange=exchange)
     lo, hi = shard_range(2, rank, world)
     batch = {"input": torch.from_numpy(g["inputs"][lo:hi]), "target": torch.from_numpy(g["targets"][lo:hi]),
              "chaos_features": torch.from_numpy(g["chaos_targets"][lo:hi]), "sequence": torch.zeros(hi - lo, 20, 8, 8)}
@@ -182,19 +182,25 @@ def _ddp_worker(rank, world, port, golden_path, out_path):
     total, *_ = train.batch_losses(ddp, PhysicsRegularizer(), batch, "cpu", chaos_noise=noise)
     total.backward()
     mean_loss = all_reduce_mean_scalars([total.item()], "cpu")[0]
+    from smokephysai_amd.utils.distributed import ddp_bucket_report
     if rank == 0:
-        torch.save({"grads": {k: p.grad.clone() for k, p in model.named_parameters()}, "loss": mean_loss}, out_path)
+        torch.save({"grads": {k: p.grad.clone() for k, p in model.named_parameters()}, "loss": mean_loss,
+                    "report": ddp_bucket_report(ddp)}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ddp_gradients_equal_single_process(golden, tmp_path):
+@pytest.mark.parametrize("exchange", ["rccl", "direct"])
+def test_ddp_gradients_equal_single_process(golden, tmp_path, exchange):
+    """2 gloo ranks, one sample each: the averaged gradients equal the single-process full-batch gradients -- with the backend's
+    all-reduce and with the direct reduce-scatter + all-gather hook (utils/distributed.direct_exchange_hook)."""
     import torch.multiprocessing as mp
     import train
     gpath = os.path.join(os.path.dirname(__file__), "golden", "train_batch.npz")
     out = str(tmp_path / "ddp.pt")
-    mp.spawn(_ddp_worker, args=(2, _free_port(), gpath, out), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, _free_port(), gpath, out, exchange), nprocs=2, join=True)
     res = torch.load(out)
+    assert ("direct" in res["report"]["grad_exchange"]) == (exchange == "direct")
     g = golden("train_batch.npz")
     model = _small_model(g).train()
     for m in model.modules():
@@ -210,6 +216,43 @@ def test_ddp_gradients_equal_single_process(golden, tmp_path):
     scale = max(float(p.grad.abs().max()) for p in model.parameters())
     for k, p in model.named_parameters():
         assert float((p.grad - res["grads"][k]).abs().max()) / scale < 5e-5, k     # fp32 reduction-order noise (observed 1.5e-5)
+
+
+def _multibucket_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    from smokephysai_amd.utils.distributed import DirectExchangeState, direct_exchange_hook, init_distributed
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    init_distributed("gloo")
+    grads = {}
+    for mode in ("allreduce", "direct"):
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(12)])
+        d = torch.nn.parallel.DistributedDataParallel(m, bucket_cap_mb=0.02)       # ~10 buckets per backward
+        st = DirectExchangeState()
+        if mode == "direct":
+            d.register_comm_hook(st, direct_exchange_hook)
+        g = torch.Generator().manual_seed(100 + rank)
+        for _ in range(3):
+            m.zero_grad()
+            d(torch.randn(9, 64, generator=g)).pow(2).mean().backward()
+        grads[mode] = torch.cat([p.grad.flatten() for p in m.parameters()])
+        grads[mode + "_calls"] = st.calls
+    if rank == 0:
+        torch.save(grads, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_exchange_with_several_buckets_in_flight(tmp_path):
+    """The hook never waits on a collective inside a callback, so many buckets per backward cannot deadlock a backend that runs
+    callbacks on its worker threads; three steps of a 12-layer stack in ~10 buckets give the all-reduce's gradients."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "mb.pt")
+    mp.spawn(_multibucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["direct_calls"] >= 10
+    assert float((res["direct"] - res["allreduce"]).abs().max()) <= 1e-6 * float(res["allreduce"].abs().max())
 
 
 # ---------------------------------------------------------------- N>1: SyncBatchNorm == single-process whole-batch BatchNorm (SURVEY 8f-3)

@@ -168,7 +168,7 @@ def main():
         ckpt = torch.load(args.resume, map_location=device)
         model.load_state_dict(ckpt["model_state_dict"])
         start_epoch = int(ckpt.get("epoch", -1)) + 1
-    ddp_model = wrap_ddp(model, device, sync_bn=bool(hw.get("sync_bn", False)))
+    ddp_model = wrap_ddp(model, device, sync_bn=bool(hw.get("sync_bn", False)), grad_exchange=str(hw.get("grad_exchange", "rccl")))
     if ddp_model is not model:                         # SyncBatchNorm conversion replaces modules: validate on the wrapped network
         model = ddp_model.module
         if rank == 0:
