@@ -408,6 +408,10 @@ def main(argv=None):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     # one process per GPU; SMK_BENCH_BACKEND=gloo lets a 1-GPU box rehearse the N>1 control path (ranks share cuda:0)
     backend = os.environ.get("SMK_BENCH_BACKEND", "nccl")
+    if backend != "nccl" and world > 1:
+        # rehearsal ranks SHARE one card: the single-launch projection needs all its workgroups resident at once (one process per GPU is
+        # the deployment model), so two processes on one device take the multi-launch form (read once, when libsmokehip loads)
+        os.environ.setdefault("SMK_JACOBI_PERSIST", "0")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
