@@ -195,7 +195,7 @@ def attach_counters(out, encoder_dtype):
         out["roofline_encoder"]["pmc"] = d
 
 
-def train_step_leg(dev, N, B, dist, world, backend, steps=4):
+def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None):
     """train.py's step (zero_grad, batch_losses, backward, clip 1.0, AdamW) on a device-built batch of B frames per rank
     (BASELINE configs[3]'s per-GPU shape), the model wrapped by utils.distributed.wrap_ddp exactly like train.py:main does:
     with N > 1 ranks the 27.8 M fp32 gradients (111 MB) are all-reduced over RCCL in 64 MB buckets overlapped with backward.
@@ -246,12 +246,13 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4):
         step()
     ms = timed(steps)
     nparam = sum(p.numel() for p in model.parameters())
-    res = {"ms_per_step": ms, "frames_per_s": world * B / (ms * 1e-3), "batch_per_gpu": B, "global_batch": world * B, "grid": N,
+    res = {} if res is None else res                         # filled as the leg goes: the watchdog prints what is there if a later part hangs
+    res.update({"ms_per_step": ms, "frames_per_s": world * B / (ms * 1e-3), "batch_per_gpu": B, "global_batch": world * B, "grid": N,
            "rccl_ranks": world if (dist is not None and backend == "nccl") else 0, "ranks": world,
            "collective_backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None,
            "grad_bytes_fp32": nparam * 4,
            "note": "forward + backward + gradient all-reduce (DDP, overlapped) + clip + AdamW; linear GEMMs, attention, LayerNorm and the "
-                   "encoder's BatchNorm/ReLU/pool, GELU/dropout/residual of the FFN on libsmokehip; convolutions on PyTorch-ROCm (MIOpen)"}
+                   "encoder's BatchNorm/ReLU/pool, GELU/dropout/residual of the FFN on libsmokehip; convolutions on PyTorch-ROCm (MIOpen)"})
     if dist is not None:
         res["ms_per_step_no_allreduce"] = timed(steps, sync=False)          # same step under ddp.no_sync(): what the exchange costs
         res["ddp_buckets"] = ddp_bucket_report(ddp)
@@ -556,12 +557,14 @@ def main(argv=None):
         # at the same deadline, rank 0 printing the headline line it already holds
         import threading
         done = threading.Event()
+        ts_partial = {}
 
         def abandon():
             if done.is_set():
                 return
             if rank == 0:
-                out["train_step"] = {"error": f"abandoned after {args.train_step_limit:.0f} s (watchdog)"}
+                out["train_step"] = dict(ts_partial, error=f"abandoned after {args.train_step_limit:.0f} s (watchdog); the keys beside this one "
+                                                            "were measured before the part that did not return")
                 print(json.dumps(out), flush=True)
             os._exit(0)
         dog = threading.Timer(args.train_step_limit, abandon)
@@ -570,9 +573,9 @@ def main(argv=None):
         del sim, enc
         torch.cuda.empty_cache()
         try:
-            ts = train_step_leg(dev, N, B, dist, world, backend)
+            ts = train_step_leg(dev, N, B, dist, world, backend, res=ts_partial)
         except Exception as e:                                   # the headline number must survive a failure of this leg
-            ts = {"error": f"{type(e).__name__}: {e}"[:400]}
+            ts = dict(ts_partial, error=f"{type(e).__name__}: {e}"[:400])
         done.set(); dog.cancel()
         if rank == 0:
             out["train_step"] = ts
