@@ -125,6 +125,17 @@ int check_launch(hipError_t e, const char *what) {
     return SMK_OK;
 }
 
+int project_status(hipError_t e) {
+    if (e == hipErrorLaunchTimeOut) {
+        set_error("project: a band of an earlier persistent projection waited longer than 0.5 s for its neighbour (its workgroups were "
+                  "not all resident at once -- is another kernel holding compute units?); the state since that step is invalid. "
+                  "Reset the simulator; later projections of this handle use the multi-launch form (SMK_JACOBI_PERSIST=0 selects it "
+                  "from the start)");
+        return SMK_ERR_HIP;
+    }
+    return check_launch(e, "project");
+}
+
 int run_stage(smk_sim *sim, int stage, float *frames, int64_t fsb, const float *fractal, float fint, hipStream_t st) {
     const Geom &g = sim->g;
     StateView &s = sim->s, &t = sim->t;
@@ -132,15 +143,7 @@ int run_stage(smk_sim *sim, int stage, float *frames, int64_t fsb, const float *
         case SMK_STAGE_BUOY_DIFFUSE:   // s -> t (u2, v2, d2)
             return check_launch(launch_buoy_diffuse(g, s, t, st), "buoy_diffuse");
         case SMK_STAGE_PROJECT: {      // on t.u, t.v with s.p
-            const hipError_t e = launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st, &sim->psync);
-            if (e == hipErrorLaunchTimeOut) {
-                set_error("project: a band of an earlier persistent projection waited longer than 0.5 s for its neighbour (its workgroups were "
-                          "not all resident at once -- is another kernel holding compute units?); the state since that step is invalid. "
-                          "Reset the simulator; later projections of this handle use the multi-launch form (SMK_JACOBI_PERSIST=0 selects it "
-                          "from the start)");
-                return SMK_ERR_HIP;
-            }
-            return check_launch(e, "project");
+            return project_status(launch_project(g, t.u, t.v, s.p, t.p, sim->div, sim->jacobi_iters, st, &sim->psync));
         }
         case SMK_STAGE_ADVECT_U:       // u <- adv(u2; u2, v2)
             return check_launch(launch_advect(g, 0, t.u, s.u, t.u, t.v, nullptr, 0, nullptr, 0.f, nullptr, nullptr, st),
@@ -290,8 +293,14 @@ int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t fsb, int6
     for (int t = 0; t < n_steps; ++t) {
         float *ft = frames ? frames + (size_t)t * fst : nullptr;
         static const bool staged = getenv("SMK_ADVECT_STAGED") != nullptr;      // diagnostic: the three advections as three launches
-        for (int stage = SMK_STAGE_BUOY_DIFFUSE; stage <= (staged ? SMK_STAGE_ADVECT_D : SMK_STAGE_PROJECT); ++stage) {
-            rc = run_stage(sim, stage, stage == SMK_STAGE_ADVECT_D ? ft : nullptr, fsb, fr, (float)fractal_intensity, st);
+        if (staged) {
+            for (int stage = SMK_STAGE_BUOY_DIFFUSE; stage <= SMK_STAGE_ADVECT_D; ++stage) {
+                rc = run_stage(sim, stage, stage == SMK_STAGE_ADVECT_D ? ft : nullptr, fsb, fr, (float)fractal_intensity, st);
+                if (rc) return rc;
+            }
+        } else {
+            // buoyancy + diffusion + projection: one persistent launch where the plan allows (stencil.hip: launch_buoy_project)
+            rc = project_status(launch_buoy_project(sim->g, sim->s, sim->t, sim->s.p, sim->div, sim->jacobi_iters, st, &sim->psync));
             if (rc) return rc;
         }
         if (!staged) {      // u <- adv(u2; u2, v2), v <- adv(v2; u, v2), density <- adv(d2; u, v) * 0.995 (+ frame) in one launch

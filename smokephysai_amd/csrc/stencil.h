@@ -29,8 +29,12 @@ void project_sync_destroy(ProjectSync &ps);
 // divergence + `iters` Jacobi sweeps + gradient subtraction on (u, v, p); p2 and div are scratch.  With `ps` the projection runs as one
 // persistent launch where the plan allows (stencil.hip: k_jacobi_band<..., PERSIST>); returns hipErrorLaunchTimeOut once if an earlier
 // persistent launch reported a timed-out wait, and uses the multi-launch form afterwards.
+// fold_in / fold_d_out: when given and the persistent form is taken, the step's buoyancy + diffusion stage (fold_in -> u, v, fold_d_out)
+// runs as that launch's prologue; *folded says whether it did (otherwise the caller's u, v must already hold the diffused fields).
 hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st,
-                          ProjectSync *ps = nullptr);
+                          ProjectSync *ps = nullptr, const StateView *fold_in = nullptr, float *fold_d_out = nullptr, bool *folded = nullptr);
+// buoyancy + diffusion (in -> out.u, out.v, out.d) followed by the projection of (out.u, out.v) with p: one launch where possible.
+hipError_t launch_buoy_project(const Geom &g, StateView in, StateView out, float *p, float *div, int iters, hipStream_t st, ProjectSync *ps);
 // JSON description of what launch_project does for this geometry (kernel, bands, launches, sweeps per launch, on-chip estimates).
 std::string describe_projection(const Geom &g, int iters, const ProjectSync *ps = nullptr);
 hipError_t launch_grad_subtract(const Geom &g, float *u, float *v, const float *p, hipStream_t st);

@@ -336,6 +336,9 @@ struct JacobiSync {
     unsigned base;            // flag value before this projection's first hand-off
     int chunks, nb, grid0, ngrids, abort_slot, fault;
     long long timeout_ticks;
+    // FOLD: this step's buoyancy + diffusion stage runs as the launch's prologue: (u_in, v_in, d_in) -> the kernel's u, v (= u2, v2) and d_out
+    const float *u_in, *v_in, *d_in;
+    float *d_out;
 };
 
 template <int VEC>
@@ -379,7 +382,7 @@ __device__ __forceinline__ void stv_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte
     }
 }
 
-template <int VEC, int RPW, int MODE, bool PERSIST = false>
+template <int VEC, int RPW, int MODE, bool PERSIST = false, bool FOLD = false>
 __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float *__restrict__ p_in,
                                                             float *__restrict__ p_out, float *__restrict__ div,
                                                             float *__restrict__ u, float *__restrict__ v,
@@ -418,11 +421,107 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
     const int row0 = r0 + wave * RPW, j0 = lane * VEC;
     const size_t base = b * g.sc + (size_t)row0 * g.pc + j0;
     float pv[RPW][VEC], dv[RPW][VEC];
+    const bool first_col = lane == 0, last_col = lane == 63;
+    if constexpr (FOLD) {
+        // ---- buoyancy + the three diffusions (navier_stokes.py:154-160; per cell the expression trees of k_buoy_diffuse4) for the
+        // tile's rows, each wave for itself from the step's input state: u2 rows row0 .. row0+RPW, v2 / d2 rows row0 .. row0+RPW-1.
+        // Halo rows are computed redundantly by the neighbour bands (no band reads another band's u2 / v2); owned rows are stored
+        // (the advection reads them) and the divergence is formed from the registers.  Rows roll through a 3-row window.
+        const float *ui = sy.u_in + b * g.su, *vi = sy.v_in + b * g.sv, *di = sy.d_in + b * g.sc;
+        float *uo = u + b * g.su, *vo = v + b * g.sv, *dout = sy.d_out + b * g.sc;
+        const int H = g.H, W = g.W;
+        auto rowu = [&](int i, float (&x)[VEC]) {
+            i = i < 0 ? 0 : (i > H ? H : i);
+            ldv<VEC>(x, ui + (size_t)i * g.pc + j0);
+        };
+        auto rowdv = [&](int i, float (&dx)[VEC], float (&vx)[VEC], float &vW) {       // d row; v row with this step's buoyancy; raw v(i, W)
+            i = i < 0 ? 0 : (i > H - 1 ? H - 1 : i);
+            ldv<VEC>(dx, di + (size_t)i * g.pc + j0);
+            ldv<VEC>(vx, vi + (size_t)i * g.pv + j0);
+            vW = vi[(size_t)i * g.pv + W];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const float bb = dx[c] * 0.1f;
+                vx[c] = vx[c] + g.dt * bb;
+            }
+        };
+        auto lap = [&](const float (&cc)[VEC], const float (&up)[VEC], const float (&dn)[VEC], float left, float right, float coef,
+                       float (&o)[VEC]) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                float l = up[c] + dn[c];
+                l = l + (c > 0 ? cc[c - 1] : left);
+                l = l + (c < VEC - 1 ? cc[c + 1] : right);
+                l = l - 4.0f * cc[c];
+                o[c] = cc[c] + coef * l;
+            }
+        };
+        float um[VEC], uc[VEC], un[VEC], dm[VEC], dc[VEC], dn[VEC], vm[VEC], vc[VEC], vn[VEC], vWm, vWc, vWn;
+        rowu(row0 - 1, um);
+        rowu(row0, uc);
+        rowdv(row0 - 1, dm, vm, vWm);
+        rowdv(row0, dc, vc, vWc);
+        float u2prev[VEC], v2keep[VEC + 1];
+#pragma unroll
+        for (int k = 0; k <= RPW; ++k) {
+            const int gi = row0 + k;
+            rowu(gi + 1, un);
+            float u2[VEC];
+            {
+                const float sl = wave_shr1(uc[VEC - 1]), sr = wave_shl1(uc[0]);
+                lap(uc, um, un, first_col ? uc[0] : sl, last_col ? uc[VEC - 1] : sr, g.coef_uv, u2);
+            }
+            if ((gi >= own0 && gi < own1) || (gi == H && band == nb - 1)) stv<VEC>(uo + (size_t)gi * g.pc + j0, u2);
+            if (k > 0) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    float a = u2[c] - u2prev[c];
+                    a = a + v2keep[c + 1];
+                    a = a - v2keep[c];
+                    dv[k - 1][c] = __fdiv_rn(a, g.dt);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) { u2prev[c] = u2[c]; um[c] = uc[c]; uc[c] = un[c]; }
+            if (k < RPW) {
+                rowdv(gi + 1, dn, vn, vWn);
+                float d2[VEC], v2[VEC];
+                {
+                    const float sl = wave_shr1(dc[VEC - 1]), sr = wave_shl1(dc[0]);
+                    lap(dc, dm, dn, first_col ? dc[0] : sl, last_col ? dc[VEC - 1] : sr, g.coef_d, d2);
+                }
+                {
+                    const float sl = wave_shr1(vc[VEC - 1]), sr = wave_shl1(vc[0]);
+                    lap(vc, vm, vn, first_col ? vc[0] : sl, last_col ? vWc : sr, g.coef_uv, v2);
+                }
+                // the field's last column j = W (no buoyancy; right neighbour = itself): meaningful in the last lane only
+                float lw = vWm + vWn;
+                lw = lw + vc[VEC - 1];
+                lw = lw + vWc;
+                lw = lw - 4.0f * vWc;
+                const float v2W = vWc + g.coef_uv * lw;
+                if (gi >= own0 && gi < own1) {
+                    stv<VEC>(dout + (size_t)gi * g.pc + j0, d2);
+                    stv<VEC>(vo + (size_t)gi * g.pv + j0, v2);
+                    if (last_col) vo[(size_t)gi * g.pv + W] = v2W;
+                }
+                const float nx = wave_shl1(v2[0]);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) v2keep[c] = v2[c];
+                v2keep[VEC] = last_col ? v2W : nx;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) { dm[c] = dc[c]; dc[c] = dn[c]; vm[c] = vc[c]; vc[c] = vn[c]; }
+                vWm = vWc; vWc = vWn;
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < RPW; ++k)
 #pragma unroll
         for (int c = 0; c < VEC; ++c) pv[k][c] = p_in[base + (size_t)k * g.pc + c];
-    if (MODE & 1) {
+    if constexpr (FOLD) {
+        // (divergence already in dv)
+    } else if (MODE & 1) {
         const float *ub = u + b * g.su + (size_t)row0 * g.pc + j0, *vb = v + b * g.sv + (size_t)row0 * g.pv + j0;
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
@@ -448,7 +547,6 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
 #pragma unroll
             for (int c = 0; c < VEC; ++c) dv[k][c] = div[base + (size_t)k * g.pc + c];
     }
-    const bool first_col = lane == 0, last_col = lane == 63;
     // ring rows (grid row 0 / H-1) exist only in the first wave of the first band and the last wave of the last band
     const int ring_k = __builtin_amdgcn_readfirstlane(row0 == 0 ? 0 : (row0 + RPW == g.H ? RPW - 1 : -1));   // wave-uniform
     // one sweep src -> dst (register ping-pong: no row copies); par selects the LDS edge buffer
@@ -626,8 +724,9 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
 //   SMK_JACOBI_RPW, SMK_JACOBI_BANDS   pin the band plan of k_jacobi_band   SMK_STENCIL_DEBUG=1    print the chosen plan
 //   SMK_JACOBI_PERSIST=0   one launch per chunk of sweeps instead of the single persistent launch
 //   SMK_JACOBI_FAULT=1     (test only) one band never publishes its hand-off: exercises the bounded wait and the error report
+//   SMK_PROJECT_FOLD=0     buoyancy + diffusion as their own launch in front of the persistent projection
 struct StencilKnobs {
-    bool generic, unfused, debug, persist, fault;
+    bool generic, unfused, debug, persist, fault, fold;
     int rpw, bands;
     StencilKnobs() {
         auto flag = [](const char *n, bool dflt) { const char *v = getenv(n); return v ? v[0] == '1' : dflt; };
@@ -637,6 +736,7 @@ struct StencilKnobs {
         debug = flag("SMK_STENCIL_DEBUG", false);
         persist = flag("SMK_JACOBI_PERSIST", true);
         fault = flag("SMK_JACOBI_FAULT", false);
+        fold = flag("SMK_PROJECT_FOLD", true);
         rpw = num("SMK_JACOBI_RPW");
         bands = num("SMK_JACOBI_BANDS");
     }
@@ -708,16 +808,26 @@ static void launch_band(const Geom &g, const JacobiPlan &pl, const float *pin, f
     }
 }
 
-// the whole projection as one persistent launch per group of co-resident grids
-template <int VEC>
+// the whole projection (FOLD: with the step's buoyancy + diffusion stage as its prologue) as one persistent launch per group of
+// co-resident grids
+template <int VEC, bool FOLD>
 static void launch_persist(const Geom &g, const JacobiPlan &pl, float *p, float *u, float *v, int iters, const JacobiSync &sy, hipStream_t st) {
     dim3 grid(pl.nb * sy.ngrids), block(JB_NW * 64);
     switch (pl.rpw) {
-        case 2: hipLaunchKernelGGL((k_jacobi_band<VEC, 2, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
-        case 3: hipLaunchKernelGGL((k_jacobi_band<VEC, 3, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
-        case 4: hipLaunchKernelGGL((k_jacobi_band<VEC, 4, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
-        case 6: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 6, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
-        case 8: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 8, 3, true>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 2: hipLaunchKernelGGL((k_jacobi_band<VEC, 2, 3, true, FOLD>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 3: hipLaunchKernelGGL((k_jacobi_band<VEC, 3, 3, true, FOLD>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 4: hipLaunchKernelGGL((k_jacobi_band<VEC, 4, 3, true, FOLD>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 6: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 6, 3, true, FOLD>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+        case 8: if constexpr (VEC <= 4) hipLaunchKernelGGL((k_jacobi_band<VEC, 8, 3, true, FOLD>), grid, block, 0, st, g, p, p, nullptr, u, v, iters, pl.br, sy); break;
+    }
+}
+template <bool FOLD>
+static void launch_persist_vec(const Geom &g, const JacobiPlan &pl, float *p, float *u, float *v, int iters, const JacobiSync &sy, hipStream_t st) {
+    switch (pl.vec) {
+        case 1: launch_persist<1, FOLD>(g, pl, p, u, v, iters, sy, st); break;
+        case 2: launch_persist<2, FOLD>(g, pl, p, u, v, iters, sy, st); break;
+        case 4: launch_persist<4, FOLD>(g, pl, p, u, v, iters, sy, st); break;
+        case 8: launch_persist<8, false>(g, pl, p, u, v, iters, sy, st); break;       // (8 cells per lane: the prologue's row windows do not fit)
     }
 }
 
@@ -802,8 +912,10 @@ static bool use_persist(const Geom &g, const ProjectSync *ps, int iters, JacobiP
     return persist_chunks(g, pl, iters, chunks);
 }
 
-hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st, ProjectSync *ps) {
+hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st, ProjectSync *ps,
+                          const StateView *fold_in, float *fold_d_out, bool *folded) {
     JacobiPlan pl;
+    if (folded) *folded = false;
     if (ps && ps->status && *ps->status != 0u && !ps->disabled) {
         // a wait inside an earlier persistent launch timed out (its workgroups were not co-resident within the limit): that projection's
         // result is invalid.  Say so once, loudly, and use the multi-launch form from here on.
@@ -825,15 +937,17 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
         sy.base = ps->seq; sy.chunks = chunks; sy.nb = pl.nb; sy.abort_slot = ps->flags_len - 1; sy.fault = knobs().fault ? 1 : 0;
         sy.timeout_ticks = knobs().fault ? 200000ll : 50000000ll;      // 100 MHz wall clock: 2 ms under fault injection, 0.5 s otherwise
         ps->seq += (unsigned)chunks;
+        // the buoyancy + diffusion stage as this launch's prologue (16-byte row accesses: pitches in multiples of 4; up to 4 cells per lane)
+        const bool fold = fold_in && fold_d_out && knobs().fold && pl.vec <= 4 && g.pv % 4 == 0 && g.pc % 4 == 0;
+        if (fold) {
+            sy.u_in = fold_in->u; sy.v_in = fold_in->v; sy.d_in = fold_in->d; sy.d_out = fold_d_out;
+            if (folded) *folded = true;
+        }
         for (int g0 = 0; g0 < g.B; g0 += per) {
             sy.grid0 = g0;
             sy.ngrids = g.B - g0 < per ? g.B - g0 : per;
-            switch (pl.vec) {
-                case 1: launch_persist<1>(g, pl, p, u, v, iters, sy, st); break;
-                case 2: launch_persist<2>(g, pl, p, u, v, iters, sy, st); break;
-                case 4: launch_persist<4>(g, pl, p, u, v, iters, sy, st); break;
-                case 8: launch_persist<8>(g, pl, p, u, v, iters, sy, st); break;
-            }
+            if (fold) launch_persist_vec<true>(g, pl, p, u, v, iters, sy, st);
+            else launch_persist_vec<false>(g, pl, p, u, v, iters, sy, st);
         }
         return hipGetLastError();
     }
@@ -860,6 +974,25 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
         float *t = cur; cur = nxt; nxt = t;
     }
     return hipGetLastError();                                 // L is even: the result is back in p
+}
+
+// Stages 1-3 of a time step (navier_stokes.py:154-163): buoyancy + diffusion (in -> out.u, out.v, out.d) and the projection of
+// (out.u, out.v) with the pressure p.  One persistent launch where the plan allows, otherwise the two stages as before.
+hipError_t launch_buoy_project(const Geom &g, StateView in, StateView out, float *p, float *div, int iters, hipStream_t st, ProjectSync *ps) {
+    bool folded = false;
+    JacobiPlan pl;
+    int chunks = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    const bool pending_error = ps && ps->status && *ps->status != 0u && !ps->disabled;
+    if (!capturing && !pending_error && use_persist(g, ps, iters, pl, chunks) && knobs().fold && pl.vec <= 4 && g.pv % 4 == 0 && g.pc % 4 == 0) {
+        const hipError_t e = launch_project(g, out.u, out.v, p, out.p, div, iters, st, ps, &in, out.d, &folded);
+        if (e != hipSuccess || folded) return e;
+        return hipErrorUnknown;                               // (unreachable: the conditions above are launch_project's own)
+    }
+    hipError_t e = launch_buoy_diffuse(g, in, out, st);
+    if (e != hipSuccess) return e;
+    return launch_project(g, out.u, out.v, p, out.p, div, iters, st, ps);
 }
 
 // What one projection launches for this geometry, as a JSON object (bench.py reports it as the stencil pass's on-chip bound: the
