@@ -79,7 +79,13 @@ int smk_sim_add_sources(smk_sim *sim, const smk_source *sources, int32_t n, void
  * (smoke_simulator.py:31-39).  After step t (0-based) the emitted frame of grid b is written to
  *     frames + t*frame_stride_t + b*frame_stride_b   as [H][W] contiguous fp32      (frames may be NULL)
  * with frame = density + (fractal_intensity*F)*density when add_fractal != 0 (fractal_generator.py:53-62, F the
- * shape-only constant), else frame = density.  Solver state keeps the unperturbed density. */
+ * shape-only constant), else frame = density.  Solver state keeps the unperturbed density.
+ * Launches per time step: two where the band plan allows (buoyancy + diffusion + the whole pressure projection as one persistent
+ * launch whose workgroups hand halo rows to each other with bounded waits, then the three advections as one launch).  The persistent
+ * launch assumes this process has the device to itself (all its workgroups resident at once): if a wait times out (0.5 s) the
+ * launch still drains, and the NEXT call on this handle returns SMK_ERR_HIP with a message naming the persistent projection -- the
+ * state since that step is invalid (smk_sim_reset), later steps use one launch per chunk of sweeps.  SMK_JACOBI_PERSIST=0 in the
+ * environment selects that form from the start; stream capture always records it. */
 int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t frame_stride_b, int64_t frame_stride_t,
                  int32_t add_fractal, double fractal_intensity, void *stream);
 
