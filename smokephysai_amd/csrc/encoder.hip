@@ -731,6 +731,12 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
         const int r0 = (rem >> lg_tiles_x) * B3_TH, c0 = (rem & ((1 << lg_tiles_x) - 1)) * B3_TW;
 
         __builtin_amdgcn_s_setprio(S16_PRIO_CONV1);
+#ifdef SMK_ENC_ABLATE      // timing ablations (tools/enc_ablate.sh; never a product build): 1 conv1 only on a workgroup's first tile,
+                           // 2 no BN/ReLU/pool epilogue, 4 no workgroup barriers, 8 no conv2 MFMAs -- results are wrong by construction
+        const bool abl_conv1 = !((SMK_ENC_ABLATE & 1) && t != (int)blockIdx.x);
+#else
+        constexpr bool abl_conv1 = true;
+#endif
         // ---- conv1 on MFMA (32x32x16, as k_encoder_bf16): results stored into the swizzled a1 image
         auto x_frags = [&](int pb, bf16x8 (&xh)[4], bf16x8 (&xl)[4], int &pix, bool &valid, bool &inimg) {
             const int pp = pb * 32 + r;
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
                 }
             }
         };
-        {
+        if (abl_conv1) {
             bf16x8 xh[4], xl[4];
             int pix; bool valid, inimg;
             x_frags(wave, xh, xl, pix, valid, inimg);
@@ -796,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
             conv1_store(acc0, 0, pix, valid, inimg);
             conv1_store(acc1, 1, pix, valid, inimg);
         }
-        {
+        if (abl_conv1) {
             bf16x8 xh[4], xl[4];
             int pix; bool valid, inimg;
             const int cb = wave & 1;
@@ -813,7 +819,9 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
             }
             conv1_store(acc, cb, pix, valid, inimg);
         }
+#if !defined(SMK_ENC_ABLATE) || !(SMK_ENC_ABLATE & 4)
         __syncthreads();                                      // a1 complete; xs is free again
+#endif
         __builtin_amdgcn_s_setprio(S16_PRIO_KLOOP);
 
         const int tn = t + gridDim.x;
@@ -893,9 +901,13 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
                             const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[slot][nt][1]);
                             f32x4v &c = acc[4 * hm + m][nt];
                             const bf16x8 ah = (u & 1) ? ahB[m] : ahA[m], al = (u & 1) ? alB[m] : alA[m];
+#if defined(SMK_ENC_ABLATE) && (SMK_ENC_ABLATE & 8)
+                            asm volatile("" :: "v"(al), "v"(ah), "v"(bh), "v"(bl), "v"(c));      // operands stay live, no MFMA
+#else
                             if (pr == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
                             else if (pr == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
                             else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+#endif
                         }
                 // 24 MFMAs of 16 cycles.  The next unit's 8 fragment reads are spread evenly, one after every third MFMA; the ring loads
                 // go right behind the first MFMAs.  (One read per second MFMA in the first 16 -- what hipcc also does unpinned -- is
@@ -914,6 +926,11 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
         auto out_index = [&](int pi, int pj, int o) -> size_t {
             return TOKENS ? ((size_t)b * 1024 + pi * 32 + pj) * 128 + o : ((size_t)b * 128 + o) * 1024 + pi * 32 + pj;
         };
+#if defined(SMK_ENC_ABLATE) && (SMK_ENC_ABLATE & 2)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) asm volatile("" :: "v"(acc[mt][0]), "v"(acc[mt][1]));
+        if (false)
+#endif
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const float s2 = nt ? s2b : s2a, t2 = nt ? t2b : t2a;
@@ -954,7 +971,9 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
 
         xs[tid] = pack_split(xr0);
         if (tid + 256 < B3_XH * B3_XW) xs[tid + 256] = pack_split(xr1);
+#if !defined(SMK_ENC_ABLATE) || !(SMK_ENC_ABLATE & 4)
         __syncthreads();
+#endif
     }
 }
 
