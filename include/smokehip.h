@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 4
+#define SMK_ABI_VERSION 5
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -266,6 +266,17 @@ int smk_bn_relu_pool_forward(const float *z, int32_t B, int32_t C, int32_t H, in
 int smk_bn_relu_pool_backward(const float *z, const float *dout, int32_t B, int32_t C, int32_t H, int32_t W, const float *gamma,
                               const float *beta, const float *mean, const float *rstd, int32_t pool, float *dz, float *dgamma,
                               float *dbeta, void *workspace, void *stream);
+
+/* The encoder's second convolution alone, for training: z2 = Conv2d(64, 128, 3, padding = 1)(a1) + bias under autograd
+ * (smokephys_net.py:28; train.py:88-89 -- train-mode BatchNorm needs the whole convolution output before it can normalise, so the
+ * fused eval encoder does not apply).  a1 [B][64][H][W] and z2 [B][128][H][W] NCHW fp32, weight [128][64][3][3], bias [128] or NULL;
+ * H % 8 == 0, W % 16 == 0.  Split-bf16 on the bf16 matrix cores with fp32 accumulation (the eval encoder's arithmetic: within 1e-5 of
+ * an fp64 convolution).  `workspace`: smk_conv2_train_workspace() bytes of device memory; the split weights are rebuilt from `weight`
+ * in the same call, so an optimizer step needs no other notification.  The two gradients stay with the caller (PyTorch-ROCm's
+ * convolution_backward in models/conv.py).  Enqueued on `stream`. */
+int64_t smk_conv2_train_workspace(void);
+int smk_conv2_train_forward(const float *a1, const float *weight, const float *bias, int32_t B, int32_t H, int32_t W, float *z2,
+                            void *workspace, void *stream);
 
 /* The passes of the two calls above one at a time, for BatchNorm statistics that span several processes: data-parallel training
  * (train.py under DistributedDataParallel) gives every process a shard of the batch, while the reference's BatchNorm2d layers see the

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "smk_attention_backward": [C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_int64] * 7 + [C.c_double, C.c_void_p],
     "smk_lorenz_states": [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     "smk_ffn_elementwise": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p],
+    "smk_conv2_train_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_bn_relu_pool_forward": [C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_double, C.c_int32] + [C.c_void_p] * 6,
     "smk_bn_relu_pool_backward": [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 5,
     "smk_bn_relu_pool_phase": [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 3 +
@@ -97,7 +98,7 @@ _SIGNATURES = {
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
-EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace"] + list(_SIGNATURES)
+EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace", "smk_conv2_train_workspace"] + list(_SIGNATURES)
 
 _lib = None
 
@@ -123,6 +124,8 @@ def load():
         L.smk_bn_train_workspace.restype = C.c_int64
         L.smk_layernorm_bwd_workspace.argtypes = [C.c_int32]
         L.smk_layernorm_bwd_workspace.restype = C.c_int64
+        L.smk_conv2_train_workspace.argtypes = []
+        L.smk_conv2_train_workspace.restype = C.c_int64
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -849,6 +849,18 @@ static int bn_check(int32_t B, int32_t C, int32_t H, int32_t W, int32_t pool) {
     return SMK_OK;
 }
 
+int64_t smk_conv2_train_workspace(void) { return (int64_t)conv2_train_workspace_bytes(); }
+
+int smk_conv2_train_forward(const float *a1, const float *weight, const float *bias, int32_t B, int32_t H, int32_t W, float *z2,
+                            void *workspace, void *stream) {
+    SMK_REQUIRE(a1 && weight && z2 && workspace, "null a1/weight/z2/workspace");
+    if (B < 1 || H < 8 || W < 16 || H % 8 != 0 || W % 16 != 0 || (int64_t)B * 128 * H * W >= (1ll << 40)) {
+        set_error("conv2_train_forward: B >= 1, H a multiple of 8, W a multiple of 16");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return check_launch(launch_conv2_train_forward(a1, weight, bias, B, H, W, z2, workspace, (hipStream_t)stream), "conv2_train_forward");
+}
+
 int64_t smk_bn_train_workspace(int32_t B, int32_t C, int32_t H, int32_t W, int32_t pool) {
     if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
     return bn_train_workspace_floats(B, C, H, W, pool) * (int64_t)sizeof(float);

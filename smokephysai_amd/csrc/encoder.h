@@ -36,4 +36,10 @@ hipError_t launch_encoder_b16(const float *frames, int64_t fstride, int B, int H
 hipError_t launch_encoder_i8(const float *frames, int64_t fstride, int B, int H, int W, const EncoderDev &e,
                              float *features, bool tokens, hipStream_t st);
 
+// Training: z2 = conv2(a1) + bias alone (Conv2d(64, 128, 3, padding = 1); NCHW fp32 in and out; H % 8 == 0, W % 16 == 0); `workspace` holds
+// the split weights (conv2_train_workspace_bytes), rebuilt from `weight` [128][64][3][3] in the same call.
+size_t conv2_train_workspace_bytes();
+hipError_t launch_conv2_train_forward(const float *a1, const float *weight, const float *bias, int B, int H, int W, float *z2, void *workspace,
+                                      hipStream_t st);
+
 }  // namespace smk

@@ -1,0 +1,46 @@
+"""Host side of libsmokehip's training convolution (smk_conv2_train_forward): SmokePhysNet.input_encoder's second convolution
+(smokephys_net.py:28, Conv2d(64, 128, 3, padding=1)) under autograd.  The forward runs on the split-bf16 MFMA kernel
+(csrc/encoder.hip: k_conv2_fwd_b16); both gradients are PyTorch-ROCm's convolution_backward on the saved input and weight."""
+import torch
+from torch import nn
+
+from .. import _lib
+
+
+def hip_conv2_train_supported(x: torch.Tensor, conv: nn.Conv2d) -> bool:
+    return (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and conv.in_channels == 64 and conv.out_channels == 128
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and x.shape[1] == 64 and x.shape[2] % 8 == 0 and x.shape[3] % 16 == 0)
+
+
+class _HipConv2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        dev = _lib.require_cuda(x.device, "hip_conv2_train")
+        L = _lib.load()
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        z = torch.empty(B, 128, H, W, device=dev, dtype=torch.float32)
+        ws = torch.empty(int(L.smk_conv2_train_workspace()), device=dev, dtype=torch.uint8)
+        w = weight.detach().contiguous()
+        b = None if bias is None else bias.detach().contiguous()
+        _lib.check(L.smk_conv2_train_forward(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), B, H, W, z.data_ptr(),
+                                             ws.data_ptr(), _lib.stream_ptr(dev)))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight = ctx.saved_tensors
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
+        dx, dw, db = torch.ops.aten.convolution_backward(dz.contiguous(), x, weight, [128] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1],
+                                                         False, [0, 0], 1, mask)
+        return dx, dw, db
+
+
+def hip_conv2_train(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    """conv(x) for the encoder's 64 -> 128 3x3 convolution with the forward on libsmokehip (raises off a ROCm device: no CPU fallback)."""
+    if not hip_conv2_train_supported(x, conv):
+        raise ValueError("hip_conv2_train: a float32 ROCm tensor [B, 64, H, W] with H % 8 == 0, W % 16 == 0 and Conv2d(64, 128, 3, padding=1)")
+    return _HipConv2Fn.apply(x, conv.weight, conv.bias)

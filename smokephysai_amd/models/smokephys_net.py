@@ -11,6 +11,7 @@ token mean are PyTorch-ROCm ops.
 Training (train mode): the encoder runs as autograd-tracked PyTorch ops with batch-statistics BatchNorm, exactly the
 reference's op sequence (smokephys_net.py:87-91).
 """
+import os
 import warnings
 from typing import Optional
 
@@ -25,6 +26,7 @@ from .encoder import HipEncoder, encoder_weight_dict
 from .hip_body import HipBody
 from .ffn import hip_dropout_add, hip_ffn_elementwise_supported, hip_gelu_dropout
 from .linear import TrainableHipLinear, hip_linear_supported
+from .conv import hip_conv2_train, hip_conv2_train_supported
 from .norm import hip_bn_relu_pool, hip_sync_bn_relu_pool
 from .sync_bn import SyncBatchNorm2d
 from .physics_regularizer import PhysicsRegularizer
@@ -59,6 +61,9 @@ def _hip_bn_ok(bn) -> bool:
     track_running_stats=False, affine=False -- runs the PyTorch modules."""
     return (type(bn) in (nn.BatchNorm2d, SyncBatchNorm2d) and bn.training and bn.affine and bn.track_running_stats
             and bn.momentum is not None)
+
+
+_HIP_CONV2_TRAIN = os.environ.get("SMK_TRAIN_CONV2_HIP", "1") != "0"      # diagnostic: 0 keeps conv2's training forward on MIOpen
 
 
 def _bn_relu_pool(z, bn, pool):
@@ -171,7 +176,8 @@ class SmokePhysNet(nn.Module):
                 # libsmokehip: BatchNorm (batch statistics) + ReLU as two passes over the conv output, and for the second block
                 # the two average pools (one P x P block mean) in the same pass -- the 256 x 256 x 128 maps are never written
                 a1 = _bn_relu_pool(conv1(x), bn1, 1)
-                return _bn_relu_pool(conv2(a1), bn2, P)
+                z2 = hip_conv2_train(a1, conv2) if (_HIP_CONV2_TRAIN and hip_conv2_train_supported(a1, conv2)) else conv2(a1)
+                return _bn_relu_pool(z2, bn2, P)
             encoded = x
             for m in self.input_encoder:
                 encoded = _avg_pool_to(encoded, m.output_size) if isinstance(m, nn.AdaptiveAvgPool2d) else m(encoded)

@@ -286,3 +286,33 @@ def test_sync_bn_relu_pool_phases_equal_the_fused_call_and_full_batch_statistics
     assert float((torch.cat(dzs) - gz_ref).abs().max()) <= 2e-5 * scale
     assert torch.allclose(tot[0], gw_ref, rtol=1e-4, atol=1e-4 * float(gw_ref.abs().max()))
     assert torch.allclose(tot[1], gb_ref, rtol=1e-4, atol=1e-4 * float(gb_ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 40, 48), (1, 8, 16), (4, 256, 256)])
+def test_training_conv2_forward_vs_fp64_and_gradients_vs_autograd(shape):
+    """smk_conv2_train_forward (k_conv2_fwd_b16): input_encoder's Conv2d(64, 128, 3, padding=1) under autograd (smokephys_net.py:28):
+    the forward within 1e-5 (max-norm) of an fp64 convolution, incl. frames that are not square, one tile only, and borders on every
+    side; both gradients equal PyTorch-ROCm's own (the backward IS its convolution_backward on the saved tensors)."""
+    from smokephysai_amd.models.conv import hip_conv2_train, hip_conv2_train_supported
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H)
+    conv = torch.nn.Conv2d(64, 128, 3, padding=1).cuda()
+    x = torch.rand(B, 64, H, W, device="cuda", generator=g) * 2.0 - 0.3
+    x = torch.relu(x)                                           # what the first block hands over: non-negative with exact zeros
+    assert hip_conv2_train_supported(x, conv)
+    xa = x.clone().requires_grad_(True)
+    z = hip_conv2_train(xa, conv)
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    err = float((z.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    dz = torch.randn(z.shape, device="cuda", generator=g)
+    z.backward(dz)
+    gw, gb, gx = conv.weight.grad.clone(), conv.bias.grad.clone(), xa.grad.clone()
+    conv.zero_grad()
+    xb = x.clone().requires_grad_(True)
+    conv(xb).backward(dz)
+    for a, b_, name in ((gw, conv.weight.grad, "dW"), (gb, conv.bias.grad, "db"), (gx, xb.grad, "dX")):
+        assert float((a - b_).abs().max()) <= 1e-6 * float(b_.abs().max()) + 1e-12, name
+    # shapes the kernel is not built for are refused, not silently rerouted
+    with pytest.raises(ValueError):
+        hip_conv2_train(torch.zeros(1, 64, 12, 16, device="cuda"), conv)
