@@ -272,11 +272,15 @@ int smk_bn_relu_pool_backward(const float *z, const float *dout, int32_t B, int3
  * fused eval encoder does not apply).  a1 [B][64][H][W] and z2 [B][128][H][W] NCHW fp32, weight [128][64][3][3], bias [128] or NULL;
  * H % 8 == 0, W % 16 == 0.  Split-bf16 on the bf16 matrix cores with fp32 accumulation (the eval encoder's arithmetic: within 1e-5 of
  * an fp64 convolution).  `workspace`: smk_conv2_train_workspace() bytes of device memory; the split weights are rebuilt from `weight`
- * in the same call, so an optimizer step needs no other notification.  The two gradients stay with the caller (PyTorch-ROCm's
- * convolution_backward in models/conv.py).  Enqueued on `stream`. */
+ * in the same call, so an optimizer step needs no other notification.  The weight / bias gradients stay with the caller (PyTorch-ROCm's
+ * convolution_backward in models/conv.py); the data gradient is smk_conv2_train_dgrad.  Enqueued on `stream`. */
 int64_t smk_conv2_train_workspace(void);
 int smk_conv2_train_forward(const float *a1, const float *weight, const float *bias, int32_t B, int32_t H, int32_t W, float *z2,
                             void *workspace, void *stream);
+/* dX [B][64][H][W] = the data gradient of that convolution from dz [B][128][H][W] (the 3x3 convolution 128 -> 64 with the flipped
+ * kernel), same arithmetic and shape rules; `workspace` as above (its own contents: do not share one buffer between a forward and a
+ * data-gradient call that may overlap).  The weight / bias gradients stay PyTorch-ROCm's. */
+int smk_conv2_train_dgrad(const float *dz, const float *weight, int32_t B, int32_t H, int32_t W, float *dx, void *workspace, void *stream);
 
 /* The passes of the two calls above one at a time, for BatchNorm statistics that span several processes: data-parallel training
  * (train.py under DistributedDataParallel) gives every process a shard of the batch, while the reference's BatchNorm2d layers see the

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "smk_lorenz_states": [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     "smk_ffn_elementwise": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p],
     "smk_conv2_train_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "smk_conv2_train_dgrad": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_bn_relu_pool_forward": [C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_double, C.c_int32] + [C.c_void_p] * 6,
     "smk_bn_relu_pool_backward": [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 5,
     "smk_bn_relu_pool_phase": [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 3 +

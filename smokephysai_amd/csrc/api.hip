@@ -861,6 +861,15 @@ int smk_conv2_train_forward(const float *a1, const float *weight, const float *b
     return check_launch(launch_conv2_train_forward(a1, weight, bias, B, H, W, z2, workspace, (hipStream_t)stream), "conv2_train_forward");
 }
 
+int smk_conv2_train_dgrad(const float *dz, const float *weight, int32_t B, int32_t H, int32_t W, float *dx, void *workspace, void *stream) {
+    SMK_REQUIRE(dz && weight && dx && workspace, "null dz/weight/dx/workspace");
+    if (B < 1 || H < 8 || W < 16 || H % 8 != 0 || W % 16 != 0 || (int64_t)B * 128 * H * W >= (1ll << 40)) {
+        set_error("conv2_train_dgrad: B >= 1, H a multiple of 8, W a multiple of 16");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return check_launch(launch_conv2_train_dgrad(dz, weight, B, H, W, dx, workspace, (hipStream_t)stream), "conv2_train_dgrad");
+}
+
 int64_t smk_bn_train_workspace(int32_t B, int32_t C, int32_t H, int32_t W, int32_t pool) {
     if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
     return bn_train_workspace_floats(B, C, H, W, pool) * (int64_t)sizeof(float);

@@ -39,6 +39,8 @@ hipError_t launch_encoder_i8(const float *frames, int64_t fstride, int B, int H,
 // Training: z2 = conv2(a1) + bias alone (Conv2d(64, 128, 3, padding = 1); NCHW fp32 in and out; H % 8 == 0, W % 16 == 0); `workspace` holds
 // the split weights (conv2_train_workspace_bytes), rebuilt from `weight` [128][64][3][3] in the same call.
 size_t conv2_train_workspace_bytes();
+// dX = the data gradient of the same convolution from dz [B][128][H][W] (same workspace size, its own contents)
+hipError_t launch_conv2_train_dgrad(const float *dz, const float *weight, int B, int H, int W, float *dx, void *workspace, hipStream_t st);
 hipError_t launch_conv2_train_forward(const float *a1, const float *weight, const float *bias, int B, int H, int W, float *z2, void *workspace,
                                       hipStream_t st);
 

@@ -1160,6 +1160,202 @@ __global__ __launch_bounds__(256, 2) void k_conv2_fwd_b16(const float *__restric
     }
 }
 
+// k_conv2_dgrad_b16: the data gradient of the same convolution, dX[b][c] = sum over o, taps of dZ[b][o][y + ky' - 1][x + kx' - 1] * W[o][c][2 - ky'][2 - kx']
+// -- a 3x3 convolution from 128 channels to 64 with the flipped kernel.  Same tile, halo image and swizzle; the 128 input channels
+// go through the 64-channel LDS image as two passes (stage half, 18 k-steps, stage the other half, 18 more) into the same accumulators.
+// With only 64 outputs the waves split the tile's rows as well as the channels: wave = (4 M-tiles, 2 N-tiles), so every unit of 24
+// MFMAs is a k-step of its own (8 A-fragment reads as in the forward, 4 weight-fragment loads: twice the forward's weight stream).
+// w2d: [pass 2][k-step 18 = tap' * 2 + o_local / 32][hi|lo][c 64][32 o]: 4 KiB per (k-step, part).
+__global__ __launch_bounds__(256, 2) void k_conv2_dgrad_b16(const float *__restrict__ dz, int H, int W, const unsigned short *__restrict__ w2d,
+                                                         float *__restrict__ dx, int tiles_x, int tiles_per_frame, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *a1h = smem, *a1l = a1h + S16_A1_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, kg = lane >> 4;
+    const int mh = wave & 1, nh = wave >> 1;
+    const int c0o = nh * 32 + px;                                             // output channel of N tile 0; tile 1 = + 16
+    const int lane_b = c0o * 64 + kg * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w2d), 0, 2 * 18 * 2 * 4096, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto load_b = [&](int ks36, int part, int nt) -> uint4 {                  // ks36 = pass * 18 + k-step
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (ks36 * 2 + part) * 4096 + nt * 1024, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    uint4 bq[2][2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        bq[0][nt][0] = load_b(0, 0, nt);
+        bq[0][nt][1] = load_b(0, 1, nt);
+    }
+    const size_t plane = (size_t)H * W;
+    constexpr int ITEMS = (B3_TH + 2) * 8 * B3_AW, NIT = (ITEMS + 255) / 256;
+    const unsigned char *a1h_w = a1h + mh * 4 * (B3_AW * 128), *a1l_w = a1l + mh * 4 * (B3_AW * 128);
+    const int c16[2] = {kg << 4, (4 + kg) << 4};
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / tiles_per_frame, rem = t - b * tiles_per_frame;
+        const int r0 = (rem / tiles_x) * B3_TH, c0 = (rem % tiles_x) * B3_TW;
+        f32x4v acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[m][nt][g] = 0.f;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            __builtin_amdgcn_s_setprio(S16_PRIO_CONV1);
+            {   // stage the halo tile of dZ's channels 64 pass .. 64 pass + 63 (as k_conv2_fwd_b16 stages a1)
+                const float *ab = dz + ((size_t)b * 128 + 64 * pass) * plane;
+                float v[NIT][8];
+#pragma unroll
+                for (int j = 0; j < NIT; ++j) {
+                    int idx = tid + 256 * j;
+                    idx = idx < ITEMS ? idx : ITEMS - 1;
+                    const int row = idx / (8 * B3_AW), rm = idx - row * (8 * B3_AW), g = rm / B3_AW, pc = rm - g * B3_AW;
+                    const int ii = r0 - 1 + row, jj = c0 - 1 + pc;
+                    const int ci = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii), cj = jj < 0 ? 0 : (jj > W - 1 ? W - 1 : jj);
+                    const float *src = ab + (size_t)(8 * g) * plane + (size_t)ci * W + cj;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[j][c] = src[(size_t)c * plane];
+                }
+#pragma unroll
+                for (int j = 0; j < NIT; ++j) {
+                    const int idx = tid + 256 * j;
+                    if (idx < ITEMS) {
+                        const int row = idx / (8 * B3_AW), rm = idx - row * (8 * B3_AW), g = rm / B3_AW, pc = rm - g * B3_AW;
+                        const int ii = r0 - 1 + row, jj = c0 - 1 + pc;
+                        const bool in = ii >= 0 && ii < H && jj >= 0 && jj < W;
+                        const int p = row * B3_AW + pc;
+                        bf16x8 vh, vl;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            __bf16 hh, ll;
+                            split_bf16(in ? v[j][c] : 0.f, hh, ll);
+                            vh[c] = hh; vl[c] = ll;
+                        }
+                        const int off = p * 128 + ((g ^ (p & 7)) * 16);
+                        *reinterpret_cast<bf16x8 *>(a1h + off) = vh;
+                        *reinterpret_cast<bf16x8 *>(a1l + off) = vl;
+                    }
+                }
+            }
+            __syncthreads();                                  // the image is complete
+            __builtin_amdgcn_s_setprio(S16_PRIO_KLOOP);
+            auto tap_consts = [&](int ki, int kj, int (&om)[4]) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) om[m] = ((px + kj) << 7) ^ (((px + kj + 2 * (m + ki)) & 7) << 4);
+            };
+            auto load_a = [&](int ki, int half, const int (&om)[4], bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
+                const unsigned char *ph = a1h_w + ki * (B3_AW * 128), *pl = a1l_w + ki * (B3_AW * 128);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int off = om[m] ^ c16[half];
+                    ah[m] = *reinterpret_cast<const bf16x8 *>(ph + off + m * (B3_AW * 128));
+                    al[m] = *reinterpret_cast<const bf16x8 *>(pl + off + m * (B3_AW * 128));
+                }
+            };
+            bf16x8 ahA[4], alA[4], ahB[4], alB[4];
+            int om[4];
+            tap_consts(0, 0, om);
+            load_a(0, 0, om, ahA, alA);
+            int ki = 0, kj = 0;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int slot = half;
+                    {   // refill the other slot with the next k-step (the ring runs through both passes and on into the next tile)
+                        int kn = pass * 18 + tap * 2 + half + 1;
+                        kn = kn >= 36 ? kn - 36 : kn;
+                        kn = __builtin_amdgcn_readfirstlane(kn);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            bq[slot ^ 1][nt][0] = load_b(kn, 0, nt);
+                            bq[slot ^ 1][nt][1] = load_b(kn, 1, nt);
+                        }
+                    }
+                    if (half == 0) {
+                        load_a(ki, 1, om, ahB, alB);
+                    } else if (tap < 8) {
+                        kj = kj == 2 ? 0 : kj + 1;
+                        ki = kj == 0 ? ki + 1 : ki;
+                        tap_consts(ki, kj, om);
+                        load_a(ki, 0, om, ahA, alA);
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt) {
+                                const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[slot][nt][0]);
+                                const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[slot][nt][1]);
+                                f32x4v &c = acc[m][nt];
+                                const bf16x8 ah = half ? ahB[m] : ahA[m], al = half ? alB[m] : alA[m];
+                                if (pr == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+                                else if (pr == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+                                else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                            }
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        else if (i == 1 || i == 2 || i == 4 || i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();                                  // every wave is done reading the image
+        }
+        // ---- epilogue: dX rows 4 mh + m, columns 4kg .. 4kg+3 of channel c0o (+ 16): 16-byte stores
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float *dst = dx + ((size_t)b * 64 + c0o + 16 * nt) * plane + (size_t)(r0 + 4 * mh) * W + c0 + 4 * kg;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4v c = acc[m][nt];
+                *reinterpret_cast<float4 *>(dst + (size_t)m * W) = make_float4(c[0], c[1], c[2], c[3]);
+            }
+        }
+    }
+}
+
+// w [128 o][64 c][3][3] -> w2d [pass = o / 64][k-step = tap' * 2 + (o % 64) / 32][hi|lo][c 64][32 o], tap' = the flipped tap (2 - ky, 2 - kx)
+__global__ void k_split_conv2_weights_dgrad(const float *__restrict__ w, unsigned short *__restrict__ w2d_) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 9 * 64 * 128) return;
+    const int o = t % 128, c = (t / 128) % 64, tap = t / (64 * 128);
+    const float v = w[((size_t)o * 64 + c) * 9 + tap];
+    const int ky = tap / 3, kx = tap - 3 * ky, tapf = (2 - ky) * 3 + (2 - kx);
+    __bf16 *w2d = reinterpret_cast<__bf16 *>(w2d_);
+    const __bf16 hi = (__bf16)v;
+    const int pass = o >> 6, ol = o & 63, ks = tapf * 2 + (ol >> 5), o32 = ol & 31;
+    const size_t base = ((size_t)(pass * 18 + ks) * 2) * 64 * 32;
+    w2d[base + (size_t)c * 32 + o32] = hi;
+    w2d[base + (size_t)64 * 32 + (size_t)c * 32 + o32] = (__bf16)(v - (float)hi);
+}
+
+hipError_t launch_conv2_train_dgrad(const float *dz, const float *weight, int B, int H, int W, float *dx, void *workspace, hipStream_t st) {
+    if (H % B3_TH != 0 || W % B3_TW != 0 || B < 1) return hipErrorInvalidValue;
+    unsigned short *w2d = static_cast<unsigned short *>(workspace);
+    hipLaunchKernelGGL(k_split_conv2_weights_dgrad, dim3(cdiv(9 * 64 * 128, 256)), dim3(256), 0, st, weight, w2d);
+    const int tiles_x = W / B3_TW, tiles_per_frame = tiles_x * (H / B3_TH), ntiles = B * tiles_per_frame;
+    constexpr int lds = 2 * S16_A1_BYTES;
+    const int wgs_per_cu = device_cached_int((const void *)k_conv2_dgrad_b16, [] {
+        (void)hipFuncSetAttribute((const void *)k_conv2_dgrad_b16, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_conv2_dgrad_b16, 256, lds) != hipSuccess || n < 1) n = 2;
+        return n;
+    });
+    int nwg = device_num_cu() * wgs_per_cu;
+    if (nwg > ntiles) nwg = ntiles;
+    hipLaunchKernelGGL(k_conv2_dgrad_b16, dim3(nwg), dim3(256), lds, st, dz, H, W, w2d, dx, tiles_x, tiles_per_frame, ntiles);
+    return hipGetLastError();
+}
+
 // w [128 o][64 c][3][3] -> w2s [k-step = tap*2 + c/32][hi|lo][o][32 c] (the B fragments of the 16x16x32 tap loop)
 __global__ void k_split_conv2_weights(const float *__restrict__ w, unsigned short *__restrict__ w2s_) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,6 +1,7 @@
 """Host side of libsmokehip's training convolution (smk_conv2_train_forward): SmokePhysNet.input_encoder's second convolution
 (smokephys_net.py:28, Conv2d(64, 128, 3, padding=1)) under autograd.  The forward runs on the split-bf16 MFMA kernel
-(csrc/encoder.hip: k_conv2_fwd_b16); both gradients are PyTorch-ROCm's convolution_backward on the saved input and weight."""
+(csrc/encoder.hip: k_conv2_fwd_b16) and so does the data gradient (k_conv2_dgrad_b16); the weight / bias gradients are PyTorch-ROCm's
+convolution_backward on the saved input."""
 import torch
 from torch import nn
 
@@ -33,9 +34,20 @@ class _HipConv2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         x, weight = ctx.saved_tensors
-        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
-        dx, dw, db = torch.ops.aten.convolution_backward(dz.contiguous(), x, weight, [128] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1],
-                                                         False, [0, 0], 1, mask)
+        dz = dz.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:                         # the data gradient on libsmokehip (k_conv2_dgrad_b16)
+            L = _lib.load()
+            B, _, H, W = x.shape
+            dx = torch.empty_like(x)
+            ws = torch.empty(int(L.smk_conv2_train_workspace()), device=x.device, dtype=torch.uint8)
+            _lib.check(L.smk_conv2_train_dgrad(dz.data_ptr(), weight.detach().contiguous().data_ptr(), B, H, W, dx.data_ptr(), ws.data_ptr(),
+                                               _lib.stream_ptr(x.device)))
+        mask = [False, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
+        dw = db = None
+        if mask[1] or mask[2]:                              # weight / bias gradients: PyTorch-ROCm
+            _, dw, db = torch.ops.aten.convolution_backward(dz, x, weight, [128] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1],
+                                                            False, [0, 0], 1, mask)
         return dx, dw, db
 
 

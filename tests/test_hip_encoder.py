@@ -292,7 +292,8 @@ def test_sync_bn_relu_pool_phases_equal_the_fused_call_and_full_batch_statistics
 def test_training_conv2_forward_vs_fp64_and_gradients_vs_autograd(shape):
     """smk_conv2_train_forward (k_conv2_fwd_b16): input_encoder's Conv2d(64, 128, 3, padding=1) under autograd (smokephys_net.py:28):
     the forward within 1e-5 (max-norm) of an fp64 convolution, incl. frames that are not square, one tile only, and borders on every
-    side; both gradients equal PyTorch-ROCm's own (the backward IS its convolution_backward on the saved tensors)."""
+    side; the data gradient (smk_conv2_train_dgrad, k_conv2_dgrad_b16) within 1e-5 of fp64 autograd; the weight / bias gradients equal
+    PyTorch-ROCm's own (they ARE its convolution_backward on the saved tensors)."""
     from smokephysai_amd.models.conv import hip_conv2_train, hip_conv2_train_supported
     B, H, W = shape
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + H)
@@ -311,8 +312,14 @@ def test_training_conv2_forward_vs_fp64_and_gradients_vs_autograd(shape):
     conv.zero_grad()
     xb = x.clone().requires_grad_(True)
     conv(xb).backward(dz)
-    for a, b_, name in ((gw, conv.weight.grad, "dW"), (gb, conv.bias.grad, "db"), (gx, xb.grad, "dX")):
+    for a, b_, name in ((gw, conv.weight.grad, "dW"), (gb, conv.bias.grad, "db")):       # PyTorch-ROCm's own convolution_backward
         assert float((a - b_).abs().max()) <= 1e-6 * float(b_.abs().max()) + 1e-12, name
+    # the data gradient is k_conv2_dgrad_b16's: against fp64 autograd
+    xd = x.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xd, conv.weight.double(), conv.bias.double(), padding=1).backward(dz.double())
+    errx = float((gx.double() - xd.grad).abs().max() / xd.grad.abs().max())
+    assert errx < 1e-5, errx
+    assert float((gx - xb.grad).abs().max() / xb.grad.abs().max()) < 1e-4      # and next to PyTorch-ROCm's fp32 one
     # shapes the kernel is not built for are refused, not silently rerouted
     with pytest.raises(ValueError):
         hip_conv2_train(torch.zeros(1, 64, 12, 16, device="cuda"), conv)
