@@ -1,7 +1,7 @@
 """Host side of libsmokehip's training convolution (smk_conv2_train_forward): SmokePhysNet.input_encoder's second convolution
-(smokephys_net.py:28, Conv2d(64, 128, 3, padding=1)) under autograd.  The forward runs on the split-bf16 MFMA kernel
-(csrc/encoder.hip: k_conv2_fwd_b16) and so does the data gradient (k_conv2_dgrad_b16); the weight / bias gradients are PyTorch-ROCm's
-convolution_backward on the saved input."""
+(smokephys_net.py:28, Conv2d(64, 128, 3, padding=1)) under autograd.  The data gradient runs on the split-bf16 MFMA kernel
+(csrc/encoder.hip: k_conv2_dgrad_b16), the forward optionally (k_conv2_fwd_b16; default PyTorch-ROCm, see hip_conv2_train); the weight /
+bias gradients are PyTorch-ROCm's convolution_backward on the saved input."""
 import torch
 from torch import nn
 
@@ -16,17 +16,20 @@ def hip_conv2_train_supported(x: torch.Tensor, conv: nn.Conv2d) -> bool:
 
 class _HipConv2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, hip_forward):
         dev = _lib.require_cuda(x.device, "hip_conv2_train")
         L = _lib.load()
         x = x.contiguous()
         B, _, H, W = x.shape
-        z = torch.empty(B, 128, H, W, device=dev, dtype=torch.float32)
-        ws = torch.empty(int(L.smk_conv2_train_workspace()), device=dev, dtype=torch.uint8)
-        w = weight.detach().contiguous()
-        b = None if bias is None else bias.detach().contiguous()
-        _lib.check(L.smk_conv2_train_forward(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), B, H, W, z.data_ptr(),
-                                             ws.data_ptr(), _lib.stream_ptr(dev)))
+        if hip_forward:
+            z = torch.empty(B, 128, H, W, device=dev, dtype=torch.float32)
+            ws = torch.empty(int(L.smk_conv2_train_workspace()), device=dev, dtype=torch.uint8)
+            w = weight.detach().contiguous()
+            b = None if bias is None else bias.detach().contiguous()
+            _lib.check(L.smk_conv2_train_forward(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), B, H, W, z.data_ptr(),
+                                                 ws.data_ptr(), _lib.stream_ptr(dev)))
+        else:                                               # PyTorch-ROCm's fp32 convolution (see hip_conv2_train)
+            z = torch.ops.aten.convolution(x, weight.detach(), None if bias is None else bias.detach(), [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return z
@@ -48,11 +51,17 @@ class _HipConv2Fn(torch.autograd.Function):
         if mask[1] or mask[2]:                              # weight / bias gradients: PyTorch-ROCm
             _, dw, db = torch.ops.aten.convolution_backward(dz, x, weight, [128] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1],
                                                             False, [0, 0], 1, mask)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def hip_conv2_train(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
-    """conv(x) for the encoder's 64 -> 128 3x3 convolution with the forward on libsmokehip (raises off a ROCm device: no CPU fallback)."""
+def hip_conv2_train(x: torch.Tensor, conv: nn.Conv2d, hip_forward: bool = False) -> torch.Tensor:
+    """conv(x) for the encoder's 64 -> 128 3x3 convolution under autograd with the DATA GRADIENT on libsmokehip (k_conv2_dgrad_b16) and,
+    with hip_forward=True, the forward too (k_conv2_fwd_b16).  Raises off a ROCm device: no CPU fallback.
+
+    Why the forward is opt-in: the split-bf16 forward is 5e-6 (max-norm) from an fp64 convolution, MIOpen's fp32 one 4e-7, and in this
+    network the convolution feeds train-mode BatchNorm + ReLU: in fp64, noise of relative size 5e-7 / 5e-6 on its output moves
+    conv2.weight.grad by 4e-3 / 1.7e-2 (ReLU masks flip) -- the faster forward would leave the band PyTorch's own fp32 gradients stay in
+    (tests/test_hip_pipeline.py).  The data gradient has no such amplifier: its 5e-6 propagates linearly."""
     if not hip_conv2_train_supported(x, conv):
         raise ValueError("hip_conv2_train: a float32 ROCm tensor [B, 64, H, W] with H % 8 == 0, W % 16 == 0 and Conv2d(64, 128, 3, padding=1)")
-    return _HipConv2Fn.apply(x, conv.weight, conv.bias)
+    return _HipConv2Fn.apply(x, conv.weight, conv.bias, bool(hip_forward))

@@ -63,7 +63,9 @@ def _hip_bn_ok(bn) -> bool:
             and bn.momentum is not None)
 
 
-_HIP_CONV2_TRAIN = os.environ.get("SMK_TRAIN_CONV2_HIP", "1") != "0"      # diagnostic: 0 keeps conv2's training forward on MIOpen
+# SMK_TRAIN_CONV2_HIP: "1" (default) conv2's data gradient on libsmokehip; "fwd" its forward too (faster, 5e-6 instead of 4e-7 from fp64:
+# models/conv.py says what that does to the gradients); "0" the whole convolution on PyTorch-ROCm
+_HIP_CONV2_TRAIN = os.environ.get("SMK_TRAIN_CONV2_HIP", "1")
 
 
 def _bn_relu_pool(z, bn, pool):
@@ -176,7 +178,8 @@ class SmokePhysNet(nn.Module):
                 # libsmokehip: BatchNorm (batch statistics) + ReLU as two passes over the conv output, and for the second block
                 # the two average pools (one P x P block mean) in the same pass -- the 256 x 256 x 128 maps are never written
                 a1 = _bn_relu_pool(conv1(x), bn1, 1)
-                z2 = hip_conv2_train(a1, conv2) if (_HIP_CONV2_TRAIN and hip_conv2_train_supported(a1, conv2)) else conv2(a1)
+                z2 = (hip_conv2_train(a1, conv2, hip_forward=_HIP_CONV2_TRAIN == "fwd")
+                      if (_HIP_CONV2_TRAIN != "0" and hip_conv2_train_supported(a1, conv2)) else conv2(a1))
                 return _bn_relu_pool(z2, bn2, P)
             encoded = x
             for m in self.input_encoder:

@@ -193,8 +193,9 @@ def test_bn_relu_pool_training_kernels_match_fp64_autograd(B, C, H, pool):
 
 
 def test_training_encoder_path_on_hip_norm_blocks_matches_the_pytorch_path():
-    """SmokePhysNet.encode_frames in train mode at 128^2: conv (MIOpen) + libsmokehip BatchNorm/ReLU/pool against the all-PyTorch
-    module path (linear_dtype='f32' disables the HIP route): features, input-encoder gradients, running statistics."""
+    """SmokePhysNet.encode_frames in train mode at 128^2: conv1 (MIOpen) + libsmokehip BatchNorm/ReLU/pool + conv2 forward / data
+    gradient on libsmokehip against the all-PyTorch module path (linear_dtype='f32' disables the HIP route): features, input-encoder
+    gradients (both against fp64), running statistics."""
     import copy
     from smokephysai_amd.models import SmokePhysNet
     torch.manual_seed(2)
@@ -212,10 +213,16 @@ def test_training_encoder_path_on_hip_norm_blocks_matches_the_pytorch_path():
     def err(a, b):
         return rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy())
     assert err(fh, fr) < 1e-5
-    scale = max(float(q.grad.abs().max()) for q in ref.input_encoder.parameters())
-    for (n, p), (_, q) in zip(hip.input_encoder.named_parameters(), ref.input_encoder.named_parameters()):
-        if float(q.grad.abs().max()) > 1e-3 * scale:
-            assert err(p.grad, q.grad) < 1e-2, n      # two fp32 pipelines through MIOpen's conv weight-gradient kernels: 1e-3 .. 3e-3 apart
+    # gradients: this loss is ill-conditioned in fp32 (ReLU masks and batch statistics downstream of two convolutions: PyTorch-ROCm's own
+    # fp32 path sits 1e-3 .. 1e-2 from fp64), so both fp32 routes are measured against the fp64 module path, not against each other
+    r64 = copy.deepcopy(ref).double()
+    r64.encode_frames(x.double()).backward(g.double())
+    scale = max(float(q.grad.abs().max()) for q in r64.input_encoder.parameters())
+    for (n, p), (_, q), (_, q64) in zip(hip.input_encoder.named_parameters(), ref.input_encoder.named_parameters(),
+                                        r64.input_encoder.named_parameters()):
+        if float(q64.grad.abs().max()) > 1e-3 * scale:
+            e_hip, e_ref = err(p.grad.double(), q64.grad), err(q.grad.double(), q64.grad)
+            assert e_hip < max(3.0 * e_ref, 5e-3), (n, e_hip, e_ref)
         else:                                                               # conv biases in front of a BatchNorm: gradient 0 (rounding noise)
             assert float(p.grad.abs().max()) < 1e-3 * scale, n
     for k in ("1.running_mean", "1.running_var", "4.running_mean", "4.running_var"):
@@ -302,7 +309,7 @@ def test_training_conv2_forward_vs_fp64_and_gradients_vs_autograd(shape):
     x = torch.relu(x)                                           # what the first block hands over: non-negative with exact zeros
     assert hip_conv2_train_supported(x, conv)
     xa = x.clone().requires_grad_(True)
-    z = hip_conv2_train(xa, conv)
+    z = hip_conv2_train(xa, conv, hip_forward=True)
     ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
     err = float((z.double() - ref).abs().max() / ref.abs().max())
     assert err < 1e-5, err
