@@ -279,8 +279,13 @@ int smk_conv2_train_forward(const float *a1, const float *weight, const float *b
                             void *workspace, void *stream);
 /* dX [B][64][H][W] = the data gradient of that convolution from dz [B][128][H][W] (the 3x3 convolution 128 -> 64 with the flipped
  * kernel), same arithmetic and shape rules; `workspace` as above (its own contents: do not share one buffer between a forward and a
- * data-gradient call that may overlap).  The weight / bias gradients stay PyTorch-ROCm's. */
+ * data-gradient call that may overlap).  */
 int smk_conv2_train_dgrad(const float *dz, const float *weight, int32_t B, int32_t H, int32_t W, float *dx, void *workspace, void *stream);
+/* dW [128][64][3][3] (and db [128] = sum of dz over batch and pixels, unless NULL) of that convolution from dz [B][128][H][W] and the saved
+ * input a1 [B][64][H][W]: per 8 x 16 tile a GEMM with the pixels as the MFMA k dimension, accumulated in registers per workgroup, the
+ * workgroups' partial sums added in a fixed order (deterministic, no atomics).  `workspace`: smk_conv2_train_wgrad_workspace() bytes. */
+int64_t smk_conv2_train_wgrad_workspace(void);
+int smk_conv2_train_wgrad(const float *dz, const float *a1, int32_t B, int32_t H, int32_t W, float *dw, float *db, void *workspace, void *stream);
 
 /* The passes of the two calls above one at a time, for BatchNorm statistics that span several processes: data-parallel training
  * (train.py under DistributedDataParallel) gives every process a shard of the batch, while the reference's BatchNorm2d layers see the

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "smk_ffn_elementwise": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p],
     "smk_conv2_train_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_conv2_train_dgrad": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "smk_conv2_train_wgrad": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_bn_relu_pool_forward": [C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_double, C.c_int32] + [C.c_void_p] * 6,
     "smk_bn_relu_pool_backward": [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 5,
     "smk_bn_relu_pool_phase": [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 3 +
@@ -99,7 +100,7 @@ _SIGNATURES = {
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
-EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace", "smk_conv2_train_workspace"] + list(_SIGNATURES)
+EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace", "smk_conv2_train_workspace", "smk_conv2_train_wgrad_workspace"] + list(_SIGNATURES)
 
 _lib = None
 
@@ -127,6 +128,8 @@ def load():
         L.smk_layernorm_bwd_workspace.restype = C.c_int64
         L.smk_conv2_train_workspace.argtypes = []
         L.smk_conv2_train_workspace.restype = C.c_int64
+        L.smk_conv2_train_wgrad_workspace.argtypes = []
+        L.smk_conv2_train_wgrad_workspace.restype = C.c_int64
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

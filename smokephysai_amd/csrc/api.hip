@@ -870,6 +870,17 @@ int smk_conv2_train_dgrad(const float *dz, const float *weight, int32_t B, int32
     return check_launch(launch_conv2_train_dgrad(dz, weight, B, H, W, dx, workspace, (hipStream_t)stream), "conv2_train_dgrad");
 }
 
+int64_t smk_conv2_train_wgrad_workspace(void) { return (int64_t)conv2_wgrad_workspace_bytes(conv2_wgrad_streams()); }
+
+int smk_conv2_train_wgrad(const float *dz, const float *a1, int32_t B, int32_t H, int32_t W, float *dw, float *db, void *workspace, void *stream) {
+    SMK_REQUIRE(dz && a1 && dw && workspace, "null dz/a1/dw/workspace");
+    if (B < 1 || H < 8 || W < 16 || H % 8 != 0 || W % 16 != 0 || (int64_t)B * 128 * H * W >= (1ll << 40)) {
+        set_error("conv2_train_wgrad: B >= 1, H a multiple of 8, W a multiple of 16");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return check_launch(launch_conv2_train_wgrad(dz, a1, B, H, W, dw, db, workspace, (hipStream_t)stream), "conv2_train_wgrad");
+}
+
 int64_t smk_bn_train_workspace(int32_t B, int32_t C, int32_t H, int32_t W, int32_t pool) {
     if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
     return bn_train_workspace_floats(B, C, H, W, pool) * (int64_t)sizeof(float);

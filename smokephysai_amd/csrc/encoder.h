@@ -41,6 +41,10 @@ hipError_t launch_encoder_i8(const float *frames, int64_t fstride, int B, int H,
 size_t conv2_train_workspace_bytes();
 // dX = the data gradient of the same convolution from dz [B][128][H][W] (same workspace size, its own contents)
 hipError_t launch_conv2_train_dgrad(const float *dz, const float *weight, int B, int H, int W, float *dx, void *workspace, hipStream_t st);
+// dW [128][64][3][3] (and db [128] unless NULL) of the same convolution from dz and a1; workspace: conv2_wgrad_workspace_bytes(conv2_wgrad_streams())
+size_t conv2_wgrad_workspace_bytes(int nstreams);
+int conv2_wgrad_streams();
+hipError_t launch_conv2_train_wgrad(const float *dz, const float *a1, int B, int H, int W, float *dw, float *db, void *workspace, hipStream_t st);
 hipError_t launch_conv2_train_forward(const float *a1, const float *weight, const float *bias, int B, int H, int W, float *z2, void *workspace,
                                       hipStream_t st);
 

@@ -1356,6 +1356,217 @@ hipError_t launch_conv2_train_dgrad(const float *dz, const float *weight, int B,
     return hipGetLastError();
 }
 
+// k_conv2_wgrad_b16: the weight gradient of the same convolution, dW[o][c][ky][kx] = sum over b, y, x of dZ[b][o][y][x] * a1[b][c][y+ky-1][x+kx-1]:
+// per 8 x 16 tile a GEMM D[o][(tap, c)] += A[o][pixel] * B[(tap, c)][pixel] with the PIXELS as the MFMA k dimension -- both operands are
+// pixel-contiguous in NCHW already, so staging is a copy + split (16 bytes of bf16 per 8 pixels of a row).
+//   workgroup: 32 output channels (2 M-tiles) x all 576 (tap, c) columns (36 N-tiles) for its stream of tiles; wave w: channels 16w .. 16w+15
+//              of a1 and all 9 taps (9 N-tiles): 72 accumulator registers, kept for the whole launch.
+//   k-step:    32 pixels = tile rows 2s, 2s+1; a lane's k-group kg = 8 consecutive x of one row (row 2s + (kg >> 1), x0 = 8 (kg & 1)).
+//   LDS:       dZ tile [hi|lo][32 o][128 px] (row pitch 272 B), a1 tile [hi|lo][64 c][10 rows][16 px] (c pitch 336 B: 16 lanes of one
+//              k-group read conflict-free) + the two halo columns [hi|lo][64 c][10 rows][2].
+//   taps:      ky moves the row (an address), kx = 1 reads the aligned 16-byte chunk, kx = 0 / 2 need the chunk shifted by one bf16: the
+//              neighbouring element comes from the other chunk of the row or from the halo column (one ds_read_u16 at a per-lane address)
+//              and four v_alignbit_b32 build the fragment.
+//   output:    every workgroup adds its tiles into registers and stores ONE partial [32 o][9 taps][64 c]; k_conv2_wgrad_finish adds the
+//              partials of a channel group in stream order (deterministic) and writes dW [128][64][3][3] (and db from the staged dZ).
+constexpr int WG_OG = 32;                                     // output channels per workgroup
+constexpr int WG_ZP = 272;                                    // dZ row pitch (bytes): 128 px * 2 B + 16
+constexpr int WG_AC = 336;                                    // a1 channel pitch (bytes): 10 rows * 32 B + 16
+constexpr int WG_Z_BYTES = WG_OG * WG_ZP;                     // 8,704 per plane
+constexpr int WG_A_BYTES = 64 * WG_AC;                        // 21,504 per plane
+constexpr int WG_H_BYTES = 64 * 10 * 2 * 2;                   // 2,560 per plane: [c][row][left|right] bf16
+constexpr int WG_LDS = 2 * (WG_Z_BYTES + WG_A_BYTES + WG_H_BYTES);   // 65,536
+
+__global__ __launch_bounds__(256, 2) void k_conv2_wgrad_b16(const float *__restrict__ dz, const float *__restrict__ a1, int H, int W, int tiles_x,
+                                                         int tiles_per_frame, int ntiles, int nstreams, float *__restrict__ part,
+                                                         float *__restrict__ dbpart) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *zh = smem, *zl = zh + WG_Z_BYTES, *ah = zl + WG_Z_BYTES, *al = ah + WG_A_BYTES, *hh = al + WG_A_BYTES, *hl = hh + WG_H_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n15 = lane & 15, kg = lane >> 4;
+    // blocks i and i + 8 share an XCD: the four channel groups of one tile stream sit on one XCD (a1 is fetched into that L2 once)
+    const int xcd = blockIdx.x & 7, og = (blockIdx.x >> 3) & 3, stream = (blockIdx.x >> 5) * 8 + xcd;
+    const size_t plane = (size_t)H * W;
+    f32x4v acc[2][9];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[m][t9][g] = 0.f;
+    float dbsum = 0.f;                                        // this thread's share of db: channel og*32 + tid / 8, pixels 16 (tid % 8) ..
+
+    for (int t = stream; t < ntiles; t += nstreams) {
+        const int b = t / tiles_per_frame, rem = t - b * tiles_per_frame;
+        const int r0 = (rem / tiles_x) * B3_TH, c0 = (rem % tiles_x) * B3_TW;
+        // ---- stage dZ: 32 o x 8 rows x 16 px; thread: o = tid / 8, row = tid % 8 (16 px = 4 x float4)
+        {
+            const int o = tid >> 3, row = tid & 7;
+            const float *src = dz + ((size_t)b * 128 + og * WG_OG + o) * plane + (size_t)(r0 + row) * W + c0;
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(src + 4 * q);
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const float f[8] = {v[2 * hlf].x, v[2 * hlf].y, v[2 * hlf].z, v[2 * hlf].w, v[2 * hlf + 1].x, v[2 * hlf + 1].y, v[2 * hlf + 1].z, v[2 * hlf + 1].w};
+                bf16x8 vh, vl;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    __bf16 a_, b_;
+                    split_bf16(f[c], a_, b_);
+                    vh[c] = a_; vl[c] = b_;
+                    dbsum += f[c];
+                }
+                const int off = o * WG_ZP + (row * 16 + 8 * hlf) * 2;
+                *reinterpret_cast<bf16x8 *>(zh + off) = vh;
+                *reinterpret_cast<bf16x8 *>(zl + off) = vl;
+            }
+        }
+        // ---- stage a1: 64 c x 10 rows x 16 px (+ 2 halo columns); items (c, row): 640 -> 3 per thread (the last partly)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int it = tid + 256 * j;
+            if (it < 640) {
+                const int c = it / 10, row = it - c * 10;
+                const int ii = r0 - 1 + row;
+                const bool rin = ii >= 0 && ii < H;
+                const float *src = a1 + ((size_t)b * 64 + c) * plane + (size_t)(rin ? ii : 0) * W + c0;
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(src + 4 * q);
+                const float lft = (rin && c0 > 0) ? src[-1] : 0.f, rgt = (rin && c0 + 16 < W) ? src[16] : 0.f;
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const float f[8] = {v[2 * hlf].x, v[2 * hlf].y, v[2 * hlf].z, v[2 * hlf].w, v[2 * hlf + 1].x, v[2 * hlf + 1].y, v[2 * hlf + 1].z, v[2 * hlf + 1].w};
+                    bf16x8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        __bf16 a_, b_;
+                        split_bf16(rin ? f[e] : 0.f, a_, b_);
+                        vh[e] = a_; vl[e] = b_;
+                    }
+                    const int off = c * WG_AC + row * 32 + 16 * hlf;
+                    *reinterpret_cast<bf16x8 *>(ah + off) = vh;
+                    *reinterpret_cast<bf16x8 *>(al + off) = vl;
+                }
+                __bf16 lh_, ll_, rh_, rl_;
+                split_bf16(lft, lh_, ll_);
+                split_bf16(rgt, rh_, rl_);
+                __bf16 *ph = reinterpret_cast<__bf16 *>(hh) + (c * 10 + row) * 2, *pl = reinterpret_cast<__bf16 *>(hl) + (c * 10 + row) * 2;
+                ph[0] = lh_; ph[1] = rh_;
+                pl[0] = ll_; pl[1] = rl_;
+            }
+        }
+        __syncthreads();
+        // ---- 4 k-steps of 32 pixels: A = dZ (2 M-tiles), B = a1 of the wave's 16 channels at the 9 taps
+        const int cw = wave * 16 + n15;                       // the lane's a1 channel (B row)
+        const int x0 = 8 * (kg & 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int prow = 2 * s4 + (kg >> 1);              // the lane's tile row in this k-step
+            bf16x8 azh[2], azl[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int off = (m * 16 + n15) * WG_ZP + (prow * 16 + x0) * 2;
+                azh[m] = *reinterpret_cast<const bf16x8 *>(zh + off);
+                azl[m] = *reinterpret_cast<const bf16x8 *>(zl + off);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int arow = prow + ky;                   // row of the 10-row halo tile (tile row + ky - 1, + 1 for the halo)
+                const int rbase = cw * WG_AC + arow * 32;
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 ch = *reinterpret_cast<const u32x4 *>(ah + rbase + 2 * x0), cl = *reinterpret_cast<const u32x4 *>(al + rbase + 2 * x0);
+                // the element left of the chunk (x0 - 1) and right of it (x0 + 8): the row's other chunk, or the halo column
+                const int lo_off = x0 ? rbase + 14 : -1, ro_off = x0 ? -1 : rbase + 16;
+                const int hidx = ((cw * 10 + arow) * 2) * 2;
+                const unsigned int leh = lo_off >= 0 ? *reinterpret_cast<const unsigned short *>(ah + lo_off) : *reinterpret_cast<const unsigned short *>(hh + hidx);
+                const unsigned int lel = lo_off >= 0 ? *reinterpret_cast<const unsigned short *>(al + lo_off) : *reinterpret_cast<const unsigned short *>(hl + hidx);
+                const unsigned int reh = ro_off >= 0 ? *reinterpret_cast<const unsigned short *>(ah + ro_off) : *reinterpret_cast<const unsigned short *>(hh + hidx + 2);
+                const unsigned int rel = ro_off >= 0 ? *reinterpret_cast<const unsigned short *>(al + ro_off) : *reinterpret_cast<const unsigned short *>(hl + hidx + 2);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    u32x4 fh, fl;
+                    if (kx == 1) {
+                        fh = ch; fl = cl;
+                    } else if (kx == 0) {                     // elements x0-1 .. x0+6
+                        fh[0] = leh | (ch[0] << 16); fl[0] = lel | (cl[0] << 16);
+#pragma unroll
+                        for (int i = 1; i < 4; ++i) {
+                            fh[i] = __builtin_amdgcn_alignbit(ch[i], ch[i - 1], 16);
+                            fl[i] = __builtin_amdgcn_alignbit(cl[i], cl[i - 1], 16);
+                        }
+                    } else {                                  // elements x0+1 .. x0+8
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            fh[i] = __builtin_amdgcn_alignbit(ch[i + 1], ch[i], 16);
+                            fl[i] = __builtin_amdgcn_alignbit(cl[i + 1], cl[i], 16);
+                        }
+                        fh[3] = (ch[3] >> 16) | (reh << 16); fl[3] = (cl[3] >> 16) | (rel << 16);
+                    }
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, fh), bl = __builtin_bit_cast(bf16x8, fl);
+                    const int t9 = ky * 3 + kx;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        f32x4v &c = acc[m][t9];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(azl[m], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(azh[m], bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(azh[m], bh, c, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                      // every wave is done reading the tiles
+    }
+    // ---- this workgroup's partial: part[stream][og][o_local 32][tap 9][c 64]; D layout: lane (n15 = column = c, kg) holds rows 4kg .. 4kg+3 (= o)
+    float *dst = part + ((size_t)stream * 4 + og) * (WG_OG * 9 * 64);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dst[((size_t)(m * 16 + 4 * kg + g) * 9 + t9) * 64 + wave * 16 + n15] = acc[m][t9][g];
+    // db partial: 8 threads per channel (tid % 8 = the tile row they staged), added in lane order
+    float sdb = dbsum;
+    sdb += __shfl_xor(sdb, 1); sdb += __shfl_xor(sdb, 2); sdb += __shfl_xor(sdb, 4);
+    if ((tid & 7) == 0) dbpart[((size_t)stream * 4 + og) * WG_OG + (tid >> 3)] = sdb;
+}
+
+// dW[o][c][tap] = sum over streams (in stream order) of part[stream][o / 32][o % 32][tap][c]; db[o] likewise
+__global__ __launch_bounds__(256) void k_conv2_wgrad_finish(const float *__restrict__ part, const float *__restrict__ dbpart, int nstreams,
+                                                          float *__restrict__ dw, float *__restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;             // over [o 128][tap 9][c 64]
+    if (i < 128 * 9 * 64) {
+        const int c = i & 63, t9 = (i >> 6) % 9, o = i / (9 * 64);
+        const float *src = part + ((size_t)(o >> 5) * (WG_OG * 9 * 64)) + ((size_t)(o & 31) * 9 + t9) * 64 + c;
+        float s = 0.f;
+        for (int st = 0; st < nstreams; ++st) s += src[(size_t)st * 4 * (WG_OG * 9 * 64)];
+        dw[((size_t)o * 64 + c) * 9 + t9] = s;
+    }
+    if (db && i < 128) {
+        float s = 0.f;
+        for (int st = 0; st < nstreams; ++st) s += dbpart[((size_t)st * 4 + (i >> 5)) * WG_OG + (i & 31)];
+        db[i] = s;
+    }
+}
+
+size_t conv2_wgrad_workspace_bytes(int nstreams) { return ((size_t)nstreams * 4 * (WG_OG * 9 * 64) + (size_t)nstreams * 4 * WG_OG) * sizeof(float); }
+int conv2_wgrad_streams() { return (device_num_cu() * 2 / 32) * 8; }     // two workgroups per CU, four channel groups per stream, 8 XCD slots
+
+hipError_t launch_conv2_train_wgrad(const float *dz, const float *a1, int B, int H, int W, float *dw, float *db, void *workspace, hipStream_t st) {
+    if (H % B3_TH != 0 || W % B3_TW != 0 || B < 1) return hipErrorInvalidValue;
+    const int tiles_x = W / B3_TW, tiles_per_frame = tiles_x * (H / B3_TH), ntiles = B * tiles_per_frame;
+    const int nstreams = conv2_wgrad_streams();
+    if (nstreams < 8) return hipErrorInvalidValue;
+    float *part = static_cast<float *>(workspace), *dbpart = part + (size_t)nstreams * 4 * (WG_OG * 9 * 64);
+    if (first_use_on_device((const void *)k_conv2_wgrad_b16))
+        (void)hipFuncSetAttribute((const void *)k_conv2_wgrad_b16, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+    hipLaunchKernelGGL(k_conv2_wgrad_b16, dim3(nstreams * 4), dim3(256), WG_LDS, st, dz, a1, H, W, tiles_x, tiles_per_frame, ntiles, nstreams, part, dbpart);
+    hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3(cdiv(128 * 9 * 64, 256)), dim3(256), 0, st, part, dbpart, nstreams, dw, db);
+    return hipGetLastError();
+}
+
 // w [128 o][64 c][3][3] -> w2s [k-step = tap*2 + c/32][hi|lo][o][32 c] (the B fragments of the 16x16x32 tap loop)
 __global__ void k_split_conv2_weights(const float *__restrict__ w, unsigned short *__restrict__ w2s_) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

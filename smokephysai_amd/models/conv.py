@@ -1,7 +1,6 @@
 """Host side of libsmokehip's training convolution (smk_conv2_train_forward): SmokePhysNet.input_encoder's second convolution
-(smokephys_net.py:28, Conv2d(64, 128, 3, padding=1)) under autograd.  The data gradient runs on the split-bf16 MFMA kernel
-(csrc/encoder.hip: k_conv2_dgrad_b16), the forward optionally (k_conv2_fwd_b16; default PyTorch-ROCm, see hip_conv2_train); the weight /
-bias gradients are PyTorch-ROCm's convolution_backward on the saved input."""
+(smokephys_net.py:28, Conv2d(64, 128, 3, padding=1)) under autograd.  The data gradient (csrc/encoder.hip: k_conv2_dgrad_b16) and the weight / bias gradients (k_conv2_wgrad_b16) run on
+split-bf16 MFMA kernels, the forward optionally (k_conv2_fwd_b16; default PyTorch-ROCm, see hip_conv2_train)."""
 import torch
 from torch import nn
 
@@ -16,7 +15,7 @@ def hip_conv2_train_supported(x: torch.Tensor, conv: nn.Conv2d) -> bool:
 
 class _HipConv2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, hip_forward):
+    def forward(ctx, x, weight, bias, hip_forward, hip_wgrad):
         dev = _lib.require_cuda(x.device, "hip_conv2_train")
         L = _lib.load()
         x = x.contiguous()
@@ -32,6 +31,7 @@ class _HipConv2Fn(torch.autograd.Function):
             z = torch.ops.aten.convolution(x, weight.detach(), None if bias is None else bias.detach(), [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.hip_wgrad = hip_wgrad
         return z
 
     @staticmethod
@@ -48,15 +48,26 @@ class _HipConv2Fn(torch.autograd.Function):
                                                _lib.stream_ptr(x.device)))
         mask = [False, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
         dw = db = None
-        if mask[1] or mask[2]:                              # weight / bias gradients: PyTorch-ROCm
+        if (mask[1] or mask[2]) and ctx.hip_wgrad:          # weight / bias gradients on libsmokehip (k_conv2_wgrad_b16)
+            L = _lib.load()
+            B, _, H, W = x.shape
+            dw = torch.empty_like(weight)
+            db = torch.empty(128, device=x.device, dtype=torch.float32) if mask[2] else None
+            ws = torch.empty(int(L.smk_conv2_train_wgrad_workspace()), device=x.device, dtype=torch.uint8)
+            _lib.check(L.smk_conv2_train_wgrad(dz.data_ptr(), x.data_ptr(), B, H, W, dw.data_ptr(), None if db is None else db.data_ptr(),
+                                               ws.data_ptr(), _lib.stream_ptr(x.device)))
+            if not mask[1]:
+                dw = None
+        elif mask[1] or mask[2]:                            # ... or PyTorch-ROCm's
             _, dw, db = torch.ops.aten.convolution_backward(dz, x, weight, [128] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1],
                                                             False, [0, 0], 1, mask)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def hip_conv2_train(x: torch.Tensor, conv: nn.Conv2d, hip_forward: bool = False) -> torch.Tensor:
-    """conv(x) for the encoder's 64 -> 128 3x3 convolution under autograd with the DATA GRADIENT on libsmokehip (k_conv2_dgrad_b16) and,
-    with hip_forward=True, the forward too (k_conv2_fwd_b16).  Raises off a ROCm device: no CPU fallback.
+def hip_conv2_train(x: torch.Tensor, conv: nn.Conv2d, hip_forward: bool = False, hip_wgrad: bool = True) -> torch.Tensor:
+    """conv(x) for the encoder's 64 -> 128 3x3 convolution under autograd with the data gradient (k_conv2_dgrad_b16) and, unless
+    hip_wgrad=False, the weight / bias gradients (k_conv2_wgrad_b16) on libsmokehip; with hip_forward=True the forward too
+    (k_conv2_fwd_b16).  Raises off a ROCm device: no CPU fallback.
 
     Why the forward is opt-in: the split-bf16 forward is 5e-6 (max-norm) from an fp64 convolution, MIOpen's fp32 one 4e-7, and in this
     network the convolution feeds train-mode BatchNorm + ReLU: in fp64, noise of relative size 5e-7 / 5e-6 on its output moves
@@ -64,4 +75,4 @@ def hip_conv2_train(x: torch.Tensor, conv: nn.Conv2d, hip_forward: bool = False)
     (tests/test_hip_pipeline.py).  The data gradient has no such amplifier: its 5e-6 propagates linearly."""
     if not hip_conv2_train_supported(x, conv):
         raise ValueError("hip_conv2_train: a float32 ROCm tensor [B, 64, H, W] with H % 8 == 0, W % 16 == 0 and Conv2d(64, 128, 3, padding=1)")
-    return _HipConv2Fn.apply(x, conv.weight, conv.bias, bool(hip_forward))
+    return _HipConv2Fn.apply(x, conv.weight, conv.bias, bool(hip_forward), bool(hip_wgrad))

@@ -2,6 +2,8 @@
 reference's captured features (tests/golden/encoder_io_*.npz) and the fp64-accumulating oracle.
 Tolerance: 1e-4 relative (max-norm), the bar BASELINE.json states for CNN features."""
 import numpy as np
+import copy
+
 import pytest
 import torch
 
@@ -319,13 +321,23 @@ def test_training_conv2_forward_vs_fp64_and_gradients_vs_autograd(shape):
     conv.zero_grad()
     xb = x.clone().requires_grad_(True)
     conv(xb).backward(dz)
-    for a, b_, name in ((gw, conv.weight.grad, "dW"), (gb, conv.bias.grad, "db")):       # PyTorch-ROCm's own convolution_backward
-        assert float((a - b_).abs().max()) <= 1e-6 * float(b_.abs().max()) + 1e-12, name
-    # the data gradient is k_conv2_dgrad_b16's: against fp64 autograd
+    # all three gradients are libsmokehip's (k_conv2_dgrad_b16, k_conv2_wgrad_b16): against fp64 autograd
     xd = x.double().requires_grad_(True)
-    torch.nn.functional.conv2d(xd, conv.weight.double(), conv.bias.double(), padding=1).backward(dz.double())
+    c64 = copy.deepcopy(conv).double()
+    c64.zero_grad()
+    c64(xd).backward(dz.double())
     errx = float((gx.double() - xd.grad).abs().max() / xd.grad.abs().max())
     assert errx < 1e-5, errx
+    errw = float((gw.double() - c64.weight.grad).abs().max() / c64.weight.grad.abs().max())
+    errb = float((gb.double() - c64.bias.grad).abs().max() / c64.bias.grad.abs().max())
+    assert errw < 1e-5 and errb < 1e-5, (errw, errb)
+    for a, b_, name in ((gw, conv.weight.grad, "dW"), (gb, conv.bias.grad, "db")):       # and next to PyTorch-ROCm's fp32 ones
+        assert float((a - b_).abs().max()) <= 1e-4 * float(b_.abs().max()), name
+    # run-to-run: the partial sums are added in a fixed order
+    conv.zero_grad()
+    xc = x.clone().requires_grad_(True)
+    hip_conv2_train(xc, conv, hip_forward=True).backward(dz)
+    assert torch.equal(conv.weight.grad, gw) and torch.equal(conv.bias.grad, gb) and torch.equal(xc.grad, gx)
     assert float((gx - xb.grad).abs().max() / xb.grad.abs().max()) < 1e-4      # and next to PyTorch-ROCm's fp32 one
     # shapes the kernel is not built for are refused, not silently rerouted
     with pytest.raises(ValueError):
