@@ -270,8 +270,8 @@ int smk_bn_relu_pool_backward(const float *z, const float *dout, int32_t B, int3
 /* The encoder's second convolution alone, for training: z2 = Conv2d(64, 128, 3, padding = 1)(a1) + bias under autograd
  * (smokephys_net.py:28; train.py:88-89 -- train-mode BatchNorm needs the whole convolution output before it can normalise, so the
  * fused eval encoder does not apply).  a1 [B][64][H][W] and z2 [B][128][H][W] NCHW fp32, weight [128][64][3][3], bias [128] or NULL;
- * H % 8 == 0, W % 16 == 0.  Split-bf16 on the bf16 matrix cores with fp32 accumulation (the eval encoder's arithmetic: within 1e-5 of
- * an fp64 convolution).  `workspace`: smk_conv2_train_workspace() bytes of device memory; the split weights are rebuilt from `weight`
+ * H % 8 == 0, W % 16 == 0.  Split-bf16 on the bf16 matrix cores with fp32 accumulation: three bf16 terms per operand, six products
+ * (within 2e-6 of an fp64 convolution -- the output feeds BatchNorm + ReLU, whose masks amplify forward error in the gradients).  `workspace`: smk_conv2_train_workspace() bytes of device memory; the split weights are rebuilt from `weight`
  * in the same call, so an optimizer step needs no other notification.  The weight / bias gradients stay with the caller (PyTorch-ROCm's
  * convolution_backward in models/conv.py); the data gradient is smk_conv2_train_dgrad.  Enqueued on `stream`. */
 int64_t smk_conv2_train_workspace(void);

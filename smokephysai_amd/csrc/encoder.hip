@@ -980,15 +980,28 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 // k_conv2_fwd_b16: the encoder's second convolution alone, for TRAINING (smokephys_net.py:28, Conv2d(64, 128, 3, padding=1) under
 // autograd): z2 = conv(a1, w) + bias with a1 the activated first block [B, 64, H, W] and z2 [B, 128, H, W], both NCHW fp32 in HBM
-// (train-mode BatchNorm needs the whole z2 before it can normalise, so nothing fuses across it).  The arithmetic, the tile (8 x 16
-// pixels, 180-pixel halo image in LDS as two swizzled bf16 planes) and the tap loop are k_encoder_b16's; the prologue stages the
-// halo tile from HBM (a thread owns one pixel and one group of 8 channels: 8 loads whose lanes run along a row, one split, one
-// 16-byte store per plane) instead of computing it, and the epilogue stores the raw accumulators (+ bias) as 16-byte row pieces.
+// (train-mode BatchNorm needs the whole z2 before it can normalise, so nothing fuses across it).  The tile (8 x 16 pixels, 180-pixel
+// halo image in LDS as swizzled bf16 planes) and the tap-loop skeleton are k_encoder_b16's; the prologue stages the halo tile from
+// HBM (a thread owns one pixel and one group of 8 channels: 8 loads whose lanes run along a row, one split, one 16-byte store per
+// plane) instead of computing it, and the epilogue stores the raw accumulators (+ bias) as 16-byte row pieces.
+// ARITHMETIC: three bf16 terms per operand (v = h + m + l, 24 bits) and the six products h*h, h*m, m*h, m*m, h*l, l*h -- not the eval
+// encoder's two terms / three products: this output feeds train-mode BatchNorm + ReLU, whose masks turn a 5e-6 forward error into a
+// 1e-2 error of conv2.weight.grad (in fp64, noise of relative size 5e-7 / 5e-6 on z2 moves that gradient by 4e-3 / 1.7e-2), so the
+// training forward has to be as exact as an fp32 convolution.  Per MFMA it moves LESS operand data than the three-product loop (12 A
+// fragments and 6 B fragments per 96 MFMAs against 8 and 4 per 48).
+constexpr int C2F_LDS = 3 * S16_A1_BYTES;                     // 69,120 -> 2 workgroups per CU
+__device__ __forceinline__ void split3_bf16(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
 __global__ __launch_bounds__(256, 2) void k_conv2_fwd_b16(const float *__restrict__ a1, int H, int W, const unsigned short *__restrict__ w2s,
                                                        const float *__restrict__ bias, float *__restrict__ z2, int tiles_x,
                                                        int tiles_per_frame, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *a1h = smem, *a1l = a1h + S16_A1_BYTES;
+    unsigned char *a1p[3] = {smem, smem + S16_A1_BYTES, smem + 2 * S16_A1_BYTES};
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, kg = lane >> 4;
@@ -996,21 +1009,17 @@ __global__ __launch_bounds__(256, 2) void k_conv2_fwd_b16(const float *__restric
     const float b2a = bias ? bias[o0] : 0.f, b2b = bias ? bias[o0 + 16] : 0.f;
     const int lane_b = o0 * 64 + kg * 16;
     const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w2s), 0, 18 * 2 * 8192, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(w2s), 0, 18 * 3 * 8192, 0x00020000);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto load_b = [&](int ks, int part, int nt) -> uint4 {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (ks * 2 + part) * 8192 + nt * 1024, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, (ks * 3 + part) * 8192 + nt * 1024, 0);
         return make_uint4(v.x, v.y, v.z, v.w);
     };
-    constexpr int RING = 2;
-    uint4 bq[RING][2][2];
+    uint4 bq[2][2][3];                                        // [slot][nt][h | m | l]
 #pragma unroll
-    for (int k = 0; k < RING - 1; ++k)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            bq[k][nt][0] = load_b(k, 0, nt);
-            bq[k][nt][1] = load_b(k, 1, nt);
-        }
+        for (int part = 0; part < 3; ++part) bq[0][nt][part] = load_b(0, part, nt);
     const size_t plane = (size_t)H * W;
     constexpr int ITEMS = (B3_TH + 2) * 8 * B3_AW;            // 10 rows x 8 channel groups x 18 pixels = 1,440 (pixel fastest)
     constexpr int NIT = (ITEMS + 255) / 256;                  // 6 per thread
@@ -1042,23 +1051,24 @@ __global__ __launch_bounds__(256, 2) void k_conv2_fwd_b16(const float *__restric
                     const int ii = r0 - 1 + row, jj = c0 - 1 + pc;
                     const bool in = ii >= 0 && ii < H && jj >= 0 && jj < W;
                     const int p = row * B3_AW + pc;
-                    bf16x8 vh, vl;
+                    bf16x8 vh, vm, vl;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        __bf16 hh, ll;
-                        split_bf16(in ? v[j][c] : 0.f, hh, ll);
-                        vh[c] = hh; vl[c] = ll;
+                        __bf16 hh, mm, ll;
+                        split3_bf16(in ? v[j][c] : 0.f, hh, mm, ll);
+                        vh[c] = hh; vm[c] = mm; vl[c] = ll;
                     }
                     const int off = p * 128 + ((g ^ (p & 7)) * 16);
-                    *reinterpret_cast<bf16x8 *>(a1h + off) = vh;
-                    *reinterpret_cast<bf16x8 *>(a1l + off) = vl;
+                    *reinterpret_cast<bf16x8 *>(a1p[0] + off) = vh;
+                    *reinterpret_cast<bf16x8 *>(a1p[1] + off) = vm;
+                    *reinterpret_cast<bf16x8 *>(a1p[2] + off) = vl;
                 }
             }
         }
         __syncthreads();                                      // a1 complete
         __builtin_amdgcn_s_setprio(S16_PRIO_KLOOP);
 
-        // ---- conv2: acc[mt][nt][reg] = D(pixel row mt, column 4 kg + reg; channel 16 nt + px of the wave's 32)
+        // ---- conv2: acc[mt][nt][reg] = D(pixel row mt, column 4 kg + reg; channel 16 nt + px of the wave's 32); units as in k_encoder_b16
         f32x4v acc[8][2];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
@@ -1066,80 +1076,68 @@ __global__ __launch_bounds__(256, 2) void k_conv2_fwd_b16(const float *__restric
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[mt][nt][g] = 0.f;
-        // unit k (0..35) = tap * 4 + half * 2 + hm: M tiles 4hm .. 4hm+3 of k-step ks = k >> 1 = tap * 2 + half.  The loop runs over
-        // the 9 taps (runtime) x 4 unrolled units.  Per tap four lane registers om[m] = pixel base ^ swizzle term of row m + ki
-        // are formed once (the base is a multiple of 128 and the term < 128, so base + (c ^ t) = base ^ t ^ c): a fragment pair then
-        // costs ONE xor, and the row offsets ki * 2304 (scalar) and 4hm * 2304 + m * 2304 (ds_read immediate) are free.
         const int c16[2] = {kg << 4, (4 + kg) << 4};
-        auto tap_consts = [&](int ki, int kj, int (&om)[4]) {
+        auto tap_consts8 = [&](int ki, int kj, int (&om8)[8]) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) om[m] = ((px + kj) << 7) ^ (((px + kj + 2 * (m + ki)) & 7) << 4);
+            for (int m = 0; m < 8; ++m) om8[m] = ((px + kj) << 7) ^ (((px + kj + 2 * (m + ki)) & 7) << 4);
         };
-        auto load_a = [&](int ki, int half, int hm, const int (&om)[4], bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
-            const unsigned char *ph = a1h + ki * (B3_AW * 128), *pl = a1l + ki * (B3_AW * 128);      // wave-uniform part
+        auto load_a = [&](int ki, int half, int mq, const int (&om8)[8], bf16x8 (&af)[3][2]) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int off = om[m] ^ c16[half];
-                ah[m] = *reinterpret_cast<const bf16x8 *>(ph + off + (4 * hm + m) * (B3_AW * 128));
-                al[m] = *reinterpret_cast<const bf16x8 *>(pl + off + (4 * hm + m) * (B3_AW * 128));
+            for (int j = 0; j < 2; ++j) {
+                const int m = 2 * mq + j;
+                const int off = (om8[m] ^ c16[half]) + (ki + m) * (B3_AW * 128);
+#pragma unroll
+                for (int part = 0; part < 3; ++part) af[part][j] = *reinterpret_cast<const bf16x8 *>(a1p[part] + off);
             }
         };
-        bf16x8 ahA[4], alA[4], ahB[4], alB[4];
-        int om[4];
-        tap_consts(0, 0, om);
-        load_a(0, 0, 0, om, ahA, alA);
+        // unit u = half * 4 + mq of a tap: pixel rows 2mq, 2mq+1 of k-step (tap, half): 24 MFMAs on 6 A fragments and the k-step's 6 B fragments
+        bf16x8 afA[3][2], afB[3][2];
+        int om8[8];
+        tap_consts8(0, 0, om8);
+        load_a(0, 0, 0, om8, afA);
         int ki = 0, kj = 0;
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int half = u >> 1, hm = u & 1, slot = half % RING;
-                if (hm == 0) {
-                    // refill: k-step ks + 1 into the slot consumed one k-step ago.  All four fragments (both N tiles, hi and lo) are
-                    // requested in the FIRST unit of the k-step, right at its start: two units (768 cycles) before their first use.
-                    // Measured placements of the ring loads within a unit: early 1.06 ms, middle 1.075, late 1.11.
-                    int kn = tap * 2 + half + RING - 1;
+            for (int u = 0; u < 8; ++u) {
+                const int half = u >> 2, mq = u & 3, slot = half;
+                if (mq == 0) {                                 // refill the other slot with k-step ks + 1: six fragments, at the k-step's start
+                    int kn = tap * 2 + half + 1;
                     kn = kn >= 18 ? kn - 18 : kn;
                     kn = __builtin_amdgcn_readfirstlane(kn);
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        bq[(slot + RING - 1) % RING][nt][0] = load_b(kn, 0, nt);
-                        bq[(slot + RING - 1) % RING][nt][1] = load_b(kn, 1, nt);
-                    }
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int part = 0; part < 3; ++part) bq[slot ^ 1][nt][part] = load_b(kn, part, nt);
                 }
-                if (u < 3) {                                   // next unit: same tap
-                    if (u & 1) load_a(ki, (u + 1) >> 1, (u + 1) & 1, om, ahA, alA);
-                    else load_a(ki, (u + 1) >> 1, (u + 1) & 1, om, ahB, alB);
-                } else if (tap < 8) {                          // first unit of the next tap (u = 3 is odd: set A)
+                if (u < 7) {
+                    if (u & 1) load_a(ki, (u + 1) >> 2, (u + 1) & 3, om8, afA);
+                    else load_a(ki, (u + 1) >> 2, (u + 1) & 3, om8, afB);
+                } else if (tap < 8) {                          // u = 7 is odd: the next tap's first unit goes to set A
                     kj = kj == 2 ? 0 : kj + 1;
                     ki = kj == 0 ? ki + 1 : ki;
-                    tap_consts(ki, kj, om);
-                    load_a(ki, 0, 0, om, ahA, alA);
+                    tap_consts8(ki, kj, om8);
+                    load_a(ki, 0, 0, om8, afA);
                 }
-                // product-major emission: consecutive MFMAs go to different accumulators (dependency distance 8 instead of 1); each
-                // accumulator still sums lo*hi, hi*lo, hi*hi in that order, so results are bitwise those of the chain-major form
+                // six products, smallest first, product-major (consecutive MFMAs go to different accumulators: dependency distance 4)
 #pragma unroll
-                for (int pr = 0; pr < 3; ++pr)
+                for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
-                            const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[slot][nt][0]);
-                            const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[slot][nt][1]);
-                            f32x4v &c = acc[4 * hm + m][nt];
-                            const bf16x8 ah = (u & 1) ? ahB[m] : ahA[m], al = (u & 1) ? alB[m] : alA[m];
-                            if (pr == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-                            else if (pr == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-                            else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};       // l*h, h*l, m*m, m*h, h*m, h*h
+                            const bf16x8 av = (u & 1) ? afB[PA[pr]][j] : afA[PA[pr]][j];
+                            const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[slot][nt][PB[pr]]);
+                            f32x4v &c = acc[2 * mq + j][nt];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
                         }
-                // 24 MFMAs of 16 cycles.  The next unit's 8 fragment reads are spread evenly, one after every third MFMA; the ring loads
-                // go right behind the first MFMAs.  (One read per second MFMA in the first 16 -- what hipcc also does unpinned -- is
-                // 4 % slower; see DESIGN.md 3.2 for the placements measured.)
+                // 24 MFMAs: the next unit's 6 fragment reads one per four MFMAs, a k-step's six weight loads behind the first MFMAs of its first unit
 #pragma unroll
                 for (int i = 0; i < 24; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    else if (hm == 0 && (i == 1 || i == 2 || i == 4 || i == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (i % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else if (mq == 0 && i < 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1567,20 +1565,22 @@ hipError_t launch_conv2_train_wgrad(const float *dz, const float *a1, int B, int
     return hipGetLastError();
 }
 
-// w [128 o][64 c][3][3] -> w2s [k-step = tap*2 + c/32][hi|lo][o][32 c] (the B fragments of the 16x16x32 tap loop)
+// w [128 o][64 c][3][3] -> w2s [k-step = tap*2 + c/32][h|m|l][o][32 c] (the B fragments of the training forward's tap loop: three bf16 terms)
 __global__ void k_split_conv2_weights(const float *__restrict__ w, unsigned short *__restrict__ w2s_) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 9 * 64 * 128) return;
     const int c = t % 64, o = (t / 64) % 128, tap = t / (64 * 128);
     const float v = w[((size_t)o * 64 + c) * 9 + tap];
     __bf16 *w2s = reinterpret_cast<__bf16 *>(w2s_);
-    const __bf16 hi = (__bf16)v;
+    __bf16 h, m, l;
+    split3_bf16(v, h, m, l);
     const int ks2 = tap * 2 + (c >> 5), c32 = c & 31;
-    w2s[((size_t)(ks2 * 2 + 0) * 128 + o) * 32 + c32] = hi;
-    w2s[((size_t)(ks2 * 2 + 1) * 128 + o) * 32 + c32] = (__bf16)(v - (float)hi);
+    w2s[((size_t)(ks2 * 3 + 0) * 128 + o) * 32 + c32] = h;
+    w2s[((size_t)(ks2 * 3 + 1) * 128 + o) * 32 + c32] = m;
+    w2s[((size_t)(ks2 * 3 + 2) * 128 + o) * 32 + c32] = l;
 }
 
-size_t conv2_train_workspace_bytes() { return (size_t)18 * 2 * 128 * 32 * sizeof(unsigned short); }
+size_t conv2_train_workspace_bytes() { return (size_t)18 * 3 * 128 * 32 * sizeof(unsigned short); }     // (the data gradient uses 2/3 of it)
 
 hipError_t launch_conv2_train_forward(const float *a1, const float *weight, const float *bias, int B, int H, int W, float *z2, void *workspace,
                                       hipStream_t st) {
@@ -1588,7 +1588,7 @@ hipError_t launch_conv2_train_forward(const float *a1, const float *weight, cons
     unsigned short *w2s = static_cast<unsigned short *>(workspace);
     hipLaunchKernelGGL(k_split_conv2_weights, dim3(cdiv(9 * 64 * 128, 256)), dim3(256), 0, st, weight, w2s);
     const int tiles_x = W / B3_TW, tiles_per_frame = tiles_x * (H / B3_TH), ntiles = B * tiles_per_frame;
-    constexpr int lds = 2 * S16_A1_BYTES;
+    constexpr int lds = C2F_LDS;
     const int wgs_per_cu = device_cached_int((const void *)k_conv2_fwd_b16, [] {
         (void)hipFuncSetAttribute((const void *)k_conv2_fwd_b16, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         int n = 0;

@@ -1,6 +1,6 @@
 """Host side of libsmokehip's training convolution (smk_conv2_train_forward): SmokePhysNet.input_encoder's second convolution
 (smokephys_net.py:28, Conv2d(64, 128, 3, padding=1)) under autograd.  The data gradient (csrc/encoder.hip: k_conv2_dgrad_b16) and the weight / bias gradients (k_conv2_wgrad_b16) run on
-split-bf16 MFMA kernels, the forward optionally (k_conv2_fwd_b16; default PyTorch-ROCm, see hip_conv2_train)."""
+split-bf16 MFMA kernels, and so does the forward (k_conv2_fwd_b16, three bf16 terms per operand: see hip_conv2_train)."""
 import torch
 from torch import nn
 
@@ -27,7 +27,7 @@ class _HipConv2Fn(torch.autograd.Function):
             b = None if bias is None else bias.detach().contiguous()
             _lib.check(L.smk_conv2_train_forward(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), B, H, W, z.data_ptr(),
                                                  ws.data_ptr(), _lib.stream_ptr(dev)))
-        else:                                               # PyTorch-ROCm's fp32 convolution (see hip_conv2_train)
+        else:                                               # PyTorch-ROCm's fp32 convolution
             z = torch.ops.aten.convolution(x, weight.detach(), None if bias is None else bias.detach(), [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -64,15 +64,16 @@ class _HipConv2Fn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-def hip_conv2_train(x: torch.Tensor, conv: nn.Conv2d, hip_forward: bool = False, hip_wgrad: bool = True) -> torch.Tensor:
-    """conv(x) for the encoder's 64 -> 128 3x3 convolution under autograd with the data gradient (k_conv2_dgrad_b16) and, unless
-    hip_wgrad=False, the weight / bias gradients (k_conv2_wgrad_b16) on libsmokehip; with hip_forward=True the forward too
-    (k_conv2_fwd_b16).  Raises off a ROCm device: no CPU fallback.
+def hip_conv2_train(x: torch.Tensor, conv: nn.Conv2d, hip_forward: bool = True, hip_wgrad: bool = True) -> torch.Tensor:
+    """conv(x) for the encoder's 64 -> 128 3x3 convolution under autograd on libsmokehip: the forward (k_conv2_fwd_b16), the data gradient
+    (k_conv2_dgrad_b16) and the weight / bias gradients (k_conv2_wgrad_b16); hip_forward / hip_wgrad = False leave that pass to
+    PyTorch-ROCm.  Raises off a ROCm device: no CPU fallback.
 
-    Why the forward is opt-in: the split-bf16 forward is 5e-6 (max-norm) from an fp64 convolution, MIOpen's fp32 one 4e-7, and in this
-    network the convolution feeds train-mode BatchNorm + ReLU: in fp64, noise of relative size 5e-7 / 5e-6 on its output moves
-    conv2.weight.grad by 4e-3 / 1.7e-2 (ReLU masks flip) -- the faster forward would leave the band PyTorch's own fp32 gradients stay in
-    (tests/test_hip_pipeline.py).  The data gradient has no such amplifier: its 5e-6 propagates linearly."""
+    The forward uses THREE bf16 terms per operand and six products (9e-7 max-norm from an fp64 convolution; MIOpen's fp32 Winograd: 4e-7),
+    not the two terms / three products of the gradients and of the eval encoder (5e-6): this output feeds train-mode BatchNorm + ReLU, and
+    in fp64, noise of relative size 5e-7 / 5e-6 on it moves conv2.weight.grad by 4e-3 / 1.7e-2 (ReLU masks flip) -- a three-product forward
+    took the full-loss gradients out of the band PyTorch's own fp32 run stays in (tests/test_hip_pipeline.py).  The gradients have no
+    such amplifier: their 5e-6 propagates linearly."""
     if not hip_conv2_train_supported(x, conv):
         raise ValueError("hip_conv2_train: a float32 ROCm tensor [B, 64, H, W] with H % 8 == 0, W % 16 == 0 and Conv2d(64, 128, 3, padding=1)")
     return _HipConv2Fn.apply(x, conv.weight, conv.bias, bool(hip_forward), bool(hip_wgrad))

@@ -63,8 +63,8 @@ def _hip_bn_ok(bn) -> bool:
             and bn.momentum is not None)
 
 
-# SMK_TRAIN_CONV2_HIP: "1" (default) conv2's data and weight gradients on libsmokehip ("dgrad": the data gradient only); "fwd" its forward too (faster, 5e-6 instead of 4e-7 from fp64:
-# models/conv.py says what that does to the gradients); "0" the whole convolution on PyTorch-ROCm
+# SMK_TRAIN_CONV2_HIP: "1" (default) conv2's forward and both gradients on libsmokehip; "grads" the gradients only; "dgrad" the data gradient only;
+# "0" the whole convolution on PyTorch-ROCm (diagnostic switches)
 _HIP_CONV2_TRAIN = os.environ.get("SMK_TRAIN_CONV2_HIP", "1")
 
 
@@ -178,7 +178,7 @@ class SmokePhysNet(nn.Module):
                 # libsmokehip: BatchNorm (batch statistics) + ReLU as two passes over the conv output, and for the second block
                 # the two average pools (one P x P block mean) in the same pass -- the 256 x 256 x 128 maps are never written
                 a1 = _bn_relu_pool(conv1(x), bn1, 1)
-                z2 = (hip_conv2_train(a1, conv2, hip_forward=_HIP_CONV2_TRAIN == "fwd", hip_wgrad=_HIP_CONV2_TRAIN != "dgrad")
+                z2 = (hip_conv2_train(a1, conv2, hip_forward=_HIP_CONV2_TRAIN not in ("grads", "dgrad"), hip_wgrad=_HIP_CONV2_TRAIN != "dgrad")
                       if (_HIP_CONV2_TRAIN != "0" and hip_conv2_train_supported(a1, conv2)) else conv2(a1))
                 return _bn_relu_pool(z2, bn2, P)
             encoded = x

@@ -300,7 +300,7 @@ def test_sync_bn_relu_pool_phases_equal_the_fused_call_and_full_batch_statistics
 @pytest.mark.parametrize("shape", [(2, 64, 64), (3, 40, 48), (1, 8, 16), (4, 256, 256)])
 def test_training_conv2_forward_vs_fp64_and_gradients_vs_autograd(shape):
     """smk_conv2_train_forward (k_conv2_fwd_b16): input_encoder's Conv2d(64, 128, 3, padding=1) under autograd (smokephys_net.py:28):
-    the forward within 1e-5 (max-norm) of an fp64 convolution, incl. frames that are not square, one tile only, and borders on every
+    the forward within 2e-6 (max-norm) of an fp64 convolution, incl. frames that are not square, one tile only, and borders on every
     side; the data gradient (smk_conv2_train_dgrad, k_conv2_dgrad_b16) within 1e-5 of fp64 autograd; the weight / bias gradients equal
     PyTorch-ROCm's own (they ARE its convolution_backward on the saved tensors)."""
     from smokephysai_amd.models.conv import hip_conv2_train, hip_conv2_train_supported
@@ -314,7 +314,7 @@ def test_training_conv2_forward_vs_fp64_and_gradients_vs_autograd(shape):
     z = hip_conv2_train(xa, conv, hip_forward=True)
     ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
     err = float((z.double() - ref).abs().max() / ref.abs().max())
-    assert err < 1e-5, err
+    assert err < 2e-6, err                                      # three bf16 terms per operand, six products (observed 9e-7; MIOpen fp32: 4e-7)
     dz = torch.randn(z.shape, device="cuda", generator=g)
     z.backward(dz)
     gw, gb, gx = conv.weight.grad.clone(), conv.bias.grad.clone(), xa.grad.clone()
