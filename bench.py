@@ -252,7 +252,7 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None):
            "collective_backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None,
            "grad_bytes_fp32": nparam * 4,
            "note": "forward + backward + gradient all-reduce (DDP, overlapped) + clip + AdamW; linear GEMMs, attention, LayerNorm and the "
-                   "encoder's BatchNorm/ReLU/pool, its second convolution (forward + both gradients), GELU/dropout/residual of the FFN on libsmokehip; the first convolution on PyTorch-ROCm (MIOpen)"})
+                   "encoder's BatchNorm/ReLU/pool, both of its convolutions, GELU/dropout/residual of the FFN on libsmokehip; the decoder head's transposed convolutions, the loss and AdamW on PyTorch-ROCm"})
     if dist is not None:
         res["ms_per_step_no_allreduce"] = timed(steps, sync=False)          # same step under ddp.no_sync(): what the exchange costs
         res["ddp_buckets"] = ddp_bucket_report(ddp)

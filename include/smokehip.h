@@ -267,6 +267,16 @@ int smk_bn_relu_pool_backward(const float *z, const float *dout, int32_t B, int3
                               const float *beta, const float *mean, const float *rstd, int32_t pool, float *dz, float *dgamma,
                               float *dbeta, void *workspace, void *stream);
 
+/* The encoder's first convolution for training: Conv2d(1, 64, 7, padding = 3) under autograd (smokephys_net.py:25; train.py:88-89), plain
+ * fp32 on the vector ALUs (its output feeds train-mode BatchNorm + ReLU: as exact as an fp32 convolution has to be).
+ *   forward: x [B][H][W] (the single input channel), weight [64][7][7], bias [64] or NULL -> z1 [B][64][H][W]; W % 4 == 0;
+ *   wgrad:   dz [B][64][H][W], x -> dW [64][7][7] and db [64] (unless NULL); H % 4 == 0, W % 64 == 0; per-workgroup partial sums added
+ *            in a fixed order (deterministic); `workspace`: smk_conv1_train_wgrad_workspace() bytes.
+ * (The input frames carry no gradient in train.py; a caller that needs dX keeps PyTorch-ROCm's.) */
+int smk_conv1_train_forward(const float *x, const float *weight, const float *bias, int32_t B, int32_t H, int32_t W, float *z1, void *stream);
+int64_t smk_conv1_train_wgrad_workspace(void);
+int smk_conv1_train_wgrad(const float *dz, const float *x, int32_t B, int32_t H, int32_t W, float *dw, float *db, void *workspace, void *stream);
+
 /* The encoder's second convolution alone, for training: z2 = Conv2d(64, 128, 3, padding = 1)(a1) + bias under autograd
  * (smokephys_net.py:28; train.py:88-89 -- train-mode BatchNorm needs the whole convolution output before it can normalise, so the
  * fused eval encoder does not apply).  a1 [B][64][H][W] and z2 [B][128][H][W] NCHW fp32, weight [128][64][3][3], bias [128] or NULL;

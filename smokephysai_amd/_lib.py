@@ -78,6 +78,8 @@ _SIGNATURES = {
     "smk_attention_backward": [C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_int64] * 7 + [C.c_double, C.c_void_p],
     "smk_lorenz_states": [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     "smk_ffn_elementwise": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p],
+    "smk_conv1_train_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
+    "smk_conv1_train_wgrad": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_conv2_train_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_conv2_train_dgrad": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_conv2_train_wgrad": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -100,7 +102,7 @@ _SIGNATURES = {
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
-EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace", "smk_conv2_train_workspace", "smk_conv2_train_wgrad_workspace"] + list(_SIGNATURES)
+EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace", "smk_conv2_train_workspace", "smk_conv2_train_wgrad_workspace", "smk_conv1_train_wgrad_workspace"] + list(_SIGNATURES)
 
 _lib = None
 
@@ -130,6 +132,8 @@ def load():
         L.smk_conv2_train_workspace.restype = C.c_int64
         L.smk_conv2_train_wgrad_workspace.argtypes = []
         L.smk_conv2_train_wgrad_workspace.restype = C.c_int64
+        L.smk_conv1_train_wgrad_workspace.argtypes = []
+        L.smk_conv1_train_wgrad_workspace.restype = C.c_int64
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

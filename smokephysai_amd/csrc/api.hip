@@ -849,6 +849,26 @@ static int bn_check(int32_t B, int32_t C, int32_t H, int32_t W, int32_t pool) {
     return SMK_OK;
 }
 
+int smk_conv1_train_forward(const float *x, const float *weight, const float *bias, int32_t B, int32_t H, int32_t W, float *z1, void *stream) {
+    SMK_REQUIRE(x && weight && z1, "null x/weight/z1");
+    if (B < 1 || H < 1 || W < 4 || W % 4 != 0 || B > 65535) {
+        set_error("conv1_train_forward: 1 <= B <= 65535, W a multiple of 4");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return check_launch(launch_conv1_train_forward(x, weight, bias, B, H, W, z1, (hipStream_t)stream), "conv1_train_forward");
+}
+
+int64_t smk_conv1_train_wgrad_workspace(void) { return (int64_t)conv1_wgrad_workspace_bytes(); }
+
+int smk_conv1_train_wgrad(const float *dz, const float *x, int32_t B, int32_t H, int32_t W, float *dw, float *db, void *workspace, void *stream) {
+    SMK_REQUIRE(dz && x && dw && workspace, "null dz/x/dw/workspace");
+    if (B < 1 || H < 4 || W < 64 || H % 4 != 0 || W % 64 != 0) {
+        set_error("conv1_train_wgrad: B >= 1, H a multiple of 4, W a multiple of 64");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return check_launch(launch_conv1_train_wgrad(dz, x, B, H, W, dw, db, workspace, (hipStream_t)stream), "conv1_train_wgrad");
+}
+
 int64_t smk_conv2_train_workspace(void) { return (int64_t)conv2_train_workspace_bytes(); }
 
 int smk_conv2_train_forward(const float *a1, const float *weight, const float *bias, int32_t B, int32_t H, int32_t W, float *z2,

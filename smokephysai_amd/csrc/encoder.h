@@ -41,6 +41,11 @@ hipError_t launch_encoder_i8(const float *frames, int64_t fstride, int B, int H,
 size_t conv2_train_workspace_bytes();
 // dX = the data gradient of the same convolution from dz [B][128][H][W] (same workspace size, its own contents)
 hipError_t launch_conv2_train_dgrad(const float *dz, const float *weight, int B, int H, int W, float *dx, void *workspace, hipStream_t st);
+// Training passes of the FIRST convolution (Conv2d(1, 64, 7, padding = 3)), fp32 on the vector ALUs: z1 = conv(x) + bias (W % 4 == 0) and
+// dW [64][7][7] / db [64] from dz [B][64][H][W] and x [B][H][W] (H % 4 == 0, W % 64 == 0; workspace conv1_wgrad_workspace_bytes()).
+size_t conv1_wgrad_workspace_bytes();
+hipError_t launch_conv1_train_forward(const float *x, const float *weight, const float *bias, int B, int H, int W, float *z1, hipStream_t st);
+hipError_t launch_conv1_train_wgrad(const float *dz, const float *x, int B, int H, int W, float *dw, float *db, void *workspace, hipStream_t st);
 // dW [128][64][3][3] (and db [128] unless NULL) of the same convolution from dz and a1; workspace: conv2_wgrad_workspace_bytes(conv2_wgrad_streams())
 size_t conv2_wgrad_workspace_bytes(int nstreams);
 int conv2_wgrad_streams();

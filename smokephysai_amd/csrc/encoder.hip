@@ -978,6 +978,174 @@ __global__ __launch_bounds__(256, 2) void k_encoder_b16(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The encoder's FIRST convolution for training (smokephys_net.py:25, Conv2d(1, 64, 7, padding=3) under autograd), in plain fp32 on the
+// vector ALUs -- 26 GFLOP per batch of 64 x 256^2, nothing for the matrix cores to win, and its output feeds train-mode BatchNorm +
+// ReLU, so it has to be as exact as an fp32 convolution (see k_conv2_fwd_b16).  Having both convolutions here also takes MIOpen's
+// find pass (20-50 s on a fresh machine for these two layers) out of the first training step.
+// k_conv1_train_fwd: z1[b][c][i][j] = bias[c] + sum over the 49 taps (ki-major, one fma chain) of x[b][i+ki-3][j+kj-3] * w[c][ki][kj].
+//   A workgroup = 4 rows x 256 columns; a thread = 4 consecutive pixels of one row, their 7 x 10 window of x in registers; the 64
+//   channels in turn, each channel's 49 weights as 13 broadcast ds_read_b128 for 196 fmas; z1 stored as float4.
+constexpr int C1_WP = 52;                                     // weights per channel in LDS (49 + 3 pad: 13 float4)
+__global__ __launch_bounds__(256) void k_conv1_train_fwd(const float *__restrict__ x, int H, int W, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, float *__restrict__ z1) {
+    __shared__ __attribute__((aligned(16))) float ws[64 * C1_WP];
+    __shared__ float xs[10][264];                             // rows i0-3 .. i0+6, columns j0-3 .. j0+258 (+ pad)
+    const int tid = threadIdx.x, b = blockIdx.z, i0 = blockIdx.y * 4, j0 = blockIdx.x * 256;
+    for (int k = tid; k < 64 * C1_WP; k += 256) {
+        const int c = k / C1_WP, t = k - c * C1_WP;
+        ws[k] = t < 49 ? w[c * 49 + t] : 0.f;
+    }
+    const float *xb = x + (size_t)b * H * W;
+    for (int k = tid; k < 10 * 262; k += 256) {
+        const int r = k / 262, cc = k - r * 262, ii = i0 - 3 + r, jj = j0 - 3 + cc;
+        xs[r][cc] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? xb[(size_t)ii * W + jj] : 0.f;
+    }
+    __syncthreads();
+    const int jq = tid & 63, row = tid >> 6;
+    float win[7][10];
+#pragma unroll
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 10; ++cc) win[r][cc] = xs[row + r][4 * jq + cc];
+    const int i = i0 + row, j = j0 + 4 * jq;
+    if (i >= H || j >= W) return;                             // (W % 4 == 0: a quad is inside or outside as a whole)
+    float *dst = z1 + ((size_t)b * 64 * H + i) * W + j;
+#pragma unroll 1
+    for (int c = 0; c < 64; ++c) {
+        float wv[C1_WP];
+#pragma unroll
+        for (int q = 0; q < C1_WP / 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(&ws[c * C1_WP + 4 * q]);
+            wv[4 * q] = t4.x; wv[4 * q + 1] = t4.y; wv[4 * q + 2] = t4.z; wv[4 * q + 3] = t4.w;
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ki = 0; ki < 7; ++ki)
+#pragma unroll
+            for (int kj = 0; kj < 7; ++kj)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p] = fmaf(win[ki][kj + p], wv[ki * 7 + kj], acc[p]);
+        const float bb = bias ? bias[c] : 0.f;
+        *reinterpret_cast<float4 *>(dst + (size_t)c * H * W) = make_float4(acc[0] + bb, acc[1] + bb, acc[2] + bb, acc[3] + bb);
+    }
+}
+
+// k_conv1_train_wgrad: dW[c][ki][kj] = sum over b, i, j of dz[b][c][i][j] * x[b][i+ki-3][j+kj-3] (and db[c] = sum of dz): an outer-product
+// accumulation over 4.2 M pixels.  A persistent workgroup walks tiles of 4 rows x 64 columns; dz of the tile sits in LDS as float4 per
+// (4-channel group, pixel), x as a 10 x 70 halo; a thread owns 4 channels x one kernel row (28 accumulators + 4 for db) for half of the
+// tile's rows: per pixel one ds_read_b128 of dz, one new x value into a 7-wide sliding window, 28 fmas.  Partials per workgroup, added in
+// workgroup order by k_conv1_wgrad_finish (deterministic).
+constexpr int C1G_PX = 4 * 64;                                // pixels per tile
+constexpr int C1G_ZP = C1G_PX * 4 + 4;                        // floats per channel group in LDS (+ 4: the 16 groups start on different banks)
+__global__ __launch_bounds__(256) void k_conv1_train_wgrad(const float *__restrict__ dz, const float *__restrict__ x, int H, int W, int tiles_x,
+                                                          int tiles_per_frame, int ntiles, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float smemf[];
+    float *zs = smemf;                                        // [16 groups][C1G_ZP]
+    float *xs = smemf + 16 * C1G_ZP;                          // [10][72]
+    const int tid = threadIdx.x;
+    const int st = tid / 112, rem = tid - st * 112, cg = rem / 7, ky = rem - cg * 7;      // tid >= 224: staging only
+    float acc[4][7], dbs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[c][k] = 0.f;
+    const size_t plane = (size_t)H * W;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / tiles_per_frame, rm = t - b * tiles_per_frame;
+        const int i0 = (rm / tiles_x) * 4, j0 = (rm % tiles_x) * 64;
+        // stage dz: (group g, pixel p) -> float4 of channels 4g .. 4g+3; 16 x 256 items, 16 per thread, lanes along the pixels
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int it = tid + 256 * k, g = it >> 8, p = it & 255, r = p >> 6, cc = p & 63;
+            const float *src = dz + ((size_t)b * 64 + 4 * g) * plane + (size_t)(i0 + r) * W + j0 + cc;
+            *reinterpret_cast<float4 *>(&zs[g * C1G_ZP + 4 * p]) = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+        }
+        const float *xb = x + (size_t)b * plane;
+        for (int k = tid; k < 10 * 70; k += 256) {
+            const int r = k / 70, cc = k - r * 70, ii = i0 - 3 + r, jj = j0 - 3 + cc;
+            xs[r * 72 + cc] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? xb[(size_t)ii * W + jj] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 224) {
+#pragma unroll 1
+            for (int r = 2 * st; r < 2 * st + 2; ++r) {
+                const float *xr = xs + (r + ky) * 72;         // x row i0 + r + ky - 3
+                float xv[7];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) xv[k + 1] = xr[k];
+#pragma unroll 4
+                for (int cc = 0; cc < 64; ++cc) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) xv[k] = xv[k + 1];
+                    xv[6] = xr[cc + 6];
+                    const float4 d = *reinterpret_cast<const float4 *>(&zs[cg * C1G_ZP + 4 * (r * 64 + cc)]);
+                    const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) acc[c][k] = fmaf(dv[c], xv[k], acc[c][k]);
+                        if (ky == 0) dbs[c] += dv[c];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the two row-halves of the workgroup: half 1 hands its sums to half 0 through LDS, half 0 stores the workgroup's partial
+    float *ex = smemf;                                        // [112][32]
+    if (st == 1 && tid < 224) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) ex[rem * 32 + c * 7 + k] = acc[c][k];
+            ex[rem * 32 + 28 + c] = dbs[c];
+        }
+    }
+    __syncthreads();
+    if (st == 0) {
+        float *dst = part + (size_t)blockIdx.x * (64 * 49 + 64);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) dst[(4 * cg + c) * 49 + ky * 7 + k] = acc[c][k] + ex[rem * 32 + c * 7 + k];
+            if (ky == 0) dst[64 * 49 + 4 * cg + c] = dbs[c] + ex[rem * 32 + 28 + c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_conv1_wgrad_finish(const float *__restrict__ part, int nparts, float *__restrict__ dw, float *__restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * 49 + 64) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * (64 * 49 + 64) + i];
+    if (i < 64 * 49) dw[i] = s;
+    else if (db) db[i - 64 * 49] = s;
+}
+
+constexpr int C1G_LDS = (16 * C1G_ZP + 10 * 72) * 4;          // 68,672 B
+int conv1_wgrad_parts() { return device_num_cu() * 2; }
+size_t conv1_wgrad_workspace_bytes() { return (size_t)conv1_wgrad_parts() * (64 * 49 + 64) * sizeof(float); }
+
+hipError_t launch_conv1_train_forward(const float *x, const float *weight, const float *bias, int B, int H, int W, float *z1, hipStream_t st) {
+    if (W % 4 != 0 || B < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_conv1_train_fwd, dim3(cdiv(W, 256), cdiv(H, 4), B), dim3(256), 0, st, x, H, W, weight, bias, z1);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv1_train_wgrad(const float *dz, const float *x, int B, int H, int W, float *dw, float *db, void *workspace, hipStream_t st) {
+    if (H % 4 != 0 || W % 64 != 0 || B < 1) return hipErrorInvalidValue;
+    const int tiles_x = W / 64, tiles_per_frame = tiles_x * (H / 4), ntiles = B * tiles_per_frame;
+    int nparts = conv1_wgrad_parts();
+    if (first_use_on_device((const void *)k_conv1_train_wgrad))
+        (void)hipFuncSetAttribute((const void *)k_conv1_train_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, C1G_LDS);
+    const int grid = nparts < ntiles ? nparts : ntiles;
+    float *part = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(k_conv1_train_wgrad, dim3(grid), dim3(256), C1G_LDS, st, dz, x, H, W, tiles_x, tiles_per_frame, ntiles, part);
+    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3(cdiv(64 * 49 + 64, 256)), dim3(256), 0, st, part, grid, dw, db);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_conv2_fwd_b16: the encoder's second convolution alone, for TRAINING (smokephys_net.py:28, Conv2d(64, 128, 3, padding=1) under
 // autograd): z2 = conv(a1, w) + bias with a1 the activated first block [B, 64, H, W] and z2 [B, 128, H, W], both NCHW fp32 in HBM
 // (train-mode BatchNorm needs the whole z2 before it can normalise, so nothing fuses across it).  The tile (8 x 16 pixels, 180-pixel

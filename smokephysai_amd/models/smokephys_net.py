@@ -26,7 +26,7 @@ from .encoder import HipEncoder, encoder_weight_dict
 from .hip_body import HipBody
 from .ffn import hip_dropout_add, hip_ffn_elementwise_supported, hip_gelu_dropout
 from .linear import TrainableHipLinear, hip_linear_supported
-from .conv import hip_conv2_train, hip_conv2_train_supported
+from .conv import hip_conv1_train, hip_conv1_train_supported, hip_conv2_train, hip_conv2_train_supported
 from .norm import hip_bn_relu_pool, hip_sync_bn_relu_pool
 from .sync_bn import SyncBatchNorm2d
 from .physics_regularizer import PhysicsRegularizer
@@ -66,6 +66,7 @@ def _hip_bn_ok(bn) -> bool:
 # SMK_TRAIN_CONV2_HIP: "1" (default) conv2's forward and both gradients on libsmokehip; "grads" the gradients only; "dgrad" the data gradient only;
 # "0" the whole convolution on PyTorch-ROCm (diagnostic switches)
 _HIP_CONV2_TRAIN = os.environ.get("SMK_TRAIN_CONV2_HIP", "1")
+_HIP_CONV1_TRAIN = os.environ.get("SMK_TRAIN_CONV1_HIP", "1") != "0"      # diagnostic: 0 keeps the first convolution on PyTorch-ROCm
 
 
 def _bn_relu_pool(z, bn, pool):
@@ -177,7 +178,8 @@ class SmokePhysNet(nn.Module):
                     and pool.output_size[0] == pool.output_size[1] and H % mid == 0 and mid % 32 == 0):
                 # libsmokehip: BatchNorm (batch statistics) + ReLU as two passes over the conv output, and for the second block
                 # the two average pools (one P x P block mean) in the same pass -- the 256 x 256 x 128 maps are never written
-                a1 = _bn_relu_pool(conv1(x), bn1, 1)
+                z1 = hip_conv1_train(x, conv1) if (_HIP_CONV1_TRAIN and hip_conv1_train_supported(x, conv1)) else conv1(x)
+                a1 = _bn_relu_pool(z1, bn1, 1)
                 z2 = (hip_conv2_train(a1, conv2, hip_forward=_HIP_CONV2_TRAIN not in ("grads", "dgrad"), hip_wgrad=_HIP_CONV2_TRAIN != "dgrad")
                       if (_HIP_CONV2_TRAIN != "0" and hip_conv2_train_supported(a1, conv2)) else conv2(a1))
                 return _bn_relu_pool(z2, bn2, P)
