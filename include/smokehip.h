@@ -215,7 +215,8 @@ int smk_linear_update(smk_linear *lin, const float *weight, int32_t transposed, 
  * (deterministic).  `workspace`: smk_linear_wgrad_workspace(rows, out, in) bytes of device memory, 16-byte aligned, owned by the
  * caller and free for reuse once the enqueued work has run.  Requires in_features % 32 == 0, out_features % 4 == 0,
  * (out_features + 256) * (rows + 4096) < 2^30 (longer inputs: call per row chunk and add).  db (may be NULL): the bias gradient
- * [out_features] = column sums of dy, taken while the call transposes dy (partials per 32-row block, added in a fixed order).  Enqueued on `stream`. */
+ * [out_features] = column sums of dy (partials per row segment, added in a fixed order).  With out_features and in_features multiples of 128
+ * neither operand is copied: both are staged as they lie and read back transposed from LDS (ds_read_b64_tr_b16).  Enqueued on `stream`. */
 int64_t smk_linear_wgrad_workspace(int64_t rows, int32_t out_features, int32_t in_features);
 int smk_linear_wgrad(const float *dy, int64_t ld_dy, const float *x, int64_t ldx, int64_t rows, int32_t out_features,
                      int32_t in_features, float *dw, float *db, void *workspace, int64_t workspace_bytes, void *stream);

@@ -672,6 +672,177 @@ __global__ __launch_bounds__(256) void k_sum_segments(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_linear_wgrad_tr: dW[out][in] = sum over the token rows of dY[row][out] * X[row][in] WITHOUT the transposed copy of dY and the
+// re-laid-out copy of X (k_transpose_pad + k_split_linear_weights_t16: 6 ms of a 64 ms step).  The token rows are the MFMA k
+// dimension, and both operands are feature-contiguous in memory, i.e. k-STRIDED: they are staged row-major as they lie (coalesced
+// 512-byte row pieces, split into bf16 hi / lo planes on the way into LDS) and read back TRANSPOSED by gfx950's ds_read_b64_tr_b16
+// (a 16-lane group reads a 4-row x 16-column block and lane i receives column i of the four rows: four consecutive k of one feature).
+//   workgroup: a 128 x 128 tile of dW for one segment of the rows; wave (wm, wn): 64 x 64 (4 x 4 MFMA tiles, 64 accumulators).
+//   chunk:     32 rows = one k-step; LDS image per operand and plane [32 rows][128 features] bf16, row pitch 288 B: with group g reading rows
+//              4g .. 4g+3 and 16+4g .. 16+4g+3 (the k order inside a k-step is free as long as both operands share it) the 32 lanes of a
+//              half touch 64 distinct banks.  Double buffered: the next chunk's global loads are in flight under this chunk's MFMAs.
+//   output:    partial [segment][out][in]; k_sum_segments adds the segments in order; the bias gradient's partial column sums of dY come
+//              from the staging registers of the workgroups with in-tile 0 (k_col_finish adds them in order).
+constexpr int WT_PITCH = 288;                                 // bytes per staged row (128 bf16 + 32 pad)
+constexpr int WT_PLANE = 32 * WT_PITCH;                       // 9,216
+constexpr int WT_LDS = 2 * 4 * WT_PLANE;                      // two buffers x (dY hi, dY lo, X hi, X lo) = 73,728
+
+struct WgradTrArgs {
+    const float *dy, *x;
+    long long ld_dy, ldx, rows, rows_per_seg;
+    int out_f, in_f, tiles_n, ntiles, nseg;
+    float *part, *dbpart;
+};
+
+__global__ __launch_bounds__(256, 2) void k_linear_wgrad_tr(WgradTrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave & 1, wn = wave >> 1;
+    // blocks i and i + 8 share an XCD: consecutive slots of one XCD take the tiles of ONE segment (they read the same rows of dY and X)
+    int seg, tile;
+    if ((a.nseg & 7) == 0) {
+        const int slot = blockIdx.x >> 3;
+        tile = slot % a.ntiles;
+        seg = (slot / a.ntiles) * 8 + (blockIdx.x & 7);
+    } else {
+        tile = blockIdx.x % a.ntiles;
+        seg = blockIdx.x / a.ntiles;
+    }
+    const int tm = tile / a.tiles_n, tn = tile - tm * a.tiles_n;
+    const long long row0 = (long long)seg * a.rows_per_seg;
+    long long row1 = row0 + a.rows_per_seg;
+    row1 = row1 < a.rows ? row1 : a.rows;
+    const float *dyb = a.dy + (size_t)tm * 128, *xb = a.x + (size_t)tn * 128;
+    // staging map: thread -> rows (tid >> 5) + 8 j (j = 0..3) of the chunk, features 4 (tid & 31) .. + 3
+    const int srow = tid >> 5, sq = tid & 31;
+    float4 ry[4], rx[4];
+    float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](long long r0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long r = r0 + srow + 8 * j;
+            const bool ok = r < row1;
+            const long long rc = ok ? r : row0;                // (clamped address, value zeroed: no divergent load)
+            ry[j] = *reinterpret_cast<const float4 *>(dyb + (size_t)rc * a.ld_dy + 4 * sq);
+            rx[j] = *reinterpret_cast<const float4 *>(xb + (size_t)rc * a.ldx + 4 * sq);
+            if (!ok) { ry[j] = make_float4(0.f, 0.f, 0.f, 0.f); rx[j] = ry[j]; }
+        }
+    };
+    auto stash = [&](int buf) {
+        unsigned char *base = smem + buf * 4 * WT_PLANE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = (srow + 8 * j) * WT_PITCH + 8 * sq;
+            const float fy[4] = {ry[j].x, ry[j].y, ry[j].z, ry[j].w}, fx[4] = {rx[j].x, rx[j].y, rx[j].z, rx[j].w};
+            bf16x4 yh, yl, xh, xl;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const __bf16 h1 = (__bf16)fy[c], h2 = (__bf16)fx[c];
+                yh[c] = h1; yl[c] = (__bf16)(fy[c] - (float)h1);
+                xh[c] = h2; xl[c] = (__bf16)(fx[c] - (float)h2);
+                dbs[c] += fy[c];
+            }
+            *reinterpret_cast<bf16x4 *>(base + off) = yh;
+            *reinterpret_cast<bf16x4 *>(base + WT_PLANE + off) = yl;
+            *reinterpret_cast<bf16x4 *>(base + 2 * WT_PLANE + off) = xh;
+            *reinterpret_cast<bf16x4 *>(base + 3 * WT_PLANE + off) = xl;
+        }
+    };
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[m][n][g] = 0.f;
+    // transposed-read addresses: 16-lane group g = lane >> 4; lane 4q + p of it supplies row (4g + q [+ 16]), features 16 t + 4p .. + 3
+    const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int tr_off = (4 * g16 + q) * WT_PITCH + 8 * pp;
+    auto frag = [&](const unsigned char *plane, int col0) -> bf16x8 {      // 8 k of feature col0 + (lane & 15): rows 4g..4g+3, 16+4g..16+4g+3
+        const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3))) *)(plane + tr_off + 2 * col0));
+        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3))) *)(plane + tr_off + 16 * WT_PITCH + 2 * col0));
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r[e] = lo4[e]; r[4 + e] = hi4[e]; }
+        return r;
+    };
+    const long long nchunks = (row1 - row0 + 31) / 32;
+    if (nchunks > 0) {
+        fetch(row0);
+        stash(0);
+    }
+    __syncthreads();
+    for (long long c = 0; c < nchunks; ++c) {
+        const int buf = (int)(c & 1);
+        if (c + 1 < nchunks) fetch(row0 + 32 * (c + 1));      // in flight under this chunk's MFMAs
+        const unsigned char *base = smem + buf * 4 * WT_PLANE;
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            ah[m] = frag(base, 64 * wm + 16 * m);
+            al[m] = frag(base + WT_PLANE, 64 * wm + 16 * m);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const bf16x8 bh = frag(base + 2 * WT_PLANE, 64 * wn + 16 * n), bl = frag(base + 3 * WT_PLANE, 64 * wn + 16 * n);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4v &cc = acc[m][n];
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, cc, 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // partial [seg][out][in]: lane (n15 = lane & 15, kg = lane >> 4) of tile (m, n) holds rows 4kg + r (out) of column n15 (in)
+    float *dst = a.part + ((size_t)seg * a.out_f + (size_t)tm * 128 + 64 * wm) * a.in_f + (size_t)tn * 128 + 64 * wn;
+    const int n15 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)(16 * m + 4 * kg + r) * a.in_f + 16 * n + n15] = acc[m][n][r];
+    if (a.dbpart && tn == 0) {                                // column sums of this segment's dY rows: 8 staging threads per feature quad
+        float *ex = reinterpret_cast<float *>(smem);           // [8][128]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ex[srow * 128 + 4 * sq + c] = dbs[c];
+        __syncthreads();
+        if (tid < 128) {
+            float sdb = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sdb += ex[k * 128 + tid];
+            a.dbpart[(size_t)seg * a.out_f + (size_t)tm * 128 + tid] = sdb;
+        }
+    }
+}
+
+struct WgradTrPlan { bool ok; int nseg, tiles_m, tiles_n; long long rows_per_seg; size_t bytes; };
+static WgradTrPlan plan_wgrad_tr(long long rows, int out_f, int in_f, long long ld_dy, long long ldx) {
+    WgradTrPlan p{};
+    static const bool off = [] { const char *e = getenv("SMK_LINEAR_WGRAD_TR"); return e && e[0] == '0'; }();
+    p.ok = !off && out_f % 128 == 0 && in_f % 128 == 0 && ld_dy % 4 == 0 && ldx % 4 == 0 && rows >= 32;
+    if (!p.ok) return p;
+    p.tiles_m = out_f / 128; p.tiles_n = in_f / 128;
+    const int tiles = p.tiles_m * p.tiles_n;
+    int nseg = 2 * device_num_cu() / tiles;
+    if (nseg >= 8) nseg &= ~7;
+    const long long max_seg = rows / 256 > 0 ? rows / 256 : 1;      // segments of at least 256 rows
+    if (nseg > max_seg) nseg = (int)max_seg;
+    if (nseg < 1) nseg = 1;
+    if (nseg >= 8) nseg &= ~7;
+    p.nseg = nseg;
+    p.rows_per_seg = ((rows + nseg - 1) / nseg + 31) / 32 * 32;
+    p.bytes = ((size_t)nseg * out_f * in_f + (size_t)nseg * out_f) * sizeof(float);
+    return p;
+}
+
 WgradPlan plan_linear_wgrad(long long rows, int out_f, int in_f) {
     WgradPlan p;
     const long long tiles = (long long)cdiv(out_f, 128) * cdiv(in_f, 128);
@@ -684,11 +855,31 @@ WgradPlan plan_linear_wgrad(long long rows, int out_f, int in_f) {
     p.off_part = p.off_wq + (size_t)p.rows_pad * in_f * 2 * sizeof(unsigned short);
     p.off_col = p.off_part + (nseg > 1 ? (size_t)nseg * out_f * in_f * sizeof(float) : 0);      // bias-gradient partials [rows_pad / 32][out]
     p.bytes = p.off_col + (size_t)(p.rows_pad / 32) * out_f * sizeof(float);
+    const WgradTrPlan t = plan_wgrad_tr(rows, out_f, in_f, 4, 4);      // the transposed-read form needs only its partial sums
+    if (t.ok && t.bytes > p.bytes) p.bytes = t.bytes;
     return p;
 }
 
 hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x, long long ldx, long long rows, int out_f, int in_f,
                                float *dw, float *db, void *workspace, hipStream_t st) {
+    const WgradTrPlan t = plan_wgrad_tr(rows, out_f, in_f, ld_dy, ldx);
+    if (t.ok && (reinterpret_cast<size_t>(dy) & 15) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) {
+        WgradTrArgs a;
+        a.dy = dy; a.x = x; a.ld_dy = ld_dy; a.ldx = ldx; a.rows = rows; a.rows_per_seg = t.rows_per_seg;
+        a.out_f = out_f; a.in_f = in_f; a.tiles_n = t.tiles_n; a.ntiles = t.tiles_m * t.tiles_n; a.nseg = t.nseg;
+        a.part = t.nseg > 1 ? reinterpret_cast<float *>(workspace) : dw;
+        a.dbpart = db ? reinterpret_cast<float *>(workspace) + (size_t)t.nseg * out_f * in_f : nullptr;
+        if (first_use_on_device((const void *)k_linear_wgrad_tr))
+            (void)hipFuncSetAttribute((const void *)k_linear_wgrad_tr, hipFuncAttributeMaxDynamicSharedMemorySize, WT_LDS);
+        hipLaunchKernelGGL(k_linear_wgrad_tr, dim3(a.ntiles * t.nseg), dim3(256), WT_LDS, st, a);
+        if (t.nseg > 1) {
+            const long long n4 = (long long)out_f * in_f / 4;
+            const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+            hipLaunchKernelGGL(k_sum_segments, dim3(blocks), dim3(256), 0, st, a.part, t.nseg, n4, dw);
+        }
+        if (db) hipLaunchKernelGGL(k_col_finish, dim3(cdiv(out_f, 16)), dim3(256), 0, st, a.dbpart, t.nseg, out_f, db);
+        return hipGetLastError();
+    }
     const WgradPlan p = plan_linear_wgrad(rows, out_f, in_f);
     float *dyt = reinterpret_cast<float *>(workspace);
     LinearDev l;
