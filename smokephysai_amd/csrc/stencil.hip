@@ -4,6 +4,9 @@
 // reference elementwise op (file is compiled with -ffp-contract=off; divides/sqrt are the correctly rounded
 // forms), so velocity/pressure/density grids are bit-identical to the torch-CPU reference for identical inputs.
 // Reference: /root/reference/src/physics/navier_stokes.py (lines cited per kernel).
+#include <map>
+#include <mutex>
+
 #include "stencil.h"
 
 #include <math.h>
@@ -912,6 +915,28 @@ static bool use_persist(const Geom &g, const ProjectSync *ps, int iters, JacobiP
     return persist_chunks(g, pl, iters, chunks);
 }
 
+// Two persistent projections cannot share the device: each needs all of its workgroups resident at once, and two half-resident grids
+// would wait for each other until their spins run out.  Launches from ONE stream are ordered anyway; when a launch comes on a different
+// stream than the previous one (of this process, on this device), the new stream is made to wait for everything submitted to the previous
+// one (an event recorded there now) -- no host stall, and nothing at all in the single-stream case.  Other PROCESSES on the device are
+// beyond this: see the bounded waits.
+static void order_persistent_launch(hipStream_t st) {
+    struct Last { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; bool any = false; };
+    static std::mutex mu;
+    static std::map<int, Last> last;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    Last &l = last[dev];
+    if (l.any && l.stream != st) {
+        if (!l.ev) (void)hipEventCreateWithFlags(&l.ev, hipEventDisableTiming);
+        if (l.ev && hipEventRecord(l.ev, l.stream) == hipSuccess) (void)hipStreamWaitEvent(st, l.ev, 0);
+        else (void)hipGetLastError();                         // (the previous stream may have been destroyed: nothing of it is left to wait for)
+    }
+    l.stream = st;
+    l.any = true;
+}
+
 hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st, ProjectSync *ps,
                           const StateView *fold_in, float *fold_d_out, bool *folded) {
     JacobiPlan pl;
@@ -937,6 +962,7 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
         sy.base = ps->seq; sy.chunks = chunks; sy.nb = pl.nb; sy.abort_slot = ps->flags_len - 1; sy.fault = knobs().fault ? 1 : 0;
         sy.timeout_ticks = knobs().fault ? 200000ll : 50000000ll;      // 100 MHz wall clock: 2 ms under fault injection, 0.5 s otherwise
         ps->seq += (unsigned)chunks;
+        order_persistent_launch(st);
         // the buoyancy + diffusion stage as this launch's prologue (16-byte row accesses: pitches in multiples of 4; up to 4 cells per lane)
         const bool fold = fold_in && fold_d_out && knobs().fold && pl.vec <= 4 && g.pv % 4 == 0 && g.pc % 4 == 0;
         if (fold) {

@@ -131,3 +131,40 @@ def test_time_steps_recorded_in_a_hip_graph_replay_bit_identically():
     for k in ("u", "v", "p", "density"):
         assert torch.equal(getattr(eager, k), getattr(graphed, k)), k
     assert torch.equal(fa, fb)
+
+
+def test_two_simulators_on_two_streams_do_not_starve_each_other():
+    """Two chip-filling simulators stepped alternately on two streams of one process: their persistent projections cannot be co-resident, so
+    the library orders the second stream behind the first (an event, no host stall).  No timed-out wait, results == a one-stream run."""
+    import time
+    import torch
+    sys.path.insert(0, ROOT)
+    from smokephysai_amd.physics import NavierStokesSimulator
+    B, N, steps = 64, 256, 6
+    srcs = [(b, 30 + 3 * b, 220 - 2 * b, 5 + b % 7, 1.0 + 0.02 * b) for b in range(B)]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    sims, frames = [], []
+    for st in (s1, s2):
+        with torch.cuda.stream(st):
+            ns = NavierStokesSimulator((N, N), batch_size=B, jacobi_iters=100)
+            ns.add_smoke_sources(srcs)
+            sims.append(ns)
+            frames.append(torch.empty(B, N, N, device="cuda"))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        for ns, fr, st in zip(sims, frames, (s1, s2)):
+            with torch.cuda.stream(st):
+                ns.step_into(fr, 1)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0                                  # (a starved pair would sit in 0.5 s waits)
+    ref = NavierStokesSimulator((N, N), batch_size=B, jacobi_iters=100)
+    ref.add_smoke_sources(srcs)
+    fr = torch.empty(B, N, N, device="cuda")
+    for _ in range(steps):
+        ref.step_into(fr, 1)
+    torch.cuda.synchronize()
+    for ns, f in zip(sims, frames):
+        for k in ("u", "v", "p", "density"):
+            assert torch.equal(getattr(ns, k), getattr(ref, k)), k
+        assert torch.equal(f, fr)
