@@ -719,23 +719,25 @@ __global__ __launch_bounds__(256, 2) void k_linear_wgrad_tr(WgradTrArgs a) {
     const int srow = tid >> 5, sq = tid & 31;
     float4 ry[4], rx[4];
     float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+    // (rows past the segment: the ADDRESS is clamped here and the VALUE zeroed in stash -- overwriting a loaded register under a condition
+    // makes the compiler wait for that load on the spot, which serialised the four load pairs of a chunk in front of its MFMAs: 2.4 us per chunk)
     auto fetch = [&](long long r0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long long r = r0 + srow + 8 * j;
-            const bool ok = r < row1;
-            const long long rc = ok ? r : row0;                // (clamped address, value zeroed: no divergent load)
+            const long long rc = r < row1 ? r : row0;
             ry[j] = *reinterpret_cast<const float4 *>(dyb + (size_t)rc * a.ld_dy + 4 * sq);
             rx[j] = *reinterpret_cast<const float4 *>(xb + (size_t)rc * a.ldx + 4 * sq);
-            if (!ok) { ry[j] = make_float4(0.f, 0.f, 0.f, 0.f); rx[j] = ry[j]; }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, long long r0) {
         unsigned char *base = smem + buf * 4 * WT_PLANE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int off = (srow + 8 * j) * WT_PITCH + 8 * sq;
-            const float fy[4] = {ry[j].x, ry[j].y, ry[j].z, ry[j].w}, fx[4] = {rx[j].x, rx[j].y, rx[j].z, rx[j].w};
+            const float keep = (r0 + srow + 8 * j) < row1 ? 1.f : 0.f;
+            const float fy[4] = {ry[j].x * keep, ry[j].y * keep, ry[j].z * keep, ry[j].w * keep};
+            const float fx[4] = {rx[j].x * keep, rx[j].y * keep, rx[j].z * keep, rx[j].w * keep};
             bf16x4 yh, yl, xh, xl;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_wgrad_tr(WgradTrArgs a) {
     const long long nchunks = (row1 - row0 + 31) / 32;
     if (nchunks > 0) {
         fetch(row0);
-        stash(0);
+        stash(0, row0);
     }
     __syncthreads();
     for (long long c = 0; c < nchunks; ++c) {
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_wgrad_tr(WgradTrArgs a) {
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, cc, 0, 0, 0);
             }
         }
-        if (c + 1 < nchunks) stash(buf ^ 1);
+        if (c + 1 < nchunks) stash(buf ^ 1, row0 + 32 * (c + 1));
         __syncthreads();
     }
     // partial [seg][out][in]: lane (n15 = lane & 15, kg = lane >> 4) of tile (m, n) holds rows 4kg + r (out) of column n15 (in)
