@@ -715,29 +715,49 @@ __global__ __launch_bounds__(256, 2) void k_linear_wgrad_tr(WgradTrArgs a) {
     long long row1 = row0 + a.rows_per_seg;
     row1 = row1 < a.rows ? row1 : a.rows;
     const float *dyb = a.dy + (size_t)tm * 128, *xb = a.x + (size_t)tn * 128;
-    // staging map: thread -> rows (tid >> 5) + 8 j (j = 0..3) of the chunk, features 4 (tid & 31) .. + 3
+    // staging map: thread -> rows (tid >> 5) + 8 j (j = 0..3) of the chunk, features 4 (tid & 31) .. + 3.  Addresses = a wave-uniform chunk base
+    // (scalar registers, advanced per chunk on the scalar unit) + a per-thread 32-bit byte offset computed once: no vector address arithmetic
+    // in the loop (it was ~70 of the loop's ~300 vector instructions).
     const int srow = tid >> 5, sq = tid & 31;
+    unsigned voy[4], vox[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        voy[j] = (unsigned)(((size_t)(srow + 8 * j) * a.ld_dy + 4 * sq) * sizeof(float));
+        vox[j] = (unsigned)(((size_t)(srow + 8 * j) * a.ldx + 4 * sq) * sizeof(float));
+    }
     float4 ry[4], rx[4];
     float dbs[4] = {0.f, 0.f, 0.f, 0.f};
-    // (rows past the segment: the ADDRESS is clamped here and the VALUE zeroed in stash -- overwriting a loaded register under a condition
-    // makes the compiler wait for that load on the spot, which serialised the four load pairs of a chunk in front of its MFMAs: 2.4 us per chunk)
-    auto fetch = [&](long long r0) {
+    // FULL chunks (all 32 rows inside the segment) load and split unconditionally; only a segment's last, partial chunk clamps its addresses and
+    // zeroes the rows past the end (at the split: overwriting a loaded register under a condition makes the compiler wait for that load on the spot)
+    auto fetch = [&](long long r0, bool partial) {
+        const unsigned char *cy = reinterpret_cast<const unsigned char *>(dyb) + (size_t)r0 * a.ld_dy * sizeof(float);
+        const unsigned char *cx = reinterpret_cast<const unsigned char *>(xb) + (size_t)r0 * a.ldx * sizeof(float);
+        if (!partial) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long r = r0 + srow + 8 * j;
-            const long long rc = r < row1 ? r : row0;
-            ry[j] = *reinterpret_cast<const float4 *>(dyb + (size_t)rc * a.ld_dy + 4 * sq);
-            rx[j] = *reinterpret_cast<const float4 *>(xb + (size_t)rc * a.ldx + 4 * sq);
+            for (int j = 0; j < 4; ++j) {
+                ry[j] = *reinterpret_cast<const float4 *>(cy + voy[j]);
+                rx[j] = *reinterpret_cast<const float4 *>(cx + vox[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = r0 + srow + 8 * j < row1;
+                ry[j] = *reinterpret_cast<const float4 *>(cy + (ok ? voy[j] : voy[0]));      // (row r0 itself is inside)
+                rx[j] = *reinterpret_cast<const float4 *>(cx + (ok ? vox[j] : vox[0]));
+            }
         }
     };
-    auto stash = [&](int buf, long long r0) {
+    auto stash = [&](int buf, long long r0, bool partial) {
         unsigned char *base = smem + buf * 4 * WT_PLANE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int off = (srow + 8 * j) * WT_PITCH + 8 * sq;
-            const float keep = (r0 + srow + 8 * j) < row1 ? 1.f : 0.f;
-            const float fy[4] = {ry[j].x * keep, ry[j].y * keep, ry[j].z * keep, ry[j].w * keep};
-            const float fx[4] = {rx[j].x * keep, rx[j].y * keep, rx[j].z * keep, rx[j].w * keep};
+            const float keep = (!partial || (r0 + srow + 8 * j) < row1) ? 1.f : 0.f;
+            float fy[4] = {ry[j].x, ry[j].y, ry[j].z, ry[j].w}, fx[4] = {rx[j].x, rx[j].y, rx[j].z, rx[j].w};
+            if (partial) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { fy[c] *= keep; fx[c] *= keep; }
+            }
             bf16x4 yh, yl, xh, xl;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -772,15 +792,19 @@ __global__ __launch_bounds__(256, 2) void k_linear_wgrad_tr(WgradTrArgs a) {
         for (int e = 0; e < 4; ++e) { r[e] = lo4[e]; r[4 + e] = hi4[e]; }
         return r;
     };
-    const long long nchunks = (row1 - row0 + 31) / 32;
+    const long long nchunks = (row1 - row0 + 31) / 32, nfull = (row1 - row0) / 32;      // nchunks - nfull = 0 or 1
     if (nchunks > 0) {
-        fetch(row0);
-        stash(0, row0);
+        fetch(row0, nfull == 0);
+        stash(0, row0, nfull == 0);
     }
     __syncthreads();
     for (long long c = 0; c < nchunks; ++c) {
         const int buf = (int)(c & 1);
-        if (c + 1 < nchunks) fetch(row0 + 32 * (c + 1));      // in flight under this chunk's MFMAs
+        const bool next_partial = c + 1 >= nfull;             // wave-uniform
+        if (c + 1 < nchunks) {
+            if (next_partial) fetch(row0 + 32 * (c + 1), true);
+            else fetch(row0 + 32 * (c + 1), false);           // in flight under this chunk's MFMAs
+        }
         const unsigned char *base = smem + buf * 4 * WT_PLANE;
         bf16x8 ah[4], al[4];
 #pragma unroll
@@ -799,7 +823,10 @@ __global__ __launch_bounds__(256, 2) void k_linear_wgrad_tr(WgradTrArgs a) {
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, cc, 0, 0, 0);
             }
         }
-        if (c + 1 < nchunks) stash(buf ^ 1, row0 + 32 * (c + 1));
+        if (c + 1 < nchunks) {
+            if (next_partial) stash(buf ^ 1, row0 + 32 * (c + 1), true);
+            else stash(buf ^ 1, row0 + 32 * (c + 1), false);
+        }
         __syncthreads();
     }
     // partial [seg][out][in]: lane (n15 = lane & 15, kg = lane >> 4) of tile (m, n) holds rows 4kg + r (out) of column n15 (in)
