@@ -996,9 +996,12 @@ __global__ __launch_bounds__(256) void k_conv1_train_fwd(const float *__restrict
         ws[k] = t < 49 ? w[c * 49 + t] : 0.f;
     }
     const float *xb = x + (size_t)b * H * W;
+    // (addresses clamped into the image, values zeroed afterwards: a load under a condition is waited for before the next one is issued)
     for (int k = tid; k < 10 * 262; k += 256) {
         const int r = k / 262, cc = k - r * 262, ii = i0 - 3 + r, jj = j0 - 3 + cc;
-        xs[r][cc] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? xb[(size_t)ii * W + jj] : 0.f;
+        const int ci = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii), cj = jj < 0 ? 0 : (jj > W - 1 ? W - 1 : jj);
+        const float v = xb[(size_t)ci * W + cj];
+        xs[r][cc] = (ii == ci && jj == cj) ? v : 0.f;
     }
     __syncthreads();
     const int jq = tid & 63, row = tid >> 6;
@@ -1063,7 +1066,9 @@ __global__ __launch_bounds__(256) void k_conv1_train_wgrad(const float *__restri
         const float *xb = x + (size_t)b * plane;
         for (int k = tid; k < 10 * 70; k += 256) {
             const int r = k / 70, cc = k - r * 70, ii = i0 - 3 + r, jj = j0 - 3 + cc;
-            xs[r * 72 + cc] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? xb[(size_t)ii * W + jj] : 0.f;
+            const int ci = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii), cj = jj < 0 ? 0 : (jj > W - 1 ? W - 1 : jj);
+            const float v = xb[(size_t)ci * W + cj];            // (clamped address, value zeroed: no load under a condition)
+            xs[r * 72 + cc] = (ii == ci && jj == cj) ? v : 0.f;
         }
         __syncthreads();
         if (tid < 224) {
