@@ -353,7 +353,7 @@ def parse_args(argv=None):
                          "under DistributedDataParallel when N > 1: the RCCL gradient all-reduce).  On by default at every N, so that the "
                          "1 -> N curve of the DDP step has its N = 1 point (adds about a minute: MIOpen tunes its convolutions on first use)")
     ap.add_argument("--no-train-step", dest="train_step", action="store_false", help="skip the train-step leg (profiling runs)")
-    ap.add_argument("--train-step-limit", type=float, default=420.0,
+    ap.add_argument("--train-step-limit", type=float, default=240.0,
                     help="seconds after which a stuck train-step leg is abandoned: rank 0 prints the headline line without it")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     ap.add_argument("--dry-run", action="store_true", help="self-launch only: print the child command as JSON and exit")
