@@ -351,7 +351,7 @@ def parse_args(argv=None):
     ap.add_argument("--train-step", dest="train_step", action="store_true", default=True,
                     help="time train.py's optimisation step (BASELINE configs[3]'s per-GPU shape: --batch frames of --grid^2, full model; "
                          "under DistributedDataParallel when N > 1: the RCCL gradient all-reduce).  On by default at every N, so that the "
-                         "1 -> N curve of the DDP step has its N = 1 point (adds about a minute: MIOpen tunes its convolutions on first use)")
+                         "1 -> N curve of the DDP step has its N = 1 point (adds about 20 s)")
     ap.add_argument("--no-train-step", dest="train_step", action="store_false", help="skip the train-step leg (profiling runs)")
     ap.add_argument("--train-step-limit", type=float, default=240.0,
                     help="seconds after which a stuck train-step leg is abandoned: rank 0 prints the headline line without it")
