@@ -195,7 +195,7 @@ def attach_counters(out, encoder_dtype):
         out["roofline_encoder"]["pmc"] = d
 
 
-def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None):
+def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None, force_dist=False):
     """train.py's step (zero_grad, batch_losses, backward, clip 1.0, AdamW) on a device-built batch of B frames per rank
     (BASELINE configs[3]'s per-GPU shape), the model wrapped by utils.distributed.wrap_ddp exactly like train.py:main does:
     with N > 1 ranks the 27.8 M fp32 gradients (111 MB) are all-reduced over RCCL in 64 MB buckets overlapped with backward.
@@ -204,10 +204,22 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None):
     from smokephysai_amd.models import SmokePhysNet
     from smokephysai_amd.models.physics_regularizer import PhysicsRegularizer
     from smokephysai_amd.utils.distributed import ddp_bucket_report, wrap_ddp
+    res = {} if res is None else res                         # filled as the leg goes: the watchdog prints what is there if a later part hangs
+    if dist is None and force_dist:
+        # N = 1 on the REAL backend: a one-rank RCCL group, DistributedDataParallel(device_ids=...), both exchange hooks and the
+        # persistent projection in one process -- the N-rank step's code path, so that the 8-GPU run is not its first contact with RCCL
+        import datetime
+        import torch.distributed as dist
+        from smokephysai_amd.utils.distributed import init_distributed
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        res["stage"] = "init_process_group(nccl, world_size=1)"
+        init_distributed("nccl", force=True)
+        backend = "nccl"
     rank = dist.get_rank() if dist is not None else 0
     torch.manual_seed(0)
     model = SmokePhysNet().to(dev).train()
-    ddp = wrap_ddp(model, dev)
+    res["stage"] = "wrap_ddp"
+    ddp = wrap_ddp(model, dev, force=force_dist)
     reg = PhysicsRegularizer()
     opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3, weight_decay=0.01)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)                 # every rank its own frames
@@ -242,22 +254,30 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None):
             el = float(t.item())
         return el / n * 1e3
 
+    res["stage"] = "warm-up steps"
     for _ in range(2):
         step()
+    res["stage"] = "timed steps"
     ms = timed(steps)
     nparam = sum(p.numel() for p in model.parameters())
-    res = {} if res is None else res                         # filled as the leg goes: the watchdog prints what is there if a later part hangs
+    exchanged = dist is not None
     res.update({"ms_per_step": ms, "frames_per_s": world * B / (ms * 1e-3), "batch_per_gpu": B, "global_batch": world * B, "grid": N,
            "rccl_ranks": world if (dist is not None and backend == "nccl") else 0, "ranks": world,
            "collective_backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None,
            "grad_bytes_fp32": nparam * 4,
-           "note": "forward + backward + gradient all-reduce (DDP, overlapped) + clip + AdamW; linear GEMMs, attention, LayerNorm and the "
-                   "encoder's BatchNorm/ReLU/pool, both of its convolutions, GELU/dropout/residual of the FFN on libsmokehip; the decoder head's transposed convolutions, the loss and AdamW on PyTorch-ROCm"})
+           "ddp_wrapped": ddp is not model,
+           "note": ("forward + backward" + (f" + gradient all-reduce over {world} rank(s) (DistributedDataParallel on {backend}, 64 MB buckets, "
+                                            "overlapped with backward)" if exchanged and ddp is not model
+                                            else " (one process, no process group: NO gradient exchange ran)") +
+                    " + clip + AdamW; linear GEMMs, attention, LayerNorm and the encoder's BatchNorm/ReLU/pool, both of its convolutions, "
+                    "GELU/dropout/residual of the FFN on libsmokehip; the decoder head's transposed convolutions, the loss and AdamW on PyTorch-ROCm")})
     if dist is not None:
+        res["stage"] = "no_sync steps"
         res["ms_per_step_no_allreduce"] = timed(steps, sync=False)          # same step under ddp.no_sync(): what the exchange costs
         res["ddp_buckets"] = ddp_bucket_report(ddp)
         # the gradient exchange alone: one flat fp32 all-reduce of the same byte count (algorithm bandwidth = bytes / time;
         # bus bandwidth = 2 (n-1)/n of that -- a ring on xGMI is bound by one 153 GB/s link)
+        res["stage"] = "flat all-reduce"
         flat = torch.zeros(nparam, device=dev if backend == "nccl" else "cpu")
         for _ in range(2):
             dist.all_reduce(flat)
@@ -271,6 +291,7 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None):
                                  "busbw_GBs": nparam * 4 / ar / 1e9 * 2 * (world - 1) / world}
         # SURVEY 8f-3's alternative on the same bytes: all-to-all of the shards + ordered local sum + all-gather (every xGMI link busy
         # for two hops instead of a ring's 2 (N-1) dependent hops) -- first as flat collectives, then as the DDP hook inside the step
+        res["stage"] = "flat direct exchange"
         shard = (nparam + world - 1) // world
         send, recv = torch.zeros(world * shard, device=flat.device), torch.empty(world * shard, device=flat.device)
         out = torch.empty(world * shard, device=flat.device)
@@ -292,10 +313,12 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None):
         del ddp, send, recv, out, flat
         import gc
         gc.collect()                                         # (the first wrapper's reducer hooks go with it)
-        ddp = wrap_ddp(model, dev, grad_exchange="direct")
+        res["stage"] = "direct-exchange steps"
+        ddp = wrap_ddp(model, dev, grad_exchange="direct", force=force_dist)
         for _ in range(2):
             step()
         res["direct_exchange_step"] = {"ms_per_step": timed(steps), "ddp_buckets": ddp_bucket_report(ddp)}
+    res.pop("stage", None)
     return res
 
 
@@ -353,6 +376,10 @@ def parse_args(argv=None):
                          "under DistributedDataParallel when N > 1: the RCCL gradient all-reduce).  On by default at every N, so that the "
                          "1 -> N curve of the DDP step has its N = 1 point (adds about 20 s)")
     ap.add_argument("--no-train-step", dest="train_step", action="store_false", help="skip the train-step leg (profiling runs)")
+    ap.add_argument("--force-dist", dest="force_dist", action="store_true", default=True,
+                    help="N = 1 only: run the train-step leg in a ONE-rank RCCL process group under DistributedDataParallel (default), so that "
+                         "the collective code path of the N-rank job -- RCCL init, DDP buckets, both exchange hooks -- runs on the real backend")
+    ap.add_argument("--no-force-dist", dest="force_dist", action="store_false", help="N = 1: the bare model, no process group")
     ap.add_argument("--train-step-limit", type=float, default=240.0,
                     help="seconds after which a stuck train-step leg is abandoned: rank 0 prints the headline line without it")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
@@ -550,39 +577,57 @@ def main(argv=None):
             out["config1"] = config1
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
+        # what the device had run when the headline's timed region began: the W warm-up steps of the headline leg itself plus the full
+        # secondary legs in front of it (a fresh process's first launches run slower while the clocks ramp; README "leg order")
+        out["effective_warmup_steps"] = {"headline_leg": W, "config1_leg_before": (W + K) if config1 is not None else 0,
+                                         "alt_leg_before": (W + K) if alt is not None else 0,
+                                         "total_steps_before_timed_region": W + ((W + K) if config1 is not None else 0) + ((W + K) if alt is not None else 0)}
         out["leg_order"] = leg_order + [k for k in ("inference_ms_per_frame", "cpu_baseline") if k in out] + (["train_step"] if args.train_step else [])
 
+    exit_code = 0
     if args.train_step:
-        # a collective that never completes on one rank would hang every rank: a watchdog on each rank abandons the leg
-        # at the same deadline, rank 0 printing the headline line it already holds
+        # A collective that never completes on one rank would hang every rank: a watchdog on each rank abandons the leg at the same
+        # deadline.  Rank 0 still prints the headline line it holds (with the partial train_step block), and then EVERY rank exits
+        # non-zero: each has touched the GPU, and an abandoned leg must not look like a clean run to torchrun or the driver.  One lock
+        # decides between "finished" and "abandoned", so the line is printed exactly once.
         import threading
-        done = threading.Event()
+        finish = threading.Lock()
+        state = {"done": False}
         ts_partial = {}
 
         def abandon():
-            if done.is_set():
-                return
-            if rank == 0:
-                out["train_step"] = dict(ts_partial, error=f"abandoned after {args.train_step_limit:.0f} s (watchdog); the keys beside this one "
-                                                            "were measured before the part that did not return")
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            with finish:
+                if state["done"]:
+                    return
+                state["done"] = True
+                if rank == 0:
+                    out["train_step"] = dict(ts_partial, error=f"abandoned after {args.train_step_limit:.0f} s (watchdog) in stage "
+                                                                f"{ts_partial.get('stage')!r}; the keys beside this one were measured before the part that did not return")
+                    print(json.dumps(out), flush=True)
+                os._exit(3)
         dog = threading.Timer(args.train_step_limit, abandon)
         dog.daemon = True
         dog.start()
         del sim, enc
         torch.cuda.empty_cache()
         try:
-            ts = train_step_leg(dev, N, B, dist, world, backend, res=ts_partial)
-        except Exception as e:                                   # the headline number must survive a failure of this leg
+            ts = train_step_leg(dev, N, B, dist, world, backend, res=ts_partial, force_dist=args.force_dist and world == 1)
+        except Exception as e:                                   # the headline number must survive a failure of this leg ...
             ts = dict(ts_partial, error=f"{type(e).__name__}: {e}"[:400])
-        done.set(); dog.cancel()
+            exit_code = 4                                        # ... but the run is not clean
+        with finish:                                             # (held by the watchdog while it prints and exits: then this never returns)
+            state["done"] = True
+        dog.cancel()
         if rank == 0:
             out["train_step"] = ts
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        tdist.destroy_process_group()
+    if exit_code:
+        sys.stdout.flush()
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

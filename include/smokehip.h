@@ -29,14 +29,15 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 5
+#define SMK_ABI_VERSION 6
 
 typedef enum smk_status {
     SMK_OK = 0,
     SMK_ERR_INVALID = -1,      /* bad argument / shape */
     SMK_ERR_HIP = -2,          /* a HIP runtime call failed (message has hipGetErrorString) */
     SMK_ERR_UNSUPPORTED = -3,  /* valid in the reference, not built here (message says what) */
-    SMK_ERR_NO_DEVICE = -4
+    SMK_ERR_NO_DEVICE = -4,
+    SMK_ERR_TIMEOUT = -5       /* a bounded wait inside a persistent launch ran out: results were poisoned (NaN), see smk_sim_status */
 } smk_status;
 
 int smk_abi_version(void);
@@ -58,7 +59,17 @@ typedef struct smk_sim_desc {
  * scratch (ping-pong fields, divergence), computes the shape-only fractal constant on the device. Does NOT
  * zero the state: call smk_sim_reset. */
 int smk_sim_create(const smk_sim_desc *desc, smk_sim **out);
+/* Frees the handle (always).  Returns SMK_ERR_TIMEOUT if a persistent projection of this handle timed out and nobody has been told yet
+ * (the frames the caller read last were NaN); SMK_OK otherwise. */
 int smk_sim_destroy(smk_sim *sim);
+
+/* Health of the handle -- no reference counterpart (the reference is synchronous: navier_stokes.py:133-149 either returns right results or
+ * raises).  The persistent projection (see smk_sim_step) bounds every inter-workgroup wait; when one runs out the kernel turns the band's
+ * p / u / v into NaN (so every later frame of the grid is NaN: wrong results cannot pass as data) and sets a host-visible word.  This call
+ * reads and acknowledges that word: SMK_ERR_TIMEOUT exactly once per event, SMK_OK otherwise; it does not synchronise -- call it after
+ * the stream the steps ran on has been synchronised to learn about THOSE steps (the Python mirror's check() does both).  Every other
+ * smk_sim_* entry point performs the same check on entry, so an event is never reported later than the next call on the handle. */
+int smk_sim_status(smk_sim *sim);
 
 /* NavierStokesSimulator.setup_grid (navier_stokes.py:24-35): zero u,v,p,density of the grids whose byte in
  * grid_mask (host, B bytes) is non-zero; NULL = all grids. */
@@ -83,9 +94,10 @@ int smk_sim_add_sources(smk_sim *sim, const smk_source *sources, int32_t n, void
  * Launches per time step: two where the band plan allows (buoyancy + diffusion + the whole pressure projection as one persistent
  * launch whose workgroups hand halo rows to each other with bounded waits, then the three advections as one launch).  The persistent
  * launch assumes this process has the device to itself (all its workgroups resident at once): if a wait times out (0.5 s) the
- * launch still drains, and the NEXT call on this handle returns SMK_ERR_HIP with a message naming the persistent projection -- the
- * state since that step is invalid (smk_sim_reset), later steps use one launch per chunk of sweeps.  SMK_JACOBI_PERSIST=0 in the
- * environment selects that form from the start; stream capture always records it. */
+ * launch still drains, the affected grids' p / u / v / density / frames become NaN, and smk_sim_status after a stream synchronise -- or
+ * at the latest the NEXT call on this handle, smk_sim_destroy included -- returns SMK_ERR_TIMEOUT with a message naming the persistent
+ * projection (then: smk_sim_reset; later steps use one launch per chunk of sweeps).  SMK_JACOBI_PERSIST=0 in the environment selects that
+ * form from the start; stream capture always records it. */
 int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t frame_stride_b, int64_t frame_stride_t,
                  int32_t add_fractal, double fractal_intensity, void *stream);
 

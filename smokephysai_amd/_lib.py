@@ -7,6 +7,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMOKEHIP_LIB") or os.path.join(_HERE, "libsmokehip.so")   # SMOKEHIP_LIB: diagnostic builds only
 
+ABI_VERSION = 6                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
+SMK_ERR_TIMEOUT = -5
 SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
 SMK_ACT_NONE, SMK_ACT_GELU, SMK_ACT_RELU = 0, 1, 2
 SMK_FMT_F32, SMK_FMT_SPLIT_BF16 = 0, 1
@@ -42,6 +44,7 @@ class SmkDecoderWeights(C.Structure):
 _SIGNATURES = {
     "smk_sim_create": [C.POINTER(SmkSimDesc), C.POINTER(C.c_void_p)],
     "smk_sim_destroy": [C.c_void_p],
+    "smk_sim_status": [C.c_void_p],
     "smk_sim_reset": [C.c_void_p, C.c_char_p, C.c_void_p],
     "smk_sim_add_sources": [C.c_void_p, C.POINTER(SmkSource), C.c_int32, C.c_void_p],
     "smk_sim_step": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_void_p],
@@ -122,6 +125,12 @@ def load():
         L = C.CDLL(LIB_PATH)
         L.smk_abi_version.restype = C.c_int
         L.smk_last_error.restype = C.c_char_p
+        have = L.smk_abi_version()
+        if have != ABI_VERSION:
+            # the .so is git-ignored and travels separately from the sources: argument lists shift between versions, and a stale library
+            # would be called with the wrong pointers
+            raise ImportError(f"{LIB_PATH} has ABI version {have}, this binding needs {ABI_VERSION}: rebuild it "
+                              "(`make -C smokephysai_amd/csrc`, or `python -c 'import __graft_entry__ as g; g.build()'`)")
         L.smk_linear_wgrad_workspace.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         L.smk_linear_wgrad_workspace.restype = C.c_int64          # a byte count, not a status
         L.smk_bn_train_workspace.argtypes = [C.c_int32] * 5

@@ -43,10 +43,18 @@ int device_num_cu() {
     return n;
 }
 
-bool first_use_on_device(const void *key) {
+bool first_use_begin(const void *key) {
     const int dev = current_device();
-    std::lock_guard<std::mutex> lk(g_dev_mu);
-    return g_dev_int.emplace(std::make_pair(dev, key), 1).second;
+    g_dev_mu.lock();
+    if (g_dev_int.count(std::make_pair(dev, key))) {
+        g_dev_mu.unlock();
+        return false;
+    }
+    return true;                                              // lock held until first_use_end
+}
+void first_use_end(const void *key) {
+    g_dev_int.emplace(std::make_pair(current_device(), key), 1);
+    g_dev_mu.unlock();
 }
 
 int device_cached_int(const void *key, int (*compute)()) {
@@ -125,15 +133,23 @@ int check_launch(hipError_t e, const char *what) {
     return SMK_OK;
 }
 
+int report_timeout() {
+    set_error("persistent projection: a band waited longer than 0.5 s for its neighbour's hand-off (its workgroups were not all "
+              "resident at once -- is another kernel or process holding compute units?).  The pressure, velocity and density of the "
+              "grids of that projection were set to NaN, and so is every frame emitted since: reset the simulator (smk_sim_reset).  "
+              "Later projections of this handle use the multi-launch form (SMK_JACOBI_PERSIST=0 selects it from the start)");
+    return SMK_ERR_TIMEOUT;
+}
+
 int project_status(hipError_t e) {
-    if (e == hipErrorLaunchTimeOut) {
-        set_error("project: a band of an earlier persistent projection waited longer than 0.5 s for its neighbour (its workgroups were "
-                  "not all resident at once -- is another kernel holding compute units?); the state since that step is invalid. "
-                  "Reset the simulator; later projections of this handle use the multi-launch form (SMK_JACOBI_PERSIST=0 selects it "
-                  "from the start)");
-        return SMK_ERR_HIP;
-    }
+    if (e == hipErrorLaunchTimeOut) return report_timeout();
     return check_launch(e, "project");
+}
+
+// Every smk_sim_* call starts here: a time-out that a persistent projection of an EARLIER call has reported by now is returned by this
+// call (once).  What the launches of the current call report is seen by smk_sim_status after the stream has been synchronised.
+int sim_entry(smk_sim *sim) {
+    return project_sync_take_timeout(sim->psync) ? report_timeout() : SMK_OK;
 }
 
 int run_stage(smk_sim *sim, int stage, float *frames, int64_t fsb, const float *fractal, float fint, hipStream_t st) {
@@ -218,17 +234,24 @@ int smk_sim_destroy(smk_sim *sim) {
     if (!sim) return SMK_OK;
     DeviceGuard guard(sim->device);              // frees run on the handle's device; the caller's device is restored
     float *ptrs[] = {sim->t.u, sim->t.v, sim->t.p, sim->t.d, sim->div, sim->perlin, sim->mandel, sim->fractal};
-    for (float *p : ptrs) if (p) (void)hipFree(p);
+    for (float *p : ptrs) if (p) (void)hipFree(p);           // (hipFree waits for the device: every launch of this handle has finished)
+    const bool timed_out = project_sync_take_timeout(sim->psync);
     project_sync_destroy(sim->psync);
     if (sim->dev_mask) (void)hipFree(sim->dev_mask);
     if (sim->dev_first) (void)hipFree(sim->dev_first);
     if (sim->dev_src) (void)hipFree(sim->dev_src);
     delete sim;
-    return SMK_OK;
+    return timed_out ? report_timeout() : SMK_OK;            // the handle is gone either way; the caller learns its last frames were NaN
+}
+
+int smk_sim_status(smk_sim *sim) {
+    SMK_REQUIRE(sim, "null sim");
+    return sim_entry(sim);
 }
 
 int smk_sim_reset(smk_sim *sim, const uint8_t *grid_mask, void *stream) {
     SMK_REQUIRE(sim, "null sim");
+    if (int e = sim_entry(sim)) return e;
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(sim->device);
     int rc = guard.rc;
@@ -243,6 +266,7 @@ int smk_sim_reset(smk_sim *sim, const uint8_t *grid_mask, void *stream) {
 
 int smk_sim_add_sources(smk_sim *sim, const smk_source *src, int32_t n, void *stream) {
     SMK_REQUIRE(sim && (src || n == 0) && n >= 0, "null sim/sources");
+    if (int e = sim_entry(sim)) return e;
     if (n == 0) return SMK_OK;
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(sim->device);
@@ -280,6 +304,7 @@ int smk_sim_add_sources(smk_sim *sim, const smk_source *src, int32_t n, void *st
 int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t fsb, int64_t fst, int32_t add_fractal,
                  double fractal_intensity, void *stream) {
     SMK_REQUIRE(sim && n_steps >= 0, "null sim / negative n_steps");
+    if (int e = sim_entry(sim)) return e;
     if (add_fractal && frames && !sim->fractal) {
         // fractal_generator.py:44,49: the [w,h] mask indexes an [h,w] buffer -> the reference raises for h != w
         set_error("fractal perturbation needs a square grid (reference raises an IndexError for H != W)");
@@ -313,6 +338,7 @@ int smk_sim_step(smk_sim *sim, int32_t n_steps, float *frames, int64_t fsb, int6
 
 int smk_sim_run_stage(smk_sim *sim, int32_t stage, void *stream) {
     SMK_REQUIRE(sim, "null sim");
+    if (int e = sim_entry(sim)) return e;
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(sim->device);
     int rc = guard.rc;
@@ -353,6 +379,7 @@ int smk_sim_run_stage(smk_sim *sim, int32_t stage, void *stream) {
 
 int smk_sim_divergence(smk_sim *sim, float *out, void *stream) {
     SMK_REQUIRE(sim && out, "null sim/out");
+    if (int e = sim_entry(sim)) return e;
     DeviceGuard guard(sim->device);
     int rc = guard.rc;
     if (rc) return rc;
@@ -363,6 +390,7 @@ int smk_sim_divergence(smk_sim *sim, float *out, void *stream) {
 
 int smk_sim_backtrace(smk_sim *sim, int32_t which, int32_t *x0, int32_t *y0, void *stream) {
     SMK_REQUIRE(sim && x0 && y0 && which >= 0 && which <= 2, "null sim/x0/y0 or which not in 0..2");
+    if (int e = sim_entry(sim)) return e;
     DeviceGuard guard(sim->device);
     int rc = guard.rc;
     if (rc) return rc;

@@ -47,7 +47,17 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Launch-time state is PER DEVICE (a process may hold handles on several GPUs): the CU count, and "has this kernel's dynamic-LDS
 // limit been raised / what did the occupancy query say" keyed by (kernel, current device).  Thread-safe (api.hip).
 int device_num_cu();                                         // CUs of the CURRENT device (cached)
-bool first_use_on_device(const void *key);                   // true exactly once per (key, current device)
+// One-time per-(key, current device) setup (hipFuncSetAttribute before a kernel's first launch): first_use_begin returns true exactly once
+// and then HOLDS the per-device lock until first_use_end, so a second host thread cannot launch before the attribute is set.
+bool first_use_begin(const void *key);
+void first_use_end(const void *key);
+template <class F>
+inline void once_per_device(const void *key, F &&setup) {
+    if (first_use_begin(key)) {
+        setup();
+        first_use_end(key);
+    }
+}
 int device_cached_int(const void *key, int (*compute)());    // compute() once per (key, current device), then the cached value
 
 }  // namespace smk

@@ -287,11 +287,11 @@ hipError_t launch_encoder_f32(const float *frames, int64_t fstride, int B, int H
     const int PS = H / 32;
     dim3 grid(W / ENC_TW, H / ENC_TH, B), block(512);
     size_t lds_bytes = sizeof(float) * (size_t)(LDS_F32_TOTAL > 256 * A2_PITCH ? LDS_F32_TOTAL : 256 * A2_PITCH);
-    if (first_use_on_device((const void *)k_encoder_f32<8>)) {
+    once_per_device((const void *)k_encoder_f32<8>, [&] {
         (void)hipFuncSetAttribute((const void *)k_encoder_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute((const void *)k_encoder_f32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute((const void *)k_encoder_f32<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    }
+    });
     switch (PS) {
         case 2: hipLaunchKernelGGL(k_encoder_f32<2>, grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
         case 4: hipLaunchKernelGGL(k_encoder_f32<4>, grid, block, lds_bytes, st, frames, fstride, H, W, e, features); break;
@@ -1141,8 +1141,9 @@ hipError_t launch_conv1_train_wgrad(const float *dz, const float *x, int B, int 
     if (H % 4 != 0 || W % 64 != 0 || B < 1) return hipErrorInvalidValue;
     const int tiles_x = W / 64, tiles_per_frame = tiles_x * (H / 4), ntiles = B * tiles_per_frame;
     int nparts = conv1_wgrad_parts();
-    if (first_use_on_device((const void *)k_conv1_train_wgrad))
+    once_per_device((const void *)k_conv1_train_wgrad, [&] {
         (void)hipFuncSetAttribute((const void *)k_conv1_train_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, C1G_LDS);
+    });
     const int grid = nparts < ntiles ? nparts : ntiles;
     float *part = static_cast<float *>(workspace);
     hipLaunchKernelGGL(k_conv1_train_wgrad, dim3(grid), dim3(256), C1G_LDS, st, dz, x, H, W, tiles_x, tiles_per_frame, ntiles, part);
@@ -1731,8 +1732,9 @@ hipError_t launch_conv2_train_wgrad(const float *dz, const float *a1, int B, int
     const int nstreams = conv2_wgrad_streams();
     if (nstreams < 8) return hipErrorInvalidValue;
     float *part = static_cast<float *>(workspace), *dbpart = part + (size_t)nstreams * 4 * (WG_OG * 9 * 64);
-    if (first_use_on_device((const void *)k_conv2_wgrad_b16))
+    once_per_device((const void *)k_conv2_wgrad_b16, [&] {
         (void)hipFuncSetAttribute((const void *)k_conv2_wgrad_b16, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+    });
     hipLaunchKernelGGL(k_conv2_wgrad_b16, dim3(nstreams * 4), dim3(256), WG_LDS, st, dz, a1, H, W, tiles_x, tiles_per_frame, ntiles, nstreams, part, dbpart);
     hipLaunchKernelGGL(k_conv2_wgrad_finish, dim3(cdiv(128 * 9 * 64, 256)), dim3(256), 0, st, part, dbpart, nstreams, dw, db);
     return hipGetLastError();

@@ -508,8 +508,9 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
 template <int MB, int NW, bool AS, int KS = 1>
 static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     constexpr int lds = KS * ln_lds_bytes<MB, NW>() + (KS - 1) * NW * 64 * MB * 16 * 4;
-    if (first_use_on_device((const void *)k_linear_x3<MB, NW, AS, KS>))
+    once_per_device((const void *)k_linear_x3<MB, NW, AS, KS>, [&] {
         (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
     const int nseg = a.c.nseg;
     const int nwg_max = (NW == 8 || KS > 1 ? 1 : 2) * a.num_cu / nseg;     // 8 waves per CU either way (split-K: one workgroup per CU)
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
@@ -898,8 +899,9 @@ hipError_t launch_linear_wgrad(const float *dy, long long ld_dy, const float *x,
         a.out_f = out_f; a.in_f = in_f; a.tiles_n = t.tiles_n; a.ntiles = t.tiles_m * t.tiles_n; a.nseg = t.nseg;
         a.part = t.nseg > 1 ? reinterpret_cast<float *>(workspace) : dw;
         a.dbpart = db ? reinterpret_cast<float *>(workspace) + (size_t)t.nseg * out_f * in_f : nullptr;
-        if (first_use_on_device((const void *)k_linear_wgrad_tr))
+        once_per_device((const void *)k_linear_wgrad_tr, [&] {
             (void)hipFuncSetAttribute((const void *)k_linear_wgrad_tr, hipFuncAttributeMaxDynamicSharedMemorySize, WT_LDS);
+        });
         hipLaunchKernelGGL(k_linear_wgrad_tr, dim3(a.ntiles * t.nseg), dim3(256), WT_LDS, st, a);
         if (t.nseg > 1) {
             const long long n4 = (long long)out_f * in_f / 4;

@@ -26,6 +26,8 @@ struct ProjectSync {
 };
 hipError_t project_sync_create(ProjectSync &ps, int B);
 void project_sync_destroy(ProjectSync &ps);
+// true exactly once after a persistent launch of this handle reported a timed-out hand-off (acknowledges the word, disables the persistent form)
+bool project_sync_take_timeout(ProjectSync &ps);
 // divergence + `iters` Jacobi sweeps + gradient subtraction on (u, v, p); p2 and div are scratch.  With `ps` the projection runs as one
 // persistent launch where the plan allows (stencil.hip: k_jacobi_band<..., PERSIST>); returns hipErrorLaunchTimeOut once if an earlier
 // persistent launch reported a timed-out wait, and uses the multi-launch form afterwards.

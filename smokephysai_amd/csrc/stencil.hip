@@ -392,6 +392,7 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
                                                             int iters, int BR, JacobiSync sy) {
     constexpr int TR = JB_NW * RPW, ROWF = 64 * VEC;
     __shared__ float edge[2][JB_NW][2][ROWF];
+    __shared__ int handoff_failed;                            // PERSIST: lane 0 saw a timed-out / aborted hand-off wait -> poison the band's results
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Bands own unequal row ranges: the first and last band of a grid need a halo only on their inner side (the other side is the
     // physical boundary), so they own TR - HALO rows and the middle bands TR - 2 HALO (HALO = BR here).  One band: the whole grid.
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
         const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(sy.x0, 0, xbytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(sy.x1, 0, xbytes, 0x00020000);
         int done = 0;
+        if (threadIdx.x == 0) handoff_failed = 0;             // (read only after a hand-off: at least two workgroup barriers later)
         for (int c = 0; c < sy.chunks; ++c) {
             const int n = (iters - done + (sy.chunks - c) - 1) / (sy.chunks - c);
             run(n);
@@ -655,10 +657,14 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
                     const bool dn = band == nb - 1 ||
                         (int)(__hip_atomic_load(sy.flags + me + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tgt) >= 0;
                     if (up && dn) break;
-                    if (__hip_atomic_load(sy.flags + sy.abort_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    if (__hip_atomic_load(sy.flags + sy.abort_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        handoff_failed = 1;                   // another band gave up: this band's halo rows are stale too
+                        break;
+                    }
                     if (wall_clock64() - t0 > sy.timeout_ticks) {
                         __hip_atomic_store(sy.flags + sy.abort_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(sy.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        handoff_failed = 1;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(2);
@@ -673,6 +679,15 @@ __global__ __launch_bounds__(JB_NW * 64) void k_jacobi_band(Geom g, const float 
                 const bool need = (gi >= own0 - halo && gi < own0) || (gi >= own1 && gi < own1 + halo);
                 if (need) ldv_sc1<VEC>(pv[k], rx, row_off + k * pitch_b);
             }
+        }
+        // A hand-off that did not complete leaves stale halo rows, and p, u, v are updated in place: results that cannot be right must not
+        // look like data.  The band's p becomes NaN (so do its u, v through the gradient below, and every frame of the grid from here on);
+        // the host reads *status at its next synchronising call (smk_sim_status) and reports the time-out for THIS projection.
+        if (sy.chunks > 1 && handoff_failed) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) pv[k][c] = __builtin_nanf("");
         }
     }
 #pragma unroll
@@ -920,13 +935,15 @@ static bool use_persist(const Geom &g, const ProjectSync *ps, int iters, JacobiP
 // stream than the previous one (of this process, on this device), the new stream is made to wait for everything submitted to the previous
 // one (an event recorded there now) -- no host stall, and nothing at all in the single-stream case.  Other PROCESSES on the device are
 // beyond this: see the bounded waits.
-static void order_persistent_launch(hipStream_t st) {
+static std::unique_lock<std::mutex> order_persistent_launch(hipStream_t st) {
     struct Last { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; bool any = false; };
     static std::mutex mu;
     static std::map<int, Last> last;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
+    // The caller keeps the lock until its persistent kernels are enqueued: a second host thread must not record its event on this
+    // stream before the launch it is meant to wait for has been submitted.
+    std::unique_lock<std::mutex> lk(mu);
     Last &l = last[dev];
     if (l.any && l.stream != st) {
         if (!l.ev) (void)hipEventCreateWithFlags(&l.ev, hipEventDisableTiming);
@@ -935,16 +952,26 @@ static void order_persistent_launch(hipStream_t st) {
     }
     l.stream = st;
     l.any = true;
+    return lk;
+}
+
+// A bounded wait of an earlier persistent launch of this handle ran out (the kernel set the host-visible word and turned the band's results
+// into NaN).  Acknowledge it: the word is cleared, the handle uses the multi-launch form from here on, and the caller reports the error
+// exactly once.  The word is meaningful after the stream has been synchronised; read earlier it may simply not be set yet.
+bool project_sync_take_timeout(ProjectSync &ps) {
+    if (!ps.status || *ps.status == 0u) return false;
+    *ps.status = 0u;
+    ps.disabled = true;
+    return true;
 }
 
 hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2, float *div, int iters, hipStream_t st, ProjectSync *ps,
                           const StateView *fold_in, float *fold_d_out, bool *folded) {
     JacobiPlan pl;
     if (folded) *folded = false;
-    if (ps && ps->status && *ps->status != 0u && !ps->disabled) {
+    if (ps && project_sync_take_timeout(*ps)) {
         // a wait inside an earlier persistent launch timed out (its workgroups were not co-resident within the limit): that projection's
-        // result is invalid.  Say so once, loudly, and use the multi-launch form from here on.
-        ps->disabled = true;
+        // result is invalid (NaN).  Say so once, loudly, and use the multi-launch form from here on.
         return hipErrorLaunchTimeOut;
     }
     int chunks = 0;
@@ -962,7 +989,7 @@ hipError_t launch_project(const Geom &g, float *u, float *v, float *p, float *p2
         sy.base = ps->seq; sy.chunks = chunks; sy.nb = pl.nb; sy.abort_slot = ps->flags_len - 1; sy.fault = knobs().fault ? 1 : 0;
         sy.timeout_ticks = knobs().fault ? 200000ll : 50000000ll;      // 100 MHz wall clock: 2 ms under fault injection, 0.5 s otherwise
         ps->seq += (unsigned)chunks;
-        order_persistent_launch(st);
+        const std::unique_lock<std::mutex> launch_order = order_persistent_launch(st);
         // the buoyancy + diffusion stage as this launch's prologue (16-byte row accesses: pitches in multiples of 4; up to 4 cells per lane)
         const bool fold = fold_in && fold_d_out && knobs().fold && pl.vec <= 4 && g.pv % 4 == 0 && g.pc % 4 == 0;
         if (fold) {
@@ -1010,7 +1037,7 @@ hipError_t launch_buoy_project(const Geom &g, StateView in, StateView out, float
     int chunks = 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-    const bool pending_error = ps && ps->status && *ps->status != 0u && !ps->disabled;
+    const bool pending_error = ps && ps->status && *ps->status != 0u;
     if (!capturing && !pending_error && use_persist(g, ps, iters, pl, chunks) && knobs().fold && pl.vec <= 4 && g.pv % 4 == 0 && g.pc % 4 == 0) {
         const hipError_t e = launch_project(g, out.u, out.v, p, out.p, div, iters, st, ps, &in, out.d, &folded);
         if (e != hipSuccess || folded) return e;

@@ -364,10 +364,10 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
 
 hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
     const int num_cu = device_num_cu();
-    if (first_use_on_device((const void *)k_attention_x3<1>)) {
+    once_per_device((const void *)k_attention_x3<1>, [&] {
         (void)hipFuncSetAttribute((const void *)k_attention_x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
         (void)hipFuncSetAttribute((const void *)k_attention_x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS);
-    }
+    });
     const int nwg = a.B * a.H * (a.L / AT_QB);
     static int force_ks = -1;
     if (force_ks < 0) { const char *sv = getenv("SMK_ATTN_KS"); force_ks = sv ? atoi(sv) : 0; }
@@ -607,10 +607,10 @@ __global__ __launch_bounds__(256, 2) void k_attention_bwd_x3(const AttnBwdArgs a
 }
 
 hipError_t launch_attention_bwd_x3(const AttnBwdArgs &a, hipStream_t st) {
-    if (first_use_on_device((const void *)k_attention_bwd_x3<false>)) {
+    once_per_device((const void *)k_attention_bwd_x3<false>, [&] {
         (void)hipFuncSetAttribute((const void *)k_attention_bwd_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_DQ);
         (void)hipFuncSetAttribute((const void *)k_attention_bwd_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_DKV);
-    }
+    });
     const int nwg = a.B * a.H * (a.L / 128);
     hipLaunchKernelGGL(k_attention_bwd_x3<true>, dim3(nwg), dim3(256), AB_LDS_DKV, st, a);
     hipLaunchKernelGGL(k_attention_bwd_x3<false>, dim3(nwg), dim3(256), AB_LDS_DQ, st, a);

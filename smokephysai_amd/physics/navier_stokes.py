@@ -57,7 +57,27 @@ class NavierStokesSimulator(nn.Module):
         h = self.__dict__.get("_handle")
         if h:
             self.__dict__["_handle"] = None       # not nn.Module.__setattr__: torch's globals may be gone at interpreter exit
-            self._L.smk_sim_destroy(h)
+            if self._L.smk_sim_destroy(h) != 0:   # (an exception raised in __del__ is only printed: warn in words)
+                import warnings
+                warnings.warn("NavierStokesSimulator: " + self._L.smk_last_error().decode(), RuntimeWarning)
+
+    def close(self):
+        """Free the library-side scratch now; raises if a persistent projection of this simulator timed out unreported."""
+        h = self.__dict__.get("_handle")
+        if h:
+            self.__dict__["_handle"] = None
+            _lib.check(self._L.smk_sim_destroy(h))
+
+    def check(self):
+        """Wait for the work enqueued on the current stream, then raise if a persistent projection among it ran into its bounded
+        wait (the affected grids were set to NaN by the kernel).  The reference is synchronous -- results are right or an exception
+        is raised (navier_stokes.py:133-149); this is the point where the asynchronous path gives the same guarantee.  Called by
+        every method that hands finished frames on (simulate_sequence, the dataset generator, the chaos statistics); not inside a
+        stream capture."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        torch.cuda.current_stream(self._dev).synchronize()
+        _lib.check(self._L.smk_sim_status(self._handle))
 
     # ---- state views with the reference's shapes (navier_stokes.py:27-32) ---------------------------------
     def _view(self, store, cols):

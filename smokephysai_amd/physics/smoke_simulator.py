@@ -51,6 +51,7 @@ class SmokeSimulator(nn.Module):
         if out is None:
             out = torch.empty(ns._B, n_steps, ns.h, ns.w, device=ns._dev)
         ns.step_into(out, n_steps, add_fractal=add_fractal, fractal_intensity=0.05)
+        ns.check()                 # all n_steps were enqueued at once: a timed-out projection among them is reported HERE, not a call later
         return out
 
     # ---- chaos statistics (smoke_simulator.py:47-140) -------------------------------------------------------
@@ -58,6 +59,7 @@ class SmokeSimulator(nn.Module):
         """Un-batched: the reference's dict (or {} with fewer than 10 frames).  Batched: a list with one dict per grid."""
         if len(self.history) < 10:
             return {} if self.batch_size is None else [{} for _ in range(self.ns_solver._B)]
+        self.ns_solver.check()     # the statistics go to the host: the frames behind them must be real
         if self.batch_size is None:
             return {"lyapunov_exponent": self.compute_lyapunov_exponent(),
                     "fractal_dimension": self.compute_fractal_dimension(),

@@ -18,15 +18,23 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def init_distributed(backend: str = None):
-    """Initialise from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*); no-op for one process.
+def init_distributed(backend: str = None, force: bool = False):
+    """Initialise from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*); no-op for one process unless `force`
+    (a world of one rank on the real backend: the collective path of the N-rank job, rehearsed on one GPU).
     Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world == 1:                                      # nobody else has to find the store: take any free port
+                import socket
+                s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+            else:
+                os.environ["MASTER_PORT"] = "29500"
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -91,10 +99,11 @@ def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) ->
     return fut.then(finish)
 
 
-def wrap_ddp(model: torch.nn.Module, device, sync_bn: bool = False, grad_exchange: str = "rccl") -> torch.nn.Module:
-    """DistributedDataParallel around `model` when a process group exists (gradient all-reduce = mean over ranks).
-    grad_exchange: "rccl" = the backend's bucketed all-reduce; "direct" / "direct_bf16" = `direct_exchange_hook`."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def wrap_ddp(model: torch.nn.Module, device, sync_bn: bool = False, grad_exchange: str = "rccl", force: bool = False) -> torch.nn.Module:
+    """DistributedDataParallel around `model` when a process group of more than one rank exists (gradient all-reduce = mean over ranks).
+    grad_exchange: "rccl" = the backend's bucketed all-reduce; "direct" / "direct_bf16" = `direct_exchange_hook`.
+    force: wrap in a one-rank group too (every collective of the N-rank step then runs on the real backend with N = 1)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return model
     if grad_exchange not in ("rccl", "direct", "direct_bf16"):
         raise ValueError(f"grad_exchange must be 'rccl', 'direct' or 'direct_bf16', not {grad_exchange!r}")
