@@ -20,8 +20,8 @@ u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 
 def build(force=False):
     so = os.path.join(_HERE, "libsmoke_oracle.so")
-    src = os.path.join(_HERE, "smoke_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("smoke_oracle.c", "encoder_fast.c", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libsmoke_oracle.so"])
     return so
 
@@ -51,6 +51,8 @@ def lib():
         L.so_encoder_frame.argtypes = [f32p, C.c_int, C.c_int, C.c_int] + [f32p] * 12 + [C.c_void_p, f32p]
         L.so_encoder_frame_fast.argtypes = [f32p, C.c_int, C.c_int, C.c_int] + [f32p] * 12 + [f32p]
         L.so_encoder_frame_fast.restype = None
+        L.so_encoder_fast_isa.argtypes = []
+        L.so_encoder_fast_isa.restype = C.c_char_p
         L.so_set_threads.argtypes = [C.c_int]
         L.so_set_threads.restype = None
         for fn in ("so_linspace so_add_source so_diffuse so_buoyancy so_divergence so_jacobi so_grad_subtract "
@@ -252,6 +254,11 @@ def encoder_features(frames, weights, input_dim=128, want_conv1=False):
 def set_threads(n):
     """OpenMP threads used by encoder_features_fast."""
     lib().so_set_threads(int(n))
+
+
+def encoder_fast_isa():
+    """Which clone of the timing-grade encoder's micro-kernel this host runs ("avx512f", "avx2+fma" or "sse2")."""
+    return lib().so_encoder_fast_isa().decode()
 
 
 def encoder_features_fast(frames, weights, input_dim=128):

@@ -388,50 +388,4 @@ SO_API void so_set_threads(int n) {
 #endif
 }
 
-/* ------------------------------------------------------------------ timing-grade encoder (cpu_baseline only)
- * Same maths as so_encoder_frame, fp32 accumulation, rows vectorised, OpenMP over output channels: the port that
- * bench.py times as the CPU baseline.  Checked against the fp64 version in tests/test_oracle_golden.py. */
-static void conv_rows_f32(const float *in, int Cin, int H, int W, const float *wgt, const float *bias, int Cout, int K,
-                          const float *bn_w, const float *bn_b, const float *bn_mean, const float *bn_var, float *out) {
-    const int P = K / 2;
-#pragma omp parallel for schedule(static)
-    for (int co = 0; co < Cout; ++co) {
-        float *o = out + (size_t)co * H * W;
-        for (size_t k = 0; k < (size_t)H * W; ++k) o[k] = 0.0f;
-        for (int ci = 0; ci < Cin; ++ci)
-            for (int ki = 0; ki < K; ++ki)
-                for (int kj = 0; kj < K; ++kj) {
-                    const float wv = wgt[(((size_t)co * Cin + ci) * K + ki) * K + kj];
-                    const int dj = kj - P, di = ki - P;
-                    const int j0 = dj < 0 ? -dj : 0, j1 = dj > 0 ? W - dj : W;
-                    for (int i = 0; i < H; ++i) {
-                        const int ii = i + di;
-                        if (ii < 0 || ii >= H) continue;
-                        const float *src = in + ((size_t)ci * H + ii) * W + dj;
-                        float *dst = o + (size_t)i * W;
-                        for (int j = j0; j < j1; ++j) dst[j] += wv * src[j];
-                    }
-                }
-        const float inv = 1.0f / sqrtf(bn_var[co] + 1e-5f), sc = inv * bn_w[co];
-        const float sh = (bias[co] - bn_mean[co]) * sc + bn_b[co];
-        for (size_t k = 0; k < (size_t)H * W; ++k) {
-            float y = o[k] * sc + sh;
-            o[k] = y > 0.0f ? y : 0.0f;
-        }
-    }
-}
-
-SO_API void so_encoder_frame_fast(const float *frame, int H, int W, int input_dim,
-                                  const float *c1w, const float *c1b, const float *bn1w, const float *bn1b,
-                                  const float *bn1m, const float *bn1v,
-                                  const float *c2w, const float *c2b, const float *bn2w, const float *bn2b,
-                                  const float *bn2m, const float *bn2v, float *features) {
-    float *a1 = (float *)malloc(sizeof(float) * 64 * (size_t)H * W);
-    float *a2 = (float *)malloc(sizeof(float) * 128 * (size_t)H * W);
-    float *pl = (float *)malloc(sizeof(float) * 128 * (size_t)input_dim * input_dim);
-    conv_rows_f32(frame, 1, H, W, c1w, c1b, 64, 7, bn1w, bn1b, bn1m, bn1v, a1);
-    conv_rows_f32(a1, 64, H, W, c2w, c2b, 128, 3, bn2w, bn2b, bn2m, bn2v, a2);
-    adaptive_pool(a2, 128, H, W, input_dim, input_dim, pl);
-    adaptive_pool(pl, 128, input_dim, input_dim, 32, 32, features);
-    free(a1); free(a2); free(pl);
-}
+/* (the timing-grade encoder bench.py's cpu_baseline uses lives in encoder_fast.c) */

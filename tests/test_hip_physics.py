@@ -93,6 +93,22 @@ def test_trajectory_bit_exact_vs_golden(golden, N, steps):
     assert rel_err(frames[0, -1].cpu().numpy(), g["final_frame_fractal"]) < 1e-6     # sin/cos differ by ulps
 
 
+def test_config0_one_source_64_50_steps_bit_exact_vs_reference(golden):
+    """BASELINE configs[0] -- 64 x 64, one source (32, 32, r 8, 1.0), 50 solver steps -- on the HIP path against the reference's own
+    fixture: end state bit-identical, the per-step density sums (fp64 sum of each returned frame) to summation-order accuracy, the same 8
+    samples (benchmark.py --num_samples 8) as ONE batch of 8 grids."""
+    g = golden("physics_traj_64_1src_50.npz")
+    sim = SmokeSimulator((64, 64), batch_size=8)
+    sim.ns_solver.density = torch.from_numpy(np.broadcast_to(g["src_density"], (8, 64, 64)).copy())
+    frames = sim.simulate_sequence(50, add_fractal=False)
+    for b in range(8):
+        for k in KEYS:
+            np.testing.assert_array_equal(getattr(sim.ns_solver, k)[b].cpu().numpy(), g[f"final_{k}"], err_msg=f"grid {b} {k}")
+    sums = frames[3].double().sum(dim=(1, 2)).cpu().numpy()
+    np.testing.assert_allclose(sums, g["density_sums"], rtol=1e-12)
+    assert abs(sums[-1] - 34.338299) < 1e-4                     # SURVEY 8c sanity value
+
+
 def test_add_source_and_run_vs_reference(golden):
     g = golden("physics_traj_64_2src_50.npz")
     sim = SmokeSimulator((64, 64))
