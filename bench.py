@@ -119,6 +119,46 @@ def cpu_baseline(N, J, weights, budget_frames):
             "reference_on_8_cores_in_build_container": "6.45 frames/s (BASELINE.md: actual reference code, torch CPU/oneDNN)"}
 
 
+def dataset_leg(dev, N=128, samples=512, cpu_budget_s=8.0):
+    """SyntheticSmokeDataset generation -- per sample 1-3 sources, 20 simulate_step() frames with the fractal
+    emit, get_chaos_features() at t >= 10 (Lyapunov over the never-cleared history, box counts, histogram entropy), as the reference's
+    data_loader.py:37-99 does it (1.43 s per sample at 128^2 on 8 cores).  Here: batched stepper (64 samples per launch
+    chain), one pass of each HIP reduction and one device-to-host copy per chunk; sequences stay on the device.  Beside it the CPU oracle
+    looped per sample like the reference (bounded sample)."""
+    import oracle
+    from smokephysai_amd.utils.data_loader import SyntheticSmokeDataset
+    np.random.seed(0)
+    SyntheticSmokeDataset(num_samples=64, grid_size=(N, N), device=dev)                # warm-up (kernels, constants, allocator)
+    torch.cuda.synchronize(dev)
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    ds = SyntheticSmokeDataset(num_samples=samples, grid_size=(N, N), device=dev)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert len(ds) == samples and all(np.isfinite(list(d["chaos_features"].values())).all() for d in ds.data)
+    del ds
+    # the oracle, one sample at a time (reference loop: setup_grid, sources, 20 steps with the fractal recomputed per frame, labels)
+    np.random.seed(0)
+    sim = oracle.OracleSmokeSimulator((N, N), jacobi_iters=20, cache_fractal=False)
+    c0 = time.perf_counter()
+    done = 0
+    while done < 2 or time.perf_counter() - c0 < cpu_budget_s:
+        sim.ns_solver.setup_grid()
+        pos, inten = oracle.draw_sources((N, N))
+        sim.add_incense_source(pos, inten)
+        for t in range(20):
+            sim.simulate_step(add_fractal=True)
+            if t >= 10:
+                sim.get_chaos_features()
+        done += 1
+    cdt = time.perf_counter() - c0
+    return {"workload": f"SyntheticSmokeDataset: {samples} samples of {N}x{N}, 20 frames each + chaos labels, Jacobi-20, sim_batch 64",
+            "value": samples / dt, "unit": "samples/s", "ms_per_sample": dt / samples * 1e3, "frames_per_s": samples * 20 / dt,
+            "cpu_port": {"value": done / cdt, "unit": "samples/s", "ms_per_sample": cdt / done * 1e3, "cores": 1,
+                         "sample": f"{done} samples looped one at a time on the C oracle, {cdt:.1f} s"},
+            "reference_on_8_cores_in_build_container": "1.43 s per sample at 128^2 (BASELINE.md: actual reference code)"}
+
+
 def hbm_copy_gbs(dev):
     """Measured device-copy bandwidth (read + write bytes / time) of a 1 GiB fp32 tensor: the practical HBM ceiling
     beside the 8 TB/s spec peak used for roofline.frac (MI355X_MICROARCH.md quotes ~6.3 TB/s for a float4 copy)."""
@@ -390,6 +430,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
     ap.add_argument("--no-alt", action="store_true", help="time only --encoder-dtype (profiling runs)")
     ap.add_argument("--no-inference", action="store_true", help="skip the per-frame inference-ms measurement (metric M2)")
+    ap.add_argument("--no-dataset", action="store_true", help="skip the dataset-generation leg (samples/s at 128^2, SURVEY 8a row 16)")
     ap.add_argument("--no-config1", action="store_true", help="skip the secondary configs[1] block (128^2 x 32, Jacobi-20, fp32 encoder)")
     ap.add_argument("--train-step", dest="train_step", action="store_true", default=True,
                     help="time train.py's optimisation step (BASELINE configs[3]'s per-GPU shape: --batch frames of --grid^2, full model; "
@@ -595,6 +636,8 @@ def main(argv=None):
             out["inference_ms_per_frame"] = inference_ms(dev, N, frame, args.encoder_dtype)
         if config1 is not None:
             out["config1"] = config1
+        if world == 1 and not args.no_dataset:
+            out["dataset"] = dataset_leg(dev)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
         # what the device had run when the headline's timed region began: the W warm-up steps of the headline leg itself plus the full
@@ -602,7 +645,7 @@ def main(argv=None):
         out["effective_warmup_steps"] = {"headline_leg": W, "config1_leg_before": (W + K) if config1 is not None else 0,
                                          "alt_leg_before": (W + K) if alt is not None else 0,
                                          "total_steps_before_timed_region": W + ((W + K) if config1 is not None else 0) + ((W + K) if alt is not None else 0)}
-        out["leg_order"] = leg_order + [k for k in ("inference_ms_per_frame", "cpu_baseline") if k in out] + (["train_step"] if args.train_step else [])
+        out["leg_order"] = leg_order + [k for k in ("inference_ms_per_frame", "dataset", "cpu_baseline") if k in out] + (["train_step"] if args.train_step else [])
 
     exit_code = 0
     if args.train_step:

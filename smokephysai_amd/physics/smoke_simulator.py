@@ -70,7 +70,9 @@ class SmokeSimulator(nn.Module):
         lyap = [0.0] * cur.shape[0]
         if len(self.history) >= 20:
             states = torch.stack(self.history[-20:], dim=1)             # [B,20,H,W]
-            lyap = [lyapunov_from_norms(frame_diff_norms(states[b]).cpu().numpy()) for b in range(cur.shape[0])]
+            # one launch over the flat stream of B x 20 frames and one copy to the host; the pair (last of grid b, first of b+1) is unused
+            d = frame_diff_norms(states.view(-1, *states.shape[2:])).cpu().numpy()
+            lyap = [lyapunov_from_norms(d[20 * b:20 * b + 19]) for b in range(cur.shape[0])]
         return [{"lyapunov_exponent": lyap[b], "fractal_dimension": fractal_dimension_from_counts(box[b]),
                  "entropy": entropy_from_hist(hist[b])} for b in range(cur.shape[0])]
 

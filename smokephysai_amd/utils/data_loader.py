@@ -71,6 +71,30 @@ def chaos_labels(seq: torch.Tensor, prev_tail: Optional[torch.Tensor], start: in
     return labels_from_stats(d, box.cpu().numpy(), hist.cpu().numpy(), T, off, start)
 
 
+HIST_TAIL = 19      # frames of earlier samples a Lyapunov window can reach back into (smoke_simulator.py:69-79: the last 20 states)
+
+
+def chunk_chaos_labels(buf: torch.Tensor, n_samples: int, T: int, valid_head: int, start: int = 10) -> List[Tuple[dict, List[dict]]]:
+    """Labels of a whole chunk of samples from ONE pass of each reduction and one device-to-host copy per result.
+
+    buf [HIST_TAIL + n_samples * T, H, W]: the last HIST_TAIL frames the simulator history held before this chunk (only the final
+    `valid_head` of them are real), then the chunk's samples back to back -- the order in which the reference's never-cleared history
+    sees them (data_loader.py:46 resets only the solver), so the distance between the last frame of sample i-1 and the first of sample i
+    is simply one more pair of the flat stream.  Launches: smk_frame_diff_norms over the stream, smk_chaos_stats over the chunk's
+    frames (all T per sample; t < start is 2x redundant work on a reduction that costs microseconds, and keeps one frame stride)."""
+    frames = buf[HIST_TAIL:]
+    d = frame_diff_norms(buf).cpu().numpy()                                   # d[k] = ||buf[k+1] - buf[k]||
+    _, box, hist = chaos_stats(frames)
+    box, hist = box.cpu().numpy(), hist.cpu().numpy()
+    out = []
+    for i in range(n_samples):
+        off = min(HIST_TAIL, valid_head + i * T)                              # earlier frames the history holds for this sample
+        lo = HIST_TAIL + i * T - off                                          # buf index of the first of them
+        sl = slice(i * T + start, (i + 1) * T)
+        out.append(labels_from_stats(d[lo:HIST_TAIL + (i + 1) * T - 1], box[sl], hist[sl], T, off, start))
+    return out
+
+
 class SyntheticSmokeDataset(Dataset):
     """Same constructor/items as the reference (data_loader.py:13-123).  Extra keyword-only knobs:
     sim_batch (grids per launch), jacobi_iters, storage_device (where sequences are kept; default = device),
@@ -105,23 +129,31 @@ class SyntheticSmokeDataset(Dataset):
         cfgs = draw_source_configs(self.num_samples, self.grid_size)       # every rank draws the full list
         lo, hi = shard_range(self.num_samples, self.rank, self.world)
         first = max(lo - 1, 0)                                              # one extra sample: its frames seed the history
-        data, prev_tail = [], None
+        data = []
         T = self.sequence_length
+        H, W = self.grid_size
+        tail, valid_head = None, 0                                          # the history's last HIST_TAIL frames before the chunk
         for c0 in range(first, hi, self.sim_batch):
             c1 = min(c0 + self.sim_batch, hi)
-            sim = SmokeSimulator(self.grid_size, device=dev, batch_size=c1 - c0, jacobi_iters=self.jacobi_iters)
+            n = c1 - c0
+            sim = SmokeSimulator(self.grid_size, device=dev, batch_size=n, jacobi_iters=self.jacobi_iters)
             srcs = [(i - c0, x, y, 8, inten) for i in range(c0, c1)
                     for (x, y), inten in zip(cfgs[i]["positions"], cfgs[i]["intensities"])]
             sim.ns_solver.add_smoke_sources(srcs)
-            seqs = sim.simulate_sequence(T, add_fractal=True)              # [chunk, T, H, W]
+            # one buffer per chunk: [history tail | sample 0's T frames | sample 1's ...]; the stepper writes the frames in place
+            buf = torch.empty(HIST_TAIL + n * T, H, W, device=dev)
+            if tail is not None:
+                buf[HIST_TAIL - tail.shape[0]:HIST_TAIL] = tail
+            seqs = buf[HIST_TAIL:].view(n, T, H, W)
+            sim.simulate_sequence(T, add_fractal=True, out=seqs)            # raises here if a persistent projection timed out
+            labels = chunk_chaos_labels(buf, n, T, valid_head)
             for i in range(c0, c1):
-                seq = seqs[i - c0]
                 if i >= lo:
-                    avg, _ = chaos_labels(seq, prev_tail)
-                    data.append({"sequence": seq.to(self.storage_device).clone(), "chaos_features": avg,
+                    data.append({"sequence": seqs[i - c0].to(self.storage_device).clone(), "chaos_features": labels[i - c0][0],
                                  "source_config": cfgs[i]})
-                # the reference's history keeps the last 100 frames across samples (smoke_simulator.py:41-43)
-                prev_tail = seq if prev_tail is None else torch.cat([prev_tail, seq])[-100:]
+            # the reference's history keeps the last 100 frames across samples (smoke_simulator.py:41-43); 19 can matter
+            tail = buf[HIST_TAIL - valid_head:][-HIST_TAIL:].clone()        # (buf[HIST_TAIL - valid_head:] = every real frame in the buffer)
+            valid_head = tail.shape[0]
             del sim
         return data
 

@@ -40,6 +40,28 @@ def test_dataset_matches_reference_frame_stream(golden, N, nsamp):
     np.testing.assert_allclose(item["chaos_features"].numpy(), g["item0_seed123_chaos"], rtol=1e-3, atol=1e-6)
 
 
+def test_chunked_labels_equal_per_sample_labels_across_chunk_boundaries():
+    """The generator labels a whole chunk from one pass of each reduction (utils.data_loader.chunk_chaos_labels); the per-sample form
+    (chaos_labels: the sample's frames behind the 19 frames the never-cleared history held before it, data_loader.py:46,71-88) must give
+    the same numbers -- 7 samples in chunks of 3, so the history crosses samples AND chunks, and the first sample has no history."""
+    from smokephysai_amd.utils.data_loader import chaos_labels
+    np.random.seed(5)
+    ds = SyntheticSmokeDataset(num_samples=7, grid_size=(64, 64), device="cuda", sim_batch=3)
+    prev = None
+    lyap = []
+    for i, s in enumerate(ds.data):
+        seq = s["sequence"]
+        avg, _ = chaos_labels(seq, prev)
+        for k in ("lyapunov_exponent", "fractal_dimension", "entropy"):
+            assert s["chaos_features"][k] == avg[k], (i, k)
+        lyap.append(avg["lyapunov_exponent"])
+        prev = seq if prev is None else torch.cat([prev, seq])[-100:]
+    np.random.seed(5)
+    whole = SyntheticSmokeDataset(num_samples=7, grid_size=(64, 64), device="cuda", sim_batch=64)
+    for a, b in zip(ds.data, whole.data):
+        assert torch.equal(a["sequence"], b["sequence"]) and a["chaos_features"] == b["chaos_features"]
+
+
 def test_chaos_stat_kernels_exact_vs_reference_and_oracle(golden):
     """HIP chaos-statistics reductions: box counts and histogram counts are integer work -> exact against the
     reference's captured values and against the CPU oracle on random frames; norms / means within fp32 rounding."""
