@@ -241,3 +241,95 @@ def test_interpolation_helpers_vs_reference(golden, name):
     R, C = f.shape
     edge = (y == R - 1) | (x == C - 1)                       # the quirk: exactly 0 on the upper clamp edge
     assert edge.sum() >= 30 and np.all(g[f"{name}_bilinear"][edge & (y <= R - 1) & (x <= C - 1)] == 0)
+
+
+# ---- the N-D restatement (oracle/ns_nd.py = SPEC_3D.md's executable form): its 2-D instance against the reference's own fixtures --------
+def _nd(shape, **kw):
+    from oracle.ns_nd import OracleNSnd
+    return OracleNSnd(shape, **kw)
+
+
+@pytest.mark.parametrize("tag,shape", [("s1", (64, 64)), ("s2", (64, 64)), ("r1", (40, 56))])
+def test_nd_oracle_2d_instance_stages_bit_exact_vs_reference(golden, tag, shape):
+    """Every stage of a step (buoyancy, 3 diffusions, divergence, projection, 3 advections, the fused step) of the generic N-D code with
+    a 2-tuple grid == the reference's captured states, bit for bit: the 3-D oracle is this code with one more axis."""
+    g = golden("physics_stages_64.npz")
+    ns = _nd(shape)
+    _load_state(ns, g, f"{tag}_in")
+    ns.buoyancy()
+    _assert_state(ns, g, f"{tag}_buoy")
+    ns.diffuse_all()
+    _assert_state(ns, g, f"{tag}_diff")
+    np.testing.assert_array_equal(ns.divergence(), g[f"{tag}_div"])
+    ns.pressure_projection()
+    _assert_state(ns, g, f"{tag}_proj")
+    ns.u = ns.advection_step(ns.u, [ns.u, ns.v])
+    _assert_state(ns, g, f"{tag}_advu")
+    ns.v = ns.advection_step(ns.v, [ns.u, ns.v])
+    _assert_state(ns, g, f"{tag}_advv")
+    ns.density = ns.advection_step(ns.density, [ns.u, ns.v])
+    _assert_state(ns, g, f"{tag}_advd")
+    ns2 = _nd(shape)
+    _load_state(ns2, g, f"{tag}_in")
+    ns2.step()
+    _assert_state(ns2, g, f"{tag}_out")
+
+
+@pytest.mark.parametrize("name,N,steps", [("physics_traj_64_1src_50.npz", 64, 50), ("physics_traj_64_2src_50.npz", 64, 50),
+                                          ("physics_traj_128_2src_100.npz", 128, 100)])
+def test_nd_oracle_2d_instance_trajectories_bit_exact_vs_reference(golden, name, N, steps):
+    g = golden(name)
+    ns = _nd((N, N))
+    ns.density = g["src_density"].copy()
+    for _ in range(steps):
+        ns.step()
+    for k in ("u", "v", "p", "density"):
+        np.testing.assert_array_equal(getattr(ns, k), g[f"final_{k}"], err_msg=k)
+
+
+def test_nd_oracle_2d_instance_backtrace_indices_and_sources(golden):
+    g = golden("backtrace_64.npz")
+    ns = _nd((48, 48))
+    ns.u, ns.v, ns.density = g["big_u"].copy(), g["big_v"].copy(), g["big_density"].copy()
+    for nm, fld in (("u", ns.u), ("v", ns.v), ("d", ns.density)):
+        out, (y0, x0) = ns.advection_step(fld, [ns.u, ns.v], want_indices=True)
+        np.testing.assert_array_equal(x0, g[f"big_{nm}_x0"]); np.testing.assert_array_equal(y0, g[f"big_{nm}_y0"])
+        np.testing.assert_array_equal(out, g[f"big_{nm}_out"])
+    s = golden("physics_stages_64.npz")
+    ns = _nd((64, 64))
+    ns.add_smoke_source(32, 32, radius=8, intensity=1.0)
+    assert np.array_equal(ns.density != 0, s["source_density"] != 0) and rel_err(ns.density, s["source_density"]) < 5e-7
+    # and the C oracle == the N-D code on a Jacobi-100 run (the C restatement is what the 2-D GPU tests use at J = 100)
+    a, b = oracle.OracleNS((64, 64), jacobi_iters=100), _nd((64, 64), jacobi_iters=100)
+    a.density = s["source_density"].copy(); b.density = s["source_density"].copy()
+    for _ in range(5):
+        a.step(); b.step()
+    for k in ("u", "v", "p", "density"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(b, k), err_msg=k)
+
+
+def test_nd_oracle_3d_instance_properties():
+    """The 3-D instance: shapes, the zero-at-the-upper-edge quirk on every axis, the Jacobi ring, warm-started p, finite values, and
+    the u / v / w coupling (buoyancy drives v; the projection spreads it to u and w)."""
+    ns = _nd((12, 20, 16))
+    assert ns.u.shape == (12, 21, 16) and ns.v.shape == (12, 20, 17) and ns.w.shape == (13, 20, 16)
+    ns.add_smoke_source(8, 10, 6, radius=4, intensity=1.5)                 # (x, y, z)
+    assert ns.density[6, 10, 8] == np.float32(1.5) and ns.density[6, 10, 13] == 0
+    p_prev = None
+    for _ in range(4):
+        fr = ns.step()
+        assert np.isfinite(fr).all()
+        for f in (ns.u, ns.v, ns.w, ns.density):
+            # the 2-D consequence of the upper-edge quirk carries over to y and x: u (v) is not staggered along the axis it acts on, so its
+            # shifted sample lands exactly on the clamp edge in the last column (row), the velocity there is 0, the back-trace stays on the
+            # edge and the gather returns 0.  Along z it does not: w IS staggered along its own axis (SPEC_3D.md section 5)
+            assert not f[:, -1].any() and not f[:, :, -1].any()
+        assert not ns.p[0].any() and not ns.p[-1].any() and not ns.p[:, 0].any() and not ns.p[:, :, -1].any()
+        p_prev = ns.p.copy()
+    assert np.abs(ns.u).max() > 0 and np.abs(ns.v).max() > 0 and np.abs(ns.w).max() > 0
+    assert np.abs(p_prev).max() > 0 and ns.density[-1].any()
+    # the interpolation routine itself: a coordinate exactly on the upper edge of ANY axis gives 0 (weights from the clamped indices)
+    f = (np.arange(4 * 5 * 6, dtype=np.float32) + 1).reshape(4, 5, 6)
+    one = lambda z, y, x: float(ns.interpolate(f, [np.array([c], np.float32) for c in (z, y, x)])[0])
+    assert one(3.0, 1.5, 2.5) == 0.0 and one(1.5, 4.0, 2.5) == 0.0 and one(1.5, 2.5, 5.0) == 0.0
+    assert one(1.5, 2.5, 3.5) == float(np.float32(f[1:3, 2:4, 3:5].mean()))
