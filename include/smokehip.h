@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 6
+#define SMK_ABI_VERSION 7
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -127,6 +127,51 @@ int smk_sim_fractal(smk_sim *sim, int32_t kind, const float **dev_ptr);
  * projection's kernel, bands per grid, launches and sweeps per launch.  No reference counterpart (the reference runs 20 separate
  * sweeps, navier_stokes.py:139-145); bench.py reports it beside the stencil roofline. */
 int smk_sim_describe(smk_sim *sim, char *buf, int64_t capacity);
+
+/* ------------------------------------------------------------------ 3-D simulation state (BASELINE configs[4])
+ * No reference counterpart: the reference is 2-D only (navier_stokes.py:10,21).  Semantics = SPEC_3D.md, the rule-by-rule generalisation
+ * of NavierStokesSimulator (navier_stokes.py:24-173) to grids [D][H][W]; each entry point names the 2-D method it generalises.
+ * Fields, batch-major with explicit row pitches (floats):
+ *     u [B][D][H+1][pitch_c]   v [B][D][H][pitch_v]   w [B][D+1][H][pitch_c]   p, density [B][D][H][pitch_c]
+ * Conventions as for smk_sim: caller-owned state, library-owned scratch, caller's stream, no implicit sync. */
+typedef struct smk_sim3d smk_sim3d;
+
+typedef struct smk_sim3d_desc {
+    int32_t batch, depth, height, width;
+    int32_t jacobi_iters;           /* SPEC_3D.md section 4: default 20, like navier_stokes.py:139 */
+    double dt, viscosity;
+    int32_t device_id;
+    int32_t pitch_c, pitch_v;
+    float *u, *v, *w, *p, *density;
+} smk_sim3d_desc;
+
+typedef struct smk_source3d {
+    int32_t grid;
+    int32_t x, y, z;    /* (column, row, plane): add_smoke_source(x, y, ...) of navier_stokes.py:37 with the depth index appended */
+    int32_t radius;
+    double intensity;
+} smk_source3d;
+
+/* __init__ (navier_stokes.py:9-22) / setup_grid (:24-35) / add_smoke_source (:37-48) in 3-D. */
+int smk_sim3d_create(const smk_sim3d_desc *desc, smk_sim3d **out);
+int smk_sim3d_destroy(smk_sim3d *sim);
+int smk_sim3d_reset(smk_sim3d *sim, const uint8_t *grid_mask, void *stream);
+int smk_sim3d_add_sources(smk_sim3d *sim, const smk_source3d *sources, int32_t n, void *stream);
+
+/* step() x n_steps (navier_stokes.py:151-173 -> SPEC_3D.md section 6).  After step t the density of grid b (the returned frame) is
+ * written to frames + t*frame_stride_t + b*frame_stride_b as [D][H][W] contiguous fp32 (frames may be NULL). */
+int smk_sim3d_step(smk_sim3d *sim, int32_t n_steps, float *frames, int64_t frame_stride_b, int64_t frame_stride_t, void *stream);
+
+/* Single stages of the 3-D step on the handle's state (per-stage parity tests); state is back in the caller's tensors afterwards. */
+typedef enum smk_stage3d {
+    SMK_STAGE3D_BUOY_DIFFUSE = 0, /* SPEC_3D.md 6.1-6.2 */
+    SMK_STAGE3D_PROJECT = 1,      /* section 4 */
+    SMK_STAGE3D_ADVECT_U = 2,
+    SMK_STAGE3D_ADVECT_V = 3,
+    SMK_STAGE3D_ADVECT_W = 4,
+    SMK_STAGE3D_ADVECT_D = 5      /* density advect + 0.995 decay */
+} smk_stage3d;
+int smk_sim3d_run_stage(smk_sim3d *sim, int32_t stage, void *stream);
 
 /* Stand-alone stateless ops (pure functions of the reference) -------------------------------------- */
 /* NavierStokesSimulator.diffusion_step(field, viscosity) (navier_stokes.py:50-72) on [B][R][pitch]. */

@@ -119,9 +119,17 @@ class OracleNSnd:
         return self._interp_comp(getattr(self, name) if comp is None else np.asarray(comp, F32), act, coords)
 
     def _interp_comp(self, comp, act, coords):
-        """(:99-101, :106-108) the shifted coordinate is clamped to the COMPONENT's extent along that axis."""
+        """(:99-101, :106-108) the shifted coordinate is clamped to the COMPONENT's extent along that axis.  The other coordinates are
+        clamped to the component's extent too: in 2-D that is a no-op -- with the reference's crossed pairing a field's index never
+        leaves the sampled component's extent on the un-shifted axis -- but in 3-D it is not (the planes of w number D + 1, those of u
+        and v only D; likewise rows of u vs w, columns of v vs w), and an index past the extent would give the clamped taps weights -1
+        and +1.  Clamped, it sits exactly on the upper edge and the sample is 0: the quirk's own answer (SPEC_3D.md section 5)."""
         c = list(coords)
-        c[act] = np.clip(c[act] + F32(0.5), F32(0), F32(comp.shape[act] - 1))
+        for a in range(len(c)):
+            if a == act:
+                c[a] = np.clip(c[a] + F32(0.5), F32(0), F32(comp.shape[a] - 1))
+            else:
+                c[a] = np.clip(c[a], F32(0), F32(comp.shape[a] - 1))
         return self.interpolate(comp, c)
 
     # ---- navier_stokes.py:74-95 ----

@@ -7,7 +7,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMOKEHIP_LIB") or os.path.join(_HERE, "libsmokehip.so")   # SMOKEHIP_LIB: diagnostic builds only
 
-ABI_VERSION = 6                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
+ABI_VERSION = 7                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
 SMK_ERR_TIMEOUT = -5
 SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
 SMK_ACT_NONE, SMK_ACT_GELU, SMK_ACT_RELU = 0, 1, 2
@@ -28,6 +28,18 @@ class SmkSource(C.Structure):
                 ("intensity", C.c_double)]
 
 
+class SmkSim3dDesc(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("depth", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("jacobi_iters", C.c_int32),
+                ("dt", C.c_double), ("viscosity", C.c_double), ("device_id", C.c_int32),
+                ("pitch_c", C.c_int32), ("pitch_v", C.c_int32),
+                ("u", C.c_void_p), ("v", C.c_void_p), ("w", C.c_void_p), ("p", C.c_void_p), ("density", C.c_void_p)]
+
+
+class SmkSource3d(C.Structure):
+    _fields_ = [("grid", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32), ("radius", C.c_int32),
+                ("intensity", C.c_double)]
+
+
 class SmkEncoderWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("conv1_w", "conv1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
@@ -45,6 +57,12 @@ _SIGNATURES = {
     "smk_sim_create": [C.POINTER(SmkSimDesc), C.POINTER(C.c_void_p)],
     "smk_sim_destroy": [C.c_void_p],
     "smk_sim_status": [C.c_void_p],
+    "smk_sim3d_create": [C.POINTER(SmkSim3dDesc), C.POINTER(C.c_void_p)],
+    "smk_sim3d_destroy": [C.c_void_p],
+    "smk_sim3d_reset": [C.c_void_p, C.c_char_p, C.c_void_p],
+    "smk_sim3d_add_sources": [C.c_void_p, C.POINTER(SmkSource3d), C.c_int32, C.c_void_p],
+    "smk_sim3d_step": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
+    "smk_sim3d_run_stage": [C.c_void_p, C.c_int32, C.c_void_p],
     "smk_sim_reset": [C.c_void_p, C.c_char_p, C.c_void_p],
     "smk_sim_add_sources": [C.c_void_p, C.POINTER(SmkSource), C.c_int32, C.c_void_p],
     "smk_sim_step": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_void_p],

@@ -14,6 +14,7 @@
 #include "linear.h"
 #include "norm.h"
 #include "stencil.h"
+#include "stencil3d.h"
 #include "transformer.h"
 
 namespace smk {
@@ -85,6 +86,19 @@ struct smk_sim {
     int jacobi_iters = 20;
     int device = 0;
     ProjectSync psync;    // hand-off flags / status word of the single-launch projection
+};
+
+struct smk_sim3d {
+    Geom3 g;
+    State3 s;             // caller-owned
+    State3 t;             // library scratch (u2, v2, w2, p2, d2)
+    float *div = nullptr;
+    uint8_t *dev_mask = nullptr;
+    Src3Dev *dev_src = nullptr;
+    int *dev_first = nullptr;
+    int src_cap = 0;
+    int jacobi_iters = 20;
+    int device = 0;
 };
 
 struct smk_decoder {
@@ -422,6 +436,196 @@ int smk_sim_describe(smk_sim *sim, char *buf, int64_t capacity) {
     }
     memcpy(buf, d.c_str(), d.size() + 1);
     return SMK_OK;
+}
+
+// ------------------------------------------------------------------ 3-D stepper (SPEC_3D.md)
+int smk_sim3d_create(const smk_sim3d_desc *d, smk_sim3d **out) {
+    SMK_REQUIRE(d && out, "null desc/out");
+    SMK_REQUIRE(d->batch >= 1 && d->depth >= 3 && d->height >= 3 && d->width >= 3, "batch>=1, depth,height,width>=3");
+    SMK_REQUIRE(d->pitch_c >= d->width && d->pitch_v >= d->width + 1, "pitch_c >= W and pitch_v >= W+1");
+    SMK_REQUIRE(d->jacobi_iters >= 0, "jacobi_iters >= 0");
+    SMK_REQUIRE((int64_t)d->batch * (d->depth + 1) <= 65535, "batch * (depth + 1) <= 65535 (one grid z-slice per plane)");
+    SMK_REQUIRE(d->u && d->v && d->w && d->p && d->density, "null state pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible");
+        return SMK_ERR_NO_DEVICE;
+    }
+    DeviceGuard guard(d->device_id);
+    if (guard.rc) return guard.rc;
+    smk_sim3d *sim = new smk_sim3d();
+    Geom3 &g = sim->g;
+    g.B = d->batch; g.D = d->depth; g.H = d->height; g.W = d->width; g.pc = d->pitch_c; g.pv = d->pitch_v;
+    g.su = (size_t)g.D * (g.H + 1) * g.pc; g.sv = (size_t)g.D * g.H * g.pv; g.sw = (size_t)(g.D + 1) * g.H * g.pc;
+    g.sc = (size_t)g.D * g.H * g.pc;
+    g.dt = (float)d->dt;
+    g.coef_uv = (float)(d->dt * d->viscosity);
+    g.coef_d = (float)(d->dt * (d->viscosity * 0.1));
+    g.sixth = (float)(1.0 / 6.0);
+    sim->s = {d->u, d->v, d->w, d->p, d->density};
+    sim->t = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    sim->jacobi_iters = d->jacobi_iters;
+    sim->device = d->device_id;
+    const size_t B = g.B;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](float **p, size_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, n * sizeof(float)); };
+    alloc(&sim->t.u, B * g.su); alloc(&sim->t.v, B * g.sv); alloc(&sim->t.w, B * g.sw); alloc(&sim->t.p, B * g.sc); alloc(&sim->t.d, B * g.sc);
+    alloc(&sim->div, B * g.sc);
+    if (e == hipSuccess) e = hipMalloc((void **)&sim->dev_mask, B);
+    if (e == hipSuccess) e = hipMalloc((void **)&sim->dev_first, (B + 1) * sizeof(int));
+    if (e != hipSuccess) {
+        set_error(std::string("smk_sim3d_create: ") + hipGetErrorString(e));
+        smk_sim3d_destroy(sim);
+        return SMK_ERR_HIP;
+    }
+    *out = sim;
+    return SMK_OK;
+}
+
+int smk_sim3d_destroy(smk_sim3d *sim) {
+    if (!sim) return SMK_OK;
+    DeviceGuard guard(sim->device);
+    float *ptrs[] = {sim->t.u, sim->t.v, sim->t.w, sim->t.p, sim->t.d, sim->div};
+    for (float *p : ptrs) if (p) (void)hipFree(p);
+    if (sim->dev_mask) (void)hipFree(sim->dev_mask);
+    if (sim->dev_first) (void)hipFree(sim->dev_first);
+    if (sim->dev_src) (void)hipFree(sim->dev_src);
+    delete sim;
+    return SMK_OK;
+}
+
+int smk_sim3d_reset(smk_sim3d *sim, const uint8_t *grid_mask, void *stream) {
+    SMK_REQUIRE(sim, "null sim");
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(sim->device);
+    if (guard.rc) return guard.rc;
+    const uint8_t *dm = nullptr;
+    if (grid_mask) {
+        SMK_HIP_TRY(hipMemcpyAsync(sim->dev_mask, grid_mask, sim->g.B, hipMemcpyHostToDevice, st));
+        dm = sim->dev_mask;
+    }
+    return check_launch(launch3_zero(sim->g, sim->s, dm, st), "zero_state3d");
+}
+
+int smk_sim3d_add_sources(smk_sim3d *sim, const smk_source3d *src, int32_t n, void *stream) {
+    SMK_REQUIRE(sim && (src || n == 0) && n >= 0, "null sim/sources");
+    if (n == 0) return SMK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(sim->device);
+    if (guard.rc) return guard.rc;
+    const int B = sim->g.B;
+    std::vector<int> first(B + 1, 0);
+    for (int k = 0; k < n; ++k) {
+        SMK_REQUIRE(src[k].grid >= 0 && src[k].grid < B, "source grid index out of range");
+        SMK_REQUIRE(src[k].radius >= 0, "radius >= 0");
+        first[src[k].grid + 1]++;
+    }
+    for (int b = 0; b < B; ++b) first[b + 1] += first[b];
+    std::vector<Src3Dev> host(n);
+    std::vector<int> fill(first.begin(), first.end() - 1);
+    for (int k = 0; k < n; ++k) {      // stable counting sort by grid keeps the caller's order within a grid
+        const smk_source3d &q = src[k];
+        const double r3 = (double)q.radius / 3.0;
+        host[fill[q.grid]++] = Src3Dev{q.x, q.y, q.z, q.radius, (float)(2.0 * (r3 * r3)), (float)q.intensity};
+    }
+    if (n > sim->src_cap) {
+        if (sim->dev_src) SMK_HIP_TRY(hipFree(sim->dev_src));
+        sim->dev_src = nullptr;
+        SMK_HIP_TRY(hipMalloc((void **)&sim->dev_src, (size_t)n * sizeof(Src3Dev)));
+        sim->src_cap = n;
+    }
+    SMK_HIP_TRY(hipMemcpyAsync(sim->dev_src, host.data(), (size_t)n * sizeof(Src3Dev), hipMemcpyHostToDevice, st));
+    SMK_HIP_TRY(hipMemcpyAsync(sim->dev_first, first.data(), (size_t)(B + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    const int rc = check_launch(launch3_add_sources(sim->g, sim->s.d, sim->dev_src, sim->dev_first, st), "add_sources3d");
+    if (rc) return rc;
+    SMK_HIP_TRY(hipStreamSynchronize(st));   // host staging vectors die here
+    return SMK_OK;
+}
+
+namespace {
+// one stage on the ping-pong pair: s = caller's tensors, t = scratch.  A step runs
+//   (u, v, w, d) --buoy+diffuse--> t --project (p in place via p2)--> t --advect u--> s.u --advect v--> s.v --advect w--> s.w --advect d--> s.d
+int run_stage3d(smk_sim3d *sim, int stage, float *frames, int64_t fsb, hipStream_t st) {
+    const Geom3 &g = sim->g;
+    State3 &s = sim->s, &t = sim->t;
+    switch (stage) {
+        case SMK_STAGE3D_BUOY_DIFFUSE:
+            return check_launch(launch3_buoy_diffuse(g, s, t, st), "buoy_diffuse3d");
+        case SMK_STAGE3D_PROJECT: {
+            int rc = check_launch(launch3_divergence(g, t, sim->div, st), "divergence3d");
+            if (rc) return rc;
+            rc = check_launch(launch3_jacobi(g, s.p, t.p, sim->div, sim->jacobi_iters, st), "jacobi3d");
+            if (rc) return rc;
+            return check_launch(launch3_grad_subtract(g, t, s.p, st), "grad_subtract3d");
+        }
+        case SMK_STAGE3D_ADVECT_U:
+            return check_launch(launch3_advect(g, 0, t.u, s.u, t.u, t.v, t.w, nullptr, 0, st), "advect_u3d");
+        case SMK_STAGE3D_ADVECT_V:
+            return check_launch(launch3_advect(g, 1, t.v, s.v, s.u, t.v, t.w, nullptr, 0, st), "advect_v3d");
+        case SMK_STAGE3D_ADVECT_W:
+            return check_launch(launch3_advect(g, 2, t.w, s.w, s.u, s.v, t.w, nullptr, 0, st), "advect_w3d");
+        case SMK_STAGE3D_ADVECT_D:
+            return check_launch(launch3_advect(g, 3, t.d, s.d, s.u, s.v, s.w, frames, fsb, st), "advect_d3d");
+    }
+    set_error("unknown 3-D stage");
+    return SMK_ERR_INVALID;
+}
+}  // namespace
+
+int smk_sim3d_step(smk_sim3d *sim, int32_t n_steps, float *frames, int64_t fsb, int64_t fst, void *stream) {
+    SMK_REQUIRE(sim && n_steps >= 0, "null sim / negative n_steps");
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(sim->device);
+    if (guard.rc) return guard.rc;
+    for (int t = 0; t < n_steps; ++t) {
+        float *ft = frames ? frames + (size_t)t * fst : nullptr;
+        for (int stage = SMK_STAGE3D_BUOY_DIFFUSE; stage <= SMK_STAGE3D_ADVECT_D; ++stage) {
+            const int rc = run_stage3d(sim, stage, stage == SMK_STAGE3D_ADVECT_D ? ft : nullptr, fsb, st);
+            if (rc) return rc;
+        }
+    }
+    return SMK_OK;
+}
+
+int smk_sim3d_run_stage(smk_sim3d *sim, int32_t stage, void *stream) {
+    SMK_REQUIRE(sim, "null sim");
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard guard(sim->device);
+    if (guard.rc) return guard.rc;
+    const Geom3 &g = sim->g;
+    const size_t B = g.B;
+    State3 &s = sim->s, &t = sim->t;
+    // stand-alone stage semantics: caller state in, caller state out -- the stage's inputs are first mirrored into the side it reads
+    auto cp = [&](float *dst, const float *src, size_t n) { return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st); };
+    int rc;
+    switch (stage) {
+        case SMK_STAGE3D_BUOY_DIFFUSE:
+            rc = run_stage3d(sim, stage, nullptr, 0, st);
+            if (rc) return rc;
+            SMK_HIP_TRY(cp(s.u, t.u, B * g.su)); SMK_HIP_TRY(cp(s.v, t.v, B * g.sv)); SMK_HIP_TRY(cp(s.w, t.w, B * g.sw));
+            SMK_HIP_TRY(cp(s.d, t.d, B * g.sc));
+            return SMK_OK;
+        case SMK_STAGE3D_PROJECT:
+            SMK_HIP_TRY(cp(t.u, s.u, B * g.su)); SMK_HIP_TRY(cp(t.v, s.v, B * g.sv)); SMK_HIP_TRY(cp(t.w, s.w, B * g.sw));
+            rc = run_stage3d(sim, stage, nullptr, 0, st);
+            if (rc) return rc;
+            SMK_HIP_TRY(cp(s.u, t.u, B * g.su)); SMK_HIP_TRY(cp(s.v, t.v, B * g.sv)); SMK_HIP_TRY(cp(s.w, t.w, B * g.sw));
+            return SMK_OK;
+        case SMK_STAGE3D_ADVECT_U:      // reads (u, v, w) -> writes u
+            SMK_HIP_TRY(cp(t.u, s.u, B * g.su)); SMK_HIP_TRY(cp(t.v, s.v, B * g.sv)); SMK_HIP_TRY(cp(t.w, s.w, B * g.sw));
+            return run_stage3d(sim, stage, nullptr, 0, st);
+        case SMK_STAGE3D_ADVECT_V:      // reads v (field), u (already advected), v, w -> writes v
+            SMK_HIP_TRY(cp(t.v, s.v, B * g.sv)); SMK_HIP_TRY(cp(t.w, s.w, B * g.sw));
+            return run_stage3d(sim, stage, nullptr, 0, st);
+        case SMK_STAGE3D_ADVECT_W:
+            SMK_HIP_TRY(cp(t.w, s.w, B * g.sw));
+            return run_stage3d(sim, stage, nullptr, 0, st);
+        case SMK_STAGE3D_ADVECT_D:
+            SMK_HIP_TRY(cp(t.d, s.d, B * g.sc));
+            return run_stage3d(sim, stage, nullptr, 0, st);
+    }
+    set_error("unknown 3-D stage");
+    return SMK_ERR_INVALID;
 }
 
 int smk_diffuse(const float *in, float *out, int32_t B, int32_t R, int32_t C, int32_t pitch, double dt, double viscosity,

@@ -1,0 +1,329 @@
+// 3-D stable-fluids stepper for gfx950 (BASELINE configs[4]: 512 x 512 x 64 grids, batch 8).
+//
+// Semantics: SPEC_3D.md -- the rule-by-rule generalisation of /root/reference/src/physics/navier_stokes.py:24-173 (the reference is 2-D
+// only), executable form oracle/ns_nd.py.  Arithmetic contract as in stencil.hip: one fp32 rounding per listed operation, in the listed
+// order (-ffp-contract=off), correctly rounded divide / sqrt, so every field is bit-identical to the oracle for identical inputs.
+//
+// Layout [B][planes][rows][pitch], x fastest, rows padded to 128-byte multiples.  Every kernel here is HBM-bound (0.2-0.3 flop per byte):
+// one thread per cell (four cells per thread as 16-byte accesses in the Jacobi sweep, which is 60 of the step's 97 floats per cell at
+// J = 20), 64 consecutive x per wavefront, z-neighbour planes served by the L2 / Infinity Cache (workgroups are issued plane-major, so
+// the planes z-1, z, z+1 of a grid are in flight together).
+#include "stencil3d.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+namespace smk {
+
+#define TX3 64
+#define TY3 4
+
+__device__ __forceinline__ float clampf3(float x, float lo, float hi) {
+    float t = x < lo ? lo : x;   // torch.clamp = min(max(x, lo), hi)
+    return t > hi ? hi : t;
+}
+__device__ __forceinline__ int clampi3(int x, int lo, int hi) {
+    int t = x < lo ? lo : x;
+    return t > hi ? hi : t;
+}
+
+// ---------------------------------------------------------------- reset (navier_stokes.py:24-35)
+__global__ void k3_zero(Geom3 g, State3 s, const uint8_t *mask) {
+    const int b = blockIdx.z / (g.D + 1), z = blockIdx.z % (g.D + 1);
+    if (mask && !mask[b]) return;
+    const int x = blockIdx.x * TX3 + threadIdx.x, y = blockIdx.y * TY3 + threadIdx.y;
+    if (z < g.D && y <= g.H && x < g.pc) s.u[b * g.su + ((size_t)z * (g.H + 1) + y) * g.pc + x] = 0.f;
+    if (z < g.D && y < g.H && x < g.pv) s.v[b * g.sv + ((size_t)z * g.H + y) * g.pv + x] = 0.f;
+    if (y < g.H && x < g.pc) s.w[b * g.sw + ((size_t)z * g.H + y) * g.pc + x] = 0.f;
+    if (z < g.D && y < g.H && x < g.pc) {
+        const size_t o = b * g.sc + ((size_t)z * g.H + y) * g.pc + x;
+        s.p[o] = 0.f;
+        s.d[o] = 0.f;
+    }
+}
+
+hipError_t launch3_zero(const Geom3 &g, State3 s, const uint8_t *dev_mask, hipStream_t st) {
+    const int maxp = g.pc > g.pv ? g.pc : g.pv;
+    dim3 grid(cdiv(maxp, TX3), cdiv(g.H + 1, TY3), g.B * (g.D + 1)), block(TX3, TY3);
+    hipLaunchKernelGGL(k3_zero, grid, block, 0, st, g, s, dev_mask);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- sources (SPEC_3D.md section 2; navier_stokes.py:37-48)
+__global__ void k3_add_sources(Geom3 g, float *density, const Src3Dev *src, const int *first) {
+    const int b = blockIdx.z / g.D, z = blockIdx.z % g.D;
+    const int s0 = first[b], s1 = first[b + 1];
+    if (s0 == s1) return;
+    const int x = blockIdx.x * TX3 + threadIdx.x, y = blockIdx.y * TY3 + threadIdx.y;
+    if (y >= g.H || x >= g.W) return;
+    float *cell = density + b * g.sc + ((size_t)z * g.H + y) * g.pc + x;
+    float d = *cell;
+    for (int s = s0; s < s1; ++s) {
+        const Src3Dev q = src[s];
+        const int dx = x - q.x, dy = y - q.y, dz = z - q.z;
+        const float dist = __fsqrt_rn((float)(dx * dx + dy * dy + dz * dz));
+        if (dist <= (float)q.radius) {
+            const float e = expf(-__fdiv_rn(dist * dist, q.denom));
+            d = d + q.fint * e;
+        }
+    }
+    *cell = d;
+}
+
+hipError_t launch3_add_sources(const Geom3 &g, float *density, const Src3Dev *src, const int *first, hipStream_t st) {
+    dim3 grid(cdiv(g.W, TX3), cdiv(g.H, TY3), g.B * g.D), block(TX3, TY3);
+    hipLaunchKernelGGL(k3_add_sources, grid, block, 0, st, g, density, src, first);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- buoyancy + diffusion (SPEC_3D.md sections 3, 6.1-6.2)
+// out = c + coef * ((((((up + down) + left) + right) + front) + back) - 6 c), replicate padding; val(z, y, x) reads the field
+template <class F>
+__device__ __forceinline__ float diffuse3_at(F val, int Dd, int R, int C, int z, int y, int x, float coef) {
+    const int yu = y > 0 ? y - 1 : 0, yd = y < R - 1 ? y + 1 : R - 1;
+    const int xl = x > 0 ? x - 1 : 0, xr = x < C - 1 ? x + 1 : C - 1;
+    const int zf = z > 0 ? z - 1 : 0, zb = z < Dd - 1 ? z + 1 : Dd - 1;
+    const float c = val(z, y, x);
+    float lap = val(z, yu, x) + val(z, yd, x);
+    lap = lap + val(z, y, xl);
+    lap = lap + val(z, y, xr);
+    lap = lap + val(zf, y, x);
+    lap = lap + val(zb, y, x);
+    lap = lap - 6.0f * c;
+    return c + coef * lap;
+}
+
+__global__ void k3_buoy_diffuse(Geom3 g, State3 in, State3 out) {
+    const int b = blockIdx.z / (g.D + 1), z = blockIdx.z % (g.D + 1);
+    const int x = blockIdx.x * TX3 + threadIdx.x, y = blockIdx.y * TY3 + threadIdx.y;
+    const int D = g.D, H = g.H, W = g.W;
+    const float *u = in.u + b * g.su, *v = in.v + b * g.sv, *w = in.w + b * g.sw, *d = in.d + b * g.sc;
+    if (z < D && y <= H && x < W) {
+        auto val = [&](int k, int i, int j) { return u[((size_t)k * (H + 1) + i) * g.pc + j]; };
+        out.u[b * g.su + ((size_t)z * (H + 1) + y) * g.pc + x] = diffuse3_at(val, D, H + 1, W, z, y, x, g.coef_uv);
+    }
+    if (z < D && y < H && x <= W) {
+        // the buoyancy-updated v that diffusion_step(v) sees: v[:, :, :-1] += dt * (density * 0.1)
+        auto val = [&](int k, int i, int j) {
+            float t = v[((size_t)k * H + i) * g.pv + j];
+            if (j < W) {
+                const float bb = d[((size_t)k * H + i) * g.pc + j] * 0.1f;
+                t = t + g.dt * bb;
+            }
+            return t;
+        };
+        out.v[b * g.sv + ((size_t)z * H + y) * g.pv + x] = diffuse3_at(val, D, H, W + 1, z, y, x, g.coef_uv);
+    }
+    if (y < H && x < W) {
+        auto val = [&](int k, int i, int j) { return w[((size_t)k * H + i) * g.pc + j]; };
+        out.w[b * g.sw + ((size_t)z * H + y) * g.pc + x] = diffuse3_at(val, D + 1, H, W, z, y, x, g.coef_uv);
+    }
+    if (z < D && y < H && x < W) {
+        auto val = [&](int k, int i, int j) { return d[((size_t)k * H + i) * g.pc + j]; };
+        out.d[b * g.sc + ((size_t)z * H + y) * g.pc + x] = diffuse3_at(val, D, H, W, z, y, x, g.coef_d);
+    }
+}
+
+hipError_t launch3_buoy_diffuse(const Geom3 &g, State3 in, State3 out, hipStream_t st) {
+    dim3 grid(cdiv(g.W + 1, TX3), cdiv(g.H + 1, TY3), g.B * (g.D + 1)), block(TX3, TY3);
+    hipLaunchKernelGGL(k3_buoy_diffuse, grid, block, 0, st, g, in, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- divergence (SPEC_3D.md section 4)
+// div = (((((u[y+1] - u[y]) + v[x+1]) - v[x]) + w[z+1]) - w[z]) / dt
+__global__ void k3_divergence(Geom3 g, State3 s, float *div) {
+    const int b = blockIdx.z / g.D, z = blockIdx.z % g.D;
+    const int x = blockIdx.x * TX3 + threadIdx.x, y = blockIdx.y * TY3 + threadIdx.y;
+    if (y >= g.H || x >= g.W) return;
+    const float *u = s.u + b * g.su + ((size_t)z * (g.H + 1) + y) * g.pc + x;
+    const float *v = s.v + b * g.sv + ((size_t)z * g.H + y) * g.pv + x;
+    const float *w = s.w + b * g.sw + ((size_t)z * g.H + y) * g.pc + x;
+    float a = u[g.pc] - u[0];
+    a = a + v[1];
+    a = a - v[0];
+    a = a + w[(size_t)g.H * g.pc];
+    a = a - w[0];
+    div[b * g.sc + ((size_t)z * g.H + y) * g.pc + x] = __fdiv_rn(a, g.dt);
+}
+
+hipError_t launch3_divergence(const Geom3 &g, State3 s, float *div, hipStream_t st) {
+    dim3 grid(cdiv(g.W, TX3), cdiv(g.H, TY3), g.B * g.D), block(TX3, TY3);
+    hipLaunchKernelGGL(k3_divergence, grid, block, 0, st, g, s, div);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- Jacobi sweep (SPEC_3D.md section 4)
+// p_new = 0 on the boundary shell; interior: (1/6) * ((((((up + down) + left) + right) + front) + back) - div)
+__global__ void k3_jacobi(Geom3 g, const float *__restrict__ p, float *__restrict__ pn, const float *__restrict__ div) {
+    const int b = blockIdx.z / g.D, z = blockIdx.z % g.D;
+    const int x = blockIdx.x * TX3 + threadIdx.x, y = blockIdx.y * TY3 + threadIdx.y;
+    if (y >= g.H || x >= g.W) return;
+    const size_t o = b * g.sc + ((size_t)z * g.H + y) * g.pc + x, ps = (size_t)g.H * g.pc;
+    float r = 0.f;
+    if (z > 0 && z < g.D - 1 && y > 0 && y < g.H - 1 && x > 0 && x < g.W - 1) {
+        float s = p[o - g.pc] + p[o + g.pc];
+        s = s + p[o - 1];
+        s = s + p[o + 1];
+        s = s + p[o - ps];
+        s = s + p[o + ps];
+        s = s - div[o];
+        r = g.sixth * s;
+    }
+    pn[o] = r;
+}
+
+// Four cells per thread (W % 4 == 0): rows as 16-byte accesses, the two x-neighbours outside the quad as scalar loads (same lines)
+__global__ void k3_jacobi4(Geom3 g, const float *__restrict__ p, float *__restrict__ pn, const float *__restrict__ div) {
+    const int b = blockIdx.z / g.D, z = blockIdx.z % g.D;
+    const int x = (blockIdx.x * TX3 + threadIdx.x) * 4, y = blockIdx.y * TY3 + threadIdx.y;
+    if (y >= g.H || x >= g.W) return;
+    const size_t o = b * g.sc + ((size_t)z * g.H + y) * g.pc + x, ps = (size_t)g.H * g.pc;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (z > 0 && z < g.D - 1 && y > 0 && y < g.H - 1) {
+        const float4 up = *reinterpret_cast<const float4 *>(p + o - g.pc), dn = *reinterpret_cast<const float4 *>(p + o + g.pc);
+        const float4 fr = *reinterpret_cast<const float4 *>(p + o - ps), bk = *reinterpret_cast<const float4 *>(p + o + ps);
+        const float4 c = *reinterpret_cast<const float4 *>(p + o), dv = *reinterpret_cast<const float4 *>(div + o);
+        const float lft = x > 0 ? p[o - 1] : 0.f, rgt = x + 4 < g.W ? p[o + 4] : 0.f;
+        auto cell = [&](float u_, float d_, float l_, float r_, float f_, float b_, float dv_) {
+            float s = u_ + d_;
+            s = s + l_;
+            s = s + r_;
+            s = s + f_;
+            s = s + b_;
+            s = s - dv_;
+            return g.sixth * s;
+        };
+        r.x = x > 0 ? cell(up.x, dn.x, lft, c.y, fr.x, bk.x, dv.x) : 0.f;
+        r.y = cell(up.y, dn.y, c.x, c.z, fr.y, bk.y, dv.y);
+        r.z = cell(up.z, dn.z, c.y, c.w, fr.z, bk.z, dv.z);
+        r.w = x + 4 < g.W ? cell(up.w, dn.w, c.z, rgt, fr.w, bk.w, dv.w) : 0.f;
+    }
+    *reinterpret_cast<float4 *>(pn + o) = r;
+}
+
+hipError_t launch3_jacobi(const Geom3 &g, float *p, float *p2, const float *div, int iters, hipStream_t st) {
+    float *cur = p, *nxt = p2;
+    const bool vec = g.W % 4 == 0 && g.pc % 4 == 0 && getenv("SMK_JACOBI3_SCALAR") == nullptr;
+    dim3 block(TX3, TY3), grid(cdiv(vec ? g.W / 4 : g.W, TX3), cdiv(g.H, TY3), g.B * g.D);
+    for (int it = 0; it < iters; ++it) {
+        if (vec) hipLaunchKernelGGL(k3_jacobi4, grid, block, 0, st, g, cur, nxt, div);
+        else hipLaunchKernelGGL(k3_jacobi, grid, block, 0, st, g, cur, nxt, div);
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != p) {
+        const hipError_t e = hipMemcpyAsync(p, cur, (size_t)g.B * g.sc * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- gradient subtraction (SPEC_3D.md section 4)
+// u[:,1:-1,:] -= dt (p[:,1:,:] - p[:,:-1,:]);  v[:,:,1:-1] -= dt (p[:,:,1:] - p[:,:,:-1]);  w[1:-1] -= dt (p[1:] - p[:-1])
+__global__ void k3_grad_subtract(Geom3 g, State3 s, const float *p) {
+    const int b = blockIdx.z / g.D, z = blockIdx.z % g.D;
+    const int x = blockIdx.x * TX3 + threadIdx.x, y = blockIdx.y * TY3 + threadIdx.y;
+    if (y >= g.H || x >= g.W) return;
+    const float *pb = p + b * g.sc + ((size_t)z * g.H + y) * g.pc + x;
+    const float pc = pb[0];
+    if (y >= 1) {
+        float *c = s.u + b * g.su + ((size_t)z * (g.H + 1) + y) * g.pc + x;
+        const float gr = pc - pb[-g.pc];
+        *c = *c - g.dt * gr;
+    }
+    if (x >= 1) {
+        float *c = s.v + b * g.sv + ((size_t)z * g.H + y) * g.pv + x;
+        const float gr = pc - pb[-1];
+        *c = *c - g.dt * gr;
+    }
+    if (z >= 1) {
+        float *c = s.w + b * g.sw + ((size_t)z * g.H + y) * g.pc + x;
+        const float gr = pc - pb[-(ptrdiff_t)((size_t)g.H * g.pc)];
+        *c = *c - g.dt * gr;
+    }
+}
+
+hipError_t launch3_grad_subtract(const Geom3 &g, State3 s, const float *p, hipStream_t st) {
+    dim3 grid(cdiv(g.W, TX3), cdiv(g.H, TY3), g.B * g.D), block(TX3, TY3);
+    hipLaunchKernelGGL(k3_grad_subtract, grid, block, 0, st, g, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- advection (SPEC_3D.md section 5)
+// A velocity component sampled at a field's INTEGER index (z, y, x), shifted +0.5 along the axis it acts on, every coordinate clamped to
+// the component's extent: the un-shifted axes put weight (i1 - c) = 1 on the low tap while the index is below the upper edge and 0 on it,
+// the shifted axis gives 0.5 / 0.5 below the edge and lands exactly on the edge otherwise (both weights 0).  So the eight-term
+// interpolation collapses EXACTLY to 0.5 c[lo] + 0.5 c[hi] when every index is <= extent - 2, and to 0 otherwise (the dropped terms are
+// products with an exact zero weight: at most the sign of a zero, which index - dt * velocity cannot see).
+template <int ACT>
+__device__ __forceinline__ float vel3_at(const float *c, int Dc, int Hc, int Wc, int pitch, int z, int y, int x) {
+    if (z > Dc - 2 || y > Hc - 2 || x > Wc - 2) return 0.f;
+    const size_t o = ((size_t)z * Hc + y) * pitch + x;
+    const size_t step = ACT == 2 ? (size_t)1 : (ACT == 1 ? (size_t)pitch : (size_t)Hc * pitch);
+    return 0.5f * c[o] + 0.5f * c[o + step];
+}
+
+// interpolate(field, pz, py, px): floor -> indices clamped -> weights from the CLAMPED indices, (wx * wy) * wz, eight terms z-low plane
+// first, x fastest, low before high
+__device__ __forceinline__ float interp3(const float *f, int Df, int Hf, int Wf, int pitch, float pz, float py, float px) {
+    int x0 = (int)floorf(px), y0 = (int)floorf(py), z0 = (int)floorf(pz);
+    int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    x0 = clampi3(x0, 0, Wf - 1); x1 = clampi3(x1, 0, Wf - 1);
+    y0 = clampi3(y0, 0, Hf - 1); y1 = clampi3(y1, 0, Hf - 1);
+    z0 = clampi3(z0, 0, Df - 1); z1 = clampi3(z1, 0, Df - 1);
+    const float wx0 = (float)x1 - px, wx1 = px - (float)x0;
+    const float wy0 = (float)y1 - py, wy1 = py - (float)y0;
+    const float wz0 = (float)z1 - pz, wz1 = pz - (float)z0;
+    const size_t r00 = ((size_t)z0 * Hf + y0) * pitch, r01 = ((size_t)z0 * Hf + y1) * pitch;
+    const size_t r10 = ((size_t)z1 * Hf + y0) * pitch, r11 = ((size_t)z1 * Hf + y1) * pitch;
+    float acc = ((wx0 * wy0) * wz0) * f[r00 + x0];
+    acc = acc + ((wx1 * wy0) * wz0) * f[r00 + x1];
+    acc = acc + ((wx0 * wy1) * wz0) * f[r01 + x0];
+    acc = acc + ((wx1 * wy1) * wz0) * f[r01 + x1];
+    acc = acc + ((wx0 * wy0) * wz1) * f[r10 + x0];
+    acc = acc + ((wx1 * wy0) * wz1) * f[r10 + x1];
+    acc = acc + ((wx0 * wy1) * wz1) * f[r11 + x0];
+    acc = acc + ((wx1 * wy1) * wz1) * f[r11 + x1];
+    return acc;
+}
+
+// WHICH 0..3 = u, v, w, density: the field's own extents and pitch
+template <int WHICH>
+__global__ void k3_advect(Geom3 g, const float *__restrict__ field, float *__restrict__ out, const float *__restrict__ u,
+                          const float *__restrict__ v, const float *__restrict__ w, float *__restrict__ frames, int64_t fsb) {
+    const int Df = g.D + (WHICH == 2), Hf = g.H + (WHICH == 0), Wf = g.W + (WHICH == 1);
+    const int pitch = WHICH == 1 ? g.pv : g.pc;
+    const size_t fs = WHICH == 0 ? g.su : (WHICH == 1 ? g.sv : (WHICH == 2 ? g.sw : g.sc));
+    const int b = blockIdx.z / Df, z = blockIdx.z % Df;
+    const int x = blockIdx.x * TX3 + threadIdx.x, y = blockIdx.y * TY3 + threadIdx.y;
+    if (y >= Hf || x >= Wf) return;
+    const float ui = vel3_at<2>(u + b * g.su, g.D, g.H + 1, g.W, g.pc, z, y, x);
+    const float vi = vel3_at<1>(v + b * g.sv, g.D, g.H, g.W + 1, g.pv, z, y, x);
+    const float wi = vel3_at<0>(w + b * g.sw, g.D + 1, g.H, g.W, g.pc, z, y, x);
+    const float tx = g.dt * ui, ty = g.dt * vi, tz = g.dt * wi;
+    const float px = clampf3((float)x - tx, 0.f, (float)(Wf - 1));
+    const float py = clampf3((float)y - ty, 0.f, (float)(Hf - 1));
+    const float pz = clampf3((float)z - tz, 0.f, (float)(Df - 1));
+    float r = interp3(field + b * fs, Df, Hf, Wf, pitch, pz, py, px);
+    if (WHICH == 3) {
+        r = r * 0.995f;                                       // navier_stokes.py:171
+        if (frames) frames[(size_t)b * fsb + ((size_t)z * g.H + y) * g.W + x] = r;
+    }
+    out[b * fs + ((size_t)z * Hf + y) * pitch + x] = r;
+}
+
+hipError_t launch3_advect(const Geom3 &g, int which, const float *field, float *out, const float *u, const float *v, const float *w,
+                          float *frames, int64_t fsb, hipStream_t st) {
+    const int Df = g.D + (which == 2), Hf = g.H + (which == 0), Wf = g.W + (which == 1);
+    dim3 grid(cdiv(Wf, TX3), cdiv(Hf, TY3), g.B * Df), block(TX3, TY3);
+    switch (which) {
+        case 0: hipLaunchKernelGGL(k3_advect<0>, grid, block, 0, st, g, field, out, u, v, w, frames, fsb); break;
+        case 1: hipLaunchKernelGGL(k3_advect<1>, grid, block, 0, st, g, field, out, u, v, w, frames, fsb); break;
+        case 2: hipLaunchKernelGGL(k3_advect<2>, grid, block, 0, st, g, field, out, u, v, w, frames, fsb); break;
+        case 3: hipLaunchKernelGGL(k3_advect<3>, grid, block, 0, st, g, field, out, u, v, w, frames, fsb); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace smk
