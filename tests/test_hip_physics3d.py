@@ -1,8 +1,8 @@
 """Parity of the 3-D stepper (csrc/stencil3d.hip, BASELINE configs[4]) through the C ABI (smk_sim3d_*) against oracle/ns_nd.py, the
 executable form of SPEC_3D.md -- the same code whose 2-D instance tests/test_oracle_golden.py holds bit-exact to the reference's fixtures
 (the reference itself is 2-D only: navier_stokes.py:10,21).  Bit-exact everywhere (fp32 index and stencil work in the oracle's operation
-order); the full-size case (8 grids of 512 x 512 x 64) uses a size-independent property: a compact source far from the y / x walls evolves,
-for one time step, exactly like the same source in a small grid (the pressure's support grows one cell per Jacobi sweep)."""
+order); the full-size case (8 grids of 512 x 512 x 64) uses a size-independent property: for one time step a compact source evolves exactly
+like the same source in a small grid that contains its neighbourhood (the pressure's support grows one cell per Jacobi sweep)."""
 import numpy as np
 import pytest
 import torch
@@ -125,37 +125,60 @@ def test_reset_of_a_grid_subset_and_loud_failures():
         NavierStokesSimulator3D((16, 16))
 
 
-def test_config4_full_size_step_equals_small_grid_oracle_by_translation():
-    """BASELINE configs[4] as stated: 8 grids of 512 x 512 x 64 (D = 64), Jacobi-20.  Every grid gets one compact source at a different
-    (x, y), at least 48 cells from the y / x walls, full depth shared.  In one step nothing travels farther than radius + 1 (diffusion) +
-    20 (one cell per sweep) + 2 cells, so the 96 x 96 window around the source must equal, bit for bit, the oracle's step on a
-    64 x 96 x 96 grid with the source at its centre -- and every cell outside the window must still be exactly 0."""
-    D, H, W, B, R = 64, 512, 512, 8, 96
+def test_config4_full_size_step_vs_small_grid_oracle():
+    """BASELINE configs[4] as stated: 8 grids of 512 x 512 x 64 (D = 64), Jacobi-20, one step.  In one step nothing travels farther than
+    radius + 1 (diffusion) + 20 (the pressure's support grows one cell per sweep) + 2 cells, so a compact source evolves exactly as in a
+    small grid that contains that neighbourhood.  Every grid gets two sources that cannot interact within the step:
+      * one inside the corner window [0,128) x [0,128) (walls y = 0 / x = 0 are the real walls): the window must equal the oracle's step
+        on a 64 x 128 x 128 grid BIT FOR BIT (same index values, so the same roundings);
+      * one far away, at a different place in every grid: its 96 x 96 window against the oracle's 64 x 96 x 96 grid translated there --
+        the back-trace `index - dt * velocity` rounds differently at index 463 than at 48, so this one is held to 1e-5 of the field's
+        maximum (the path's float bar is 1e-4), not to equality;
+    and every cell outside the two windows must still be exactly 0."""
+    D, H, W, B, R, RN = 64, 512, 512, 8, 96, 128
     sim = NavierStokesSimulator3D((D, H, W), batch_size=B, jacobi_iters=20)
-    centres = [(48, 48), (463, 48), (48, 463), (463, 463), (256, 256), (100, 411), (333, 77), (200, 300)]      # (x, y)
-    srcs = [(b, cx, cy, 20 + 3 * b, 5, 1.0 + 0.1 * b) for b, (cx, cy) in enumerate(centres)]
+    far = [(300, 180), (463, 48), (48, 463), (463, 463), (256, 256), (100, 411), (333, 77), (200, 300)]        # (x, y)
+    near = [(40 + 6 * b, 90 - 7 * b) for b in range(B)]
+    srcs = []
+    for b in range(B):
+        srcs.append((b, near[b][0], near[b][1], 12 + 5 * b, 5, 1.0 + 0.1 * b))
+        srcs.append((b, far[b][0], far[b][1], 20 + 3 * b, 5, 1.5 - 0.1 * b))
     sim.add_smoke_sources(srcs)
-    dens0 = [sim.density[b, :, cy - 48:cy + 48, cx - 48:cx + 48].cpu().numpy().copy() for b, (cx, cy) in enumerate(centres)]
+    d_near = [sim.density[b, :, :RN, :RN].cpu().numpy().copy() for b in range(B)]
+    d_far = [sim.density[b, :, cy - 48:cy + 48, cx - 48:cx + 48].cpu().numpy().copy() for b, (cx, cy) in enumerate(far)]
     frame = torch.empty(B, D, H, W, device="cuda")
     sim.step_into(frame, 1)
     torch.cuda.synchronize()
     assert torch.isfinite(frame).all()
-    for b, (cx, cy) in enumerate(centres):
+
+    def window(b, y0, x0, r):
+        return {"u": sim.u[b, :, y0:y0 + r + 1, x0:x0 + r], "v": sim.v[b, :, y0:y0 + r, x0:x0 + r + 1], "w": sim.w[b, :, y0:y0 + r, x0:x0 + r],
+                "p": sim.p[b, :, y0:y0 + r, x0:x0 + r], "density": sim.density[b, :, y0:y0 + r, x0:x0 + r]}
+
+    for b in range(B):
+        o = OracleNSnd((D, RN, RN), jacobi_iters=20)
+        o.density = d_near[b]
+        out = o.step()
+        wn = window(b, 0, 0, RN)
+        for k in KEYS:
+            got = wn[k].cpu().numpy()
+            ref = getattr(o, k)
+            # the oracle's own high walls (row / column 128) force zeros the big grid does not have there; the source's reach ends far below
+            np.testing.assert_array_equal(got[:, :RN - 1, :RN - 1], ref[:, :RN - 1, :RN - 1], err_msg=f"grid {b} near {k}")
+        np.testing.assert_array_equal(frame[b, :, :RN - 1, :RN - 1].cpu().numpy(), out[:, :RN - 1, :RN - 1])
+        cx, cy = far[b]
         y0, x0 = cy - 48, cx - 48
         o = OracleNSnd((D, R, R), jacobi_iters=20)
-        o.density = dens0[b]
-        out = o.step()
-        win = {"u": sim.u[b, :, y0:y0 + R + 1, x0:x0 + R], "v": sim.v[b, :, y0:y0 + R, x0:x0 + R + 1], "w": sim.w[b, :, y0:y0 + R, x0:x0 + R],
-               "p": sim.p[b, :, y0:y0 + R, x0:x0 + R], "density": sim.density[b, :, y0:y0 + R, x0:x0 + R]}
+        o.density = d_far[b]
+        o.step()
+        wf = window(b, y0, x0, R)
         for k in KEYS:
-            np.testing.assert_array_equal(win[k].cpu().numpy(), getattr(o, k), err_msg=f"grid {b} {k}")
-        np.testing.assert_array_equal(frame[b, :, y0:y0 + R, x0:x0 + R].cpu().numpy(), out)
-        for k in KEYS:                                 # nothing outside the window
+            got, ref = wf[k].cpu().numpy(), getattr(o, k)
+            assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), (b, k, np.abs(got - ref).max(), np.abs(ref).max())
+        for k in KEYS:                                 # nothing outside the two windows
             f = getattr(sim, k)[b]
-            total = float(f.abs().sum())
-            inside = float(win[k].abs().sum())
-            assert total == inside or abs(total - inside) <= 1e-6 * total, (b, k)
             m = torch.ones_like(f, dtype=torch.bool)
-            m[:, y0:y0 + win[k].shape[1], x0:x0 + win[k].shape[2]] = False
+            m[:, :wn[k].shape[1], :wn[k].shape[2]] = False
+            m[:, y0:y0 + wf[k].shape[1], x0:x0 + wf[k].shape[2]] = False
             assert not f[m].any(), (b, k)
     assert float(sim.w.abs().max()) > 0 and float(sim.p.abs().max()) > 0
