@@ -159,6 +159,38 @@ def dataset_leg(dev, N=128, samples=512, cpu_budget_s=8.0):
             "reference_on_8_cores_in_build_container": "1.43 s per sample at 128^2 (BASELINE.md: actual reference code)"}
 
 
+def config4_leg(dev, steps=6):
+    """BASELINE configs[4], the stepper half (the conv3d encoder is not built yet): 8 grids of 512 x 512 x 64, Jacobi-20, SPEC_3D.md
+    semantics, through smk_sim3d_step.  HIP events on the launch stream; roofline = SPEC_3D.md section 7's pass-model bytes,
+    4 (37 + 3 J) per cell and step, against HBM 8 TB/s."""
+    from smokephysai_amd.physics import NavierStokesSimulator3D
+    B, D, H, W, J = 8, 64, 512, 512, 20
+    sim = NavierStokesSimulator3D((D, H, W), device=dev, batch_size=B, jacobi_iters=J)
+    rng = np.random.RandomState(4)
+    sim.add_smoke_sources([(b, int(rng.randint(40, W - 40)), int(rng.randint(40, H - 40)), int(rng.randint(10, D - 10)), 8,
+                            float(rng.uniform(0.5, 2.0))) for b in range(B) for _ in range(3)])
+    frame = torch.empty(B, D, H, W, device=dev)
+    for _ in range(2):
+        sim.step_into(frame, 1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for k in range(steps):
+        sim.step_into(frame, 1)
+        ev[k + 1].record()
+    torch.cuda.synchronize(dev)
+    assert torch.isfinite(frame).all() and float(frame.abs().sum()) > 0
+    ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]))
+    cells = B * D * H * W
+    alg = cells * 4.0 * (37 + 3 * J)
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"workload": f"configs[4] stepper: {W}x{H}x{D} grid, batch {B}, Jacobi-{J} (SPEC_3D.md; conv3d encoder not built)",
+            "value": B / (ms * 1e-3), "unit": "volumes/s", "ms_per_step": ms, "steps": steps, "dtype": "f32", "cells_per_step": cells,
+            "algorithmic_bytes_per_step": alg, "launches_per_step": 8 + J,
+            "roofline_stencil": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "note": "pass-model bytes 4*(37+3J) per cell (SPEC_3D.md section 7); every sweep is its own launch, so "
+                                         "the counted bytes are also what the kernels move"}}
+
+
 def hbm_copy_gbs(dev):
     """Measured device-copy bandwidth (read + write bytes / time) of a 1 GiB fp32 tensor: the practical HBM ceiling
     beside the 8 TB/s spec peak used for roofline.frac (MI355X_MICROARCH.md quotes ~6.3 TB/s for a float4 copy)."""
@@ -430,6 +462,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-encode", action="store_true", help="stencil only (diagnostic; not the headline metric)")
     ap.add_argument("--no-alt", action="store_true", help="time only --encoder-dtype (profiling runs)")
     ap.add_argument("--no-inference", action="store_true", help="skip the per-frame inference-ms measurement (metric M2)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] block (3-D stepper, 512x512x64 x 8)")
     ap.add_argument("--no-dataset", action="store_true", help="skip the dataset-generation leg (samples/s at 128^2, SURVEY 8a row 16)")
     ap.add_argument("--no-config1", action="store_true", help="skip the secondary configs[1] block (128^2 x 32, Jacobi-20, fp32 encoder)")
     ap.add_argument("--train-step", dest="train_step", action="store_true", default=True,
@@ -638,6 +671,8 @@ def main(argv=None):
             out["config1"] = config1
         if world == 1 and not args.no_dataset:
             out["dataset"] = dataset_leg(dev)
+        if world == 1 and not args.no_config4:
+            out["config4"] = config4_leg(dev)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
         # what the device had run when the headline's timed region began: the W warm-up steps of the headline leg itself plus the full
@@ -645,7 +680,7 @@ def main(argv=None):
         out["effective_warmup_steps"] = {"headline_leg": W, "config1_leg_before": (W + K) if config1 is not None else 0,
                                          "alt_leg_before": (W + K) if alt is not None else 0,
                                          "total_steps_before_timed_region": W + ((W + K) if config1 is not None else 0) + ((W + K) if alt is not None else 0)}
-        out["leg_order"] = leg_order + [k for k in ("inference_ms_per_frame", "dataset", "cpu_baseline") if k in out] + (["train_step"] if args.train_step else [])
+        out["leg_order"] = leg_order + [k for k in ("inference_ms_per_frame", "dataset", "config4", "cpu_baseline") if k in out] + (["train_step"] if args.train_step else [])
 
     exit_code = 0
     if args.train_step:

@@ -531,6 +531,263 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_linear_b16: the same layer on the 16x16x32 MFMA shape (v_mfma_f32_16x16x32_bf16) -- the form the full-size calls take (128-row
+// tiles, fp32 activations in and out).  Cycles per flop are those of the 32x32x16 shape; the point is the power limit: with the whole
+// chip in this kernel the shader clock falls to 1.3-1.7 GHz (stamps above), and at equal cycles the 16x16x32 shape sustains a higher
+// clock (MI355X_MICROARCH.md "Shape": 1.12-1.15 x the FLOP/s; k_encoder_b16 gained 20 % from the same change).
+//   tile 128 tokens x 32 NW columns, wave w owns columns 32w .. 32w+31 as 2 column blocks x 8 token blocks of 16 x 16 (64 accumulator
+//   registers, as before); the WEIGHTS are the MFMA's row operand, so a lane ends with 4 consecutive output columns of one token row
+//   per accumulator -> 16-byte stores.  The unit of the loop is half a 32-k step: 4 token blocks x 2 column blocks x 3 products = 24
+//   MFMAs = 384 matrix-pipe cycles (the old k-step), so the skeleton carries over: four units per 64-k chunk, the next unit's 8 token
+//   fragments read under this unit's MFMAs, staging of the chunk after next spread over units 0-2, one barrier per chunk before unit 3's
+//   reads of the other buffer.  Weight fragments come from the SAME pre-split layout ([K/16][hi|lo][N][16]: lane group g = lane >> 4
+//   takes k = 8g .. 8g+7 of the 32-k step, i.e. half of k16 block (g >> 1)) through a ring two 32-k steps deep, all four loads of step
+//   s+1 issued behind the first MFMAs of step s.
+//   Token image in LDS: [128 rows][64 k] bf16 per plane, UNPADDED 128-byte rows with the 16-byte unit u of row r stored at u ^ (r & 7):
+//   conflict-free for this shape's ds_read_b128 (lanes {0-3, 12-15, 20-27} together: 8 rows of one k-group with 8 rows of the next) and
+//   for the 8-byte staging stores, found by search over pitches x swizzles; 65 KB per workgroup instead of 74.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int TM = 128, TN = NW * 32, RP = NW * 4, NP = TM / RP, PLANE = TM * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.l.K, N = a.l.N, M = a.c.M;
+    const int nchunks = K >> 6, nks = nchunks * 2;           // 32-k steps
+    const int vid = a.swz ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;    // XCD-contiguous ids (see k_linear_x3)
+    const int tn = vid % a.tiles_n, tm_step = (int)gridDim.x / a.tiles_n;
+    int tm = vid / a.tiles_n;
+    const int ncol0 = tn * TN + wave * 32;
+    const bool nw_ok = ncol0 < N;                            // N % 32 == 0: a wave's 32 columns are all inside or all outside
+
+    // ---- weight ring: per 32-k step four 16-byte loads per lane (column block 0 / 1 x hi / lo) at a lane-constant offset from a scalar base
+    const int lane_b = nw_ok ? (g >> 1) * (N * 64) + (ncol0 + l16) * 32 + (g & 1) * 16 : 0;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.l.wq), 0, K * N * 4, 0x00020000);
+    const int step_bytes = N * 128, part_bytes = N * 32;     // one 32-k step = two k16 blocks x (hi | lo) planes of N x 32 bytes
+    uint4 bq[2][4];                                          // [ring slot = step parity][nb * 2 + part]
+    auto load_b = [&](int slot, int kn) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b + nb * 512, kn * step_bytes + part * part_bytes, 0);
+                bq[slot][nb * 2 + part] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+    };
+    load_b(0, 0);
+
+    // ---- token staging (as k_linear_x3, fp32 source): thread = float4 column sc of rows sr, sr + RP, ...
+    const int sc = tid & 15, sr = tid >> 4;
+    float4 stage[NP];
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.c.x), 0, (int)(((long long)(M - 1) * a.c.ldx + K) * 4), 0x00020000);
+    const int ldxb = (int)a.c.ldx * 4;
+    const int lane_x = sr * ldxb + sc * 16;
+    auto stage_load = [&](int tmx, int cx, int j) {
+        const unsigned off = ((unsigned)tmx * TM + RP * j) * (unsigned)ldxb + (unsigned)cx * 256u;    // rows past M read as zero in hardware
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
+        stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    // row sr + RP j: RP is a multiple of 8, so (row & 7) = sr & 7 for every piece
+    const int st_off = sr * 128 + ((((sc >> 1) ^ (sr & 7))) << 4) + (sc & 1) * 8;
+    auto stage_store = [&](int buf, int j) {
+        unsigned char *ph = smem + buf * 2 * PLANE + st_off + RP * j * 128;
+        const float v[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
+        bf16x4 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __bf16 h = (__bf16)v[i];
+            vh[i] = h;
+            vl[i] = (__bf16)(v[i] - (float)h);
+        }
+        *reinterpret_cast<bf16x4 *>(ph) = vh;
+        *reinterpret_cast<bf16x4 *>(ph + PLANE) = vl;
+    };
+    int ld_tm = tm, ld_c = 0;
+    auto advance = [&]() {
+        if (++ld_c == nchunks) { ld_c = 0; ld_tm = ld_tm + tm_step < a.tiles_m ? ld_tm + tm_step : a.tiles_m; }
+    };
+#pragma unroll
+    for (int j = 0; j < NP; ++j) stage_load(ld_tm, ld_c, j);
+    advance();
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        stage_store(0, j);
+        stage_load(ld_tm, ld_c, j);
+    }
+    advance();
+    float *bias_s = reinterpret_cast<float *>(smem + 4 * PLANE);
+    if (tid < TN) bias_s[tid] = (a.l.bias && tn * TN + tid < N) ? a.l.bias[tn * TN + tid] : 0.f;
+    __syncthreads();
+
+    // token fragments of unit u (32-k step u >> 1, token blocks 4 (u & 1) .. + 3): lane = (token l16 of the block, k-group g)
+    const int fa0 = l16 * 128 + ((g ^ (lane & 7)) << 4);      // 32-k step 0 of the chunk; step 1 = the unit index ^ 4, i.e. offset ^ 64
+    auto load_a = [&](int buf, int u, bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
+        const unsigned char *p = smem + buf * 2 * PLANE + ((u & 2) ? (fa0 ^ 64) : fa0) + (u & 1) * (4 * 2048);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ah[t] = *reinterpret_cast<const bf16x8 *>(p + t * 2048);
+            al[t] = *reinterpret_cast<const bf16x8 *>(p + PLANE + t * 2048);
+        }
+    };
+    bf16x8 ahA[4], alA[4], ahB[4], alB[4];
+    int buf = 0;
+    load_a(0, 0, ahA, alA);
+
+    for (; tm < a.tiles_m; tm += tm_step) {
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int c = 0; c < nchunks; ++c) {
+            auto unit = [&](auto U) {
+                constexpr int u = decltype(U)::value, ks = u >> 1, h = u & 1;
+                if (h == 0) {                               // all four weight loads of the NEXT 32-k step, behind this step's first MFMAs
+                    int kn = c * 2 + ks + 1;
+                    kn = kn >= nks ? kn - nks : kn;          // wraps: the next tile uses the same weights
+                    load_b(ks ^ 1, __builtin_amdgcn_readfirstlane(kn));
+                }
+                constexpr int P0 = (NP * 3 + 7) / 8, P1 = (NP * 6 + 7) / 8;
+                constexpr int pbeg = u == 0 ? 0 : u == 1 ? P0 : u == 2 ? P1 : NP, pend = u == 0 ? P0 : u == 1 ? P1 : NP;
+#pragma unroll
+                for (int j = pbeg; j < pend; ++j) {
+                    stage_store(buf ^ 1, j);
+                    stage_load(ld_tm, ld_c, j);
+                }
+                if (u == 2) advance();
+                if (u == 3) __syncthreads();                // other buffer complete and visible; every read of this buffer has returned
+                if (u & 1) load_a(u == 3 ? buf ^ 1 : buf, (u + 1) & 3, ahA, alA);
+                else load_a(buf, u + 1, ahB, alB);
+                bf16x8 wh[2], wl[2];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    wh[nb] = __builtin_bit_cast(bf16x8, bq[ks][nb * 2]);
+                    wl[nb] = __builtin_bit_cast(bf16x8, bq[ks][nb * 2 + 1]);
+                }
+                // product-major: consecutive MFMAs go to different accumulators; each accumulator still sums hi*lo, lo*hi, hi*hi in order
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[nb][4 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nb], (u & 1) ? alB[t] : alA[t], acc[nb][4 * h + t], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[nb][4 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nb], (u & 1) ? ahB[t] : ahA[t], acc[nb][4 * h + t], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[nb][4 * h + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nb], (u & 1) ? ahB[t] : ahA[t], acc[nb][4 * h + t], 0, 0, 0);
+                {
+                    // one fragment read per third MFMA, the weight loads right behind the first MFMAs (k_encoder_b16's placement), the
+                    // split arithmetic spread over the gaps (an MFMA of this shape leaves 8 of its 16 cycles to other vector issue)
+                    constexpr int NMF = 24, NPC = pend - pbeg, VPER = NPC ? (14 * NPC + NMF - 1) / NMF : 0;
+#pragma unroll
+                    for (int i = 0; i < NMF; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
+                        if (h == 0 && i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // weight ring (L2 latency)
+                        if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 DS read (next unit's fragment)
+                        if (VPER) __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);             // split arithmetic
+                        if (i >= NMF - NPC) {
+                            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                      // a finished piece: 2 DS writes
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      //   + its re-issued load
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            unit(std::integral_constant<int, 0>{});
+            unit(std::integral_constant<int, 1>{});
+            unit(std::integral_constant<int, 2>{});
+            unit(std::integral_constant<int, 3>{});
+            buf ^= 1;
+        }
+
+        // ---- epilogue: acc[nb][t][i] = token row t*16 + l16, output column ncol0 + nb*16 + 4g + i
+        if (nw_ok) {
+            const int row0 = tm * TM, ncol = ncol0 + 4 * g;
+            const float *bias_w = bias_s + wave * 32 + 4 * g;
+            const float4 b0 = *reinterpret_cast<const float4 *>(bias_w), b1 = *reinterpret_cast<const float4 *>(bias_w + 16);
+            const bool any_ex = a.c.res || a.c.padd;
+            float4 ex[2][2];
+            auto fetch_extra = [&](int t, float4 (&e)[2]) {
+                const int row = row0 + t * 16 + l16;
+                e[0] = e[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row >= M) return;
+                if (a.c.padd) {                              // a tile lies inside one group (launcher: rows_per_group % 128 == 0)
+                    const int grp = row0 / a.c.rows_per_group;
+                    const int xx = row - grp * a.c.rows_per_group;
+                    int ph = xx - (int)((float)xx * (1.0f / (float)a.c.period)) * a.c.period;
+                    ph = ph < 0 ? ph + a.c.period : (ph >= a.c.period ? ph - a.c.period : ph);
+                    const float *pp = a.c.padd + ((size_t)grp * a.c.period + ph) * N + ncol;
+                    e[0] = *reinterpret_cast<const float4 *>(pp);
+                    e[1] = *reinterpret_cast<const float4 *>(pp + 16);
+                } else {
+                    const float *rp = a.c.res + (long long)row * a.c.ldr + ncol;
+                    e[0] = *reinterpret_cast<const float4 *>(rp);
+                    e[1] = *reinterpret_cast<const float4 *>(rp + 16);
+                }
+            };
+            auto finish = [&](float (&v)[4]) {
+                if (a.c.act == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+                } else if (a.c.act == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                }
+            };
+            if (any_ex) fetch_extra(0, ex[0]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                // loads of block t+1 before the stores of block t: vmcnt retires stores in order with loads
+                if (any_ex && t + 1 < 8) fetch_extra(t + 1, ex[(t + 1) & 1]);
+                const int row = row0 + t * 16 + l16;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const float4 bb = nb ? b1 : b0;
+                    float v[4] = {acc[nb][t][0] + bb.x, acc[nb][t][1] + bb.y, acc[nb][t][2] + bb.z, acc[nb][t][3] + bb.w};
+                    if (any_ex) {
+                        const float4 eq = ex[t & 1][nb];
+                        if (a.c.padd) { v[0] += eq.x; v[1] += eq.y; v[2] += eq.z; v[3] += eq.w; }
+                        finish(v);
+                        if (!a.c.padd) { v[0] = eq.x + v[0]; v[1] = eq.y + v[1]; v[2] = eq.z + v[2]; v[3] = eq.w + v[3]; }
+                    } else {
+                        finish(v);
+                    }
+                    if (row < M) *reinterpret_cast<float4 *>(a.c.y + (long long)row * a.c.ldy + ncol + 16 * nb) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int NW>
+static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
+    constexpr int lds = 4 * 128 * 128 + 1024;
+    once_per_device((const void *)k_linear_b16<NW>, [&] {
+        (void)hipFuncSetAttribute((const void *)k_linear_b16<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    const int nwg_max = (NW == 8 ? 1 : 2) * a.num_cu;        // 8 waves per CU either way
+    const long long tiles = (long long)a.tiles_m * a.tiles_n;
+    long long nwg = tiles < nwg_max ? tiles : nwg_max;
+    nwg -= nwg % a.tiles_n;                                  // every workgroup keeps one column tile
+    if (nwg < a.tiles_n) nwg = a.tiles_n;
+    LinearArgs b = a;
+    static int swz_env = -1;
+    if (swz_env < 0) { const char *s = getenv("SMK_LINEAR_SWZ"); swz_env = s ? atoi(s) : 1; }
+    b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
+    hipLaunchKernelGGL((k_linear_b16<NW>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t st) {
     const int num_cu = device_num_cu();
     LinearArgs a;
@@ -572,6 +829,12 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     a.stamps = stamp_buf;
 #endif
     hipError_t e;
+    // full 128-row tiles of fp32 activations: the 16x16x32-shape kernel (SMK_LINEAR_SHAPE=32 keeps the 32x32x16 one for A/B runs)
+    static int shape_env = -1;
+    if (shape_env < 0) { const char *s = getenv("SMK_LINEAR_SHAPE"); shape_env = s ? atoi(s) : 16; }
+    if (shape_env != 32 && mb == 4 && !c.x_split && !c.y_split && c.nseg == 1 && !a.stamps && !dbg && (!c.padd || c.rows_per_group % 128 == 0)) {
+        return nw == 8 ? launch_b16<8>(a, st) : launch_b16<4>(a, st);
+    }
     if (c.x_split) {
         if (nw == 8) e = launch_mb<4, 8, true>(a, st);
         else if (mb == 4) e = launch_mb<4, 4, true>(a, st);

@@ -109,7 +109,7 @@ def test_one_rank_rccl_ddp_step_equals_the_unwrapped_step_bit_for_bit():
 
 def test_bench_train_step_leg_runs_on_rccl_at_n1():
     """`python bench.py --gpus 1` (what the driver runs): the train-step leg is the DDP step on a one-rank RCCL group, and says so."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-config1", "--no-alt", "--no-dataset",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-config1", "--no-alt", "--no-dataset", "--no-config4",
            "--no-inference", "--cpu-frames", "0"]
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
