@@ -577,10 +577,16 @@ int smk_sim3d_step(smk_sim3d *sim, int32_t n_steps, float *frames, int64_t fsb, 
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(sim->device);
     if (guard.rc) return guard.rc;
+    static const bool staged = getenv("SMK_ADVECT3_STAGED") != nullptr;      // diagnostic: the four advections as four launches
     for (int t = 0; t < n_steps; ++t) {
         float *ft = frames ? frames + (size_t)t * fst : nullptr;
-        for (int stage = SMK_STAGE3D_BUOY_DIFFUSE; stage <= SMK_STAGE3D_ADVECT_D; ++stage) {
+        const int last = staged ? SMK_STAGE3D_ADVECT_D : SMK_STAGE3D_PROJECT;
+        for (int stage = SMK_STAGE3D_BUOY_DIFFUSE; stage <= last; ++stage) {
             const int rc = run_stage3d(sim, stage, stage == SMK_STAGE3D_ADVECT_D ? ft : nullptr, fsb, st);
+            if (rc) return rc;
+        }
+        if (!staged) {
+            const int rc = check_launch(launch3_advect_fused(sim->g, sim->t, sim->s, ft, fsb, st), "advect_fused3d");
             if (rc) return rc;
         }
     }

@@ -28,4 +28,7 @@ hipError_t launch3_grad_subtract(const Geom3 &g, State3 s, const float *p, hipSt
 hipError_t launch3_advect(const Geom3 &g, int which, const float *field, float *out, const float *u, const float *v, const float *w,
                           float *frames, int64_t frame_stride_b, hipStream_t st);
 
+// the four advections of one step as one launch: in = (u2, v2, w2, -, d2), out = (u, v, w, -, density); bit-identical to the four launches
+hipError_t launch3_advect_fused(const Geom3 &g, State3 in, State3 out, float *frames, int64_t frame_stride_b, hipStream_t st);
+
 }  // namespace smk

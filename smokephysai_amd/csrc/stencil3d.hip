@@ -202,11 +202,117 @@ __global__ void k3_jacobi4(Geom3 g, const float *__restrict__ p, float *__restri
     *reinterpret_cast<float4 *>(pn + o) = r;
 }
 
+// T sweeps per launch (temporal blocking, 2.5-D): a workgroup owns a (y, x) tile of the grid plus a T-cell halo on each side, CY columns
+// per thread, and marches along z.  Level l (0 = the input p, l = the result of sweep l) is kept per column as the values at three
+// consecutive planes in registers; in iteration z sweep s = 1 .. T forms plane z - s + 1 from level s-1 (planes z-s and z-s+2 of its own
+// column from registers -- the latter is what sweep s-1 produced a moment ago, or the prefetched input plane -- and the four lateral
+// neighbours of plane z-s+1 from LDS, where every thread put its value at the top of the iteration).  Only sweep T's result goes to
+// HBM.  The LDS planes are double-buffered: one workgroup barrier per plane.  Per output cell and per T sweeps the launch moves
+// (2 reads x tile / inner + 1 write) floats instead of 3 T; every cell's value is k3_jacobi's expression applied T times --
+// bit-identical.  Halo threads compute values nobody uses (their lateral reads are clamped into the block); cells on the grid's shell
+// are 0 after every sweep, cells outside the grid are never stored.
+template <int T, int TXB, int TYB, int CY>
+__global__ __launch_bounds__(TXB * TYB) void k3_jacobi_xt(Geom3 g, const float *__restrict__ p, float *__restrict__ pn, const float *__restrict__ div) {
+    constexpr int ROWS = TYB * CY;
+    __shared__ float L[T][2][ROWS][TXB];
+    const int tx = threadIdx.x, b = blockIdx.z;
+    const int x = blockIdx.x * (TXB - 2 * T) - T + tx;
+    const bool x_in = x >= 0 && x < g.W;
+    const int txl = tx > 0 ? tx - 1 : 0, txr = tx < TXB - 1 ? tx + 1 : TXB - 1;
+    const size_t ps = (size_t)g.H * g.pc;
+    int ty[CY], tyu[CY], tyd[CY];
+    bool inside[CY], lshell[CY], outc[CY];
+    size_t o[CY];
+    float lm[T][CY], lc[T][CY];       // level l at planes z-l-1 and z-l
+    float dv[T][CY];                  // div at planes z .. z-T+1
+    float a_p[CY];                    // input at plane z+1
+#pragma unroll
+    for (int c = 0; c < CY; ++c) {
+        ty[c] = threadIdx.y + c * TYB;
+        tyu[c] = ty[c] > 0 ? ty[c] - 1 : 0;
+        tyd[c] = ty[c] < ROWS - 1 ? ty[c] + 1 : ROWS - 1;
+        const int y = blockIdx.y * (ROWS - 2 * T) - T + ty[c];
+        inside[c] = x_in && y >= 0 && y < g.H;
+        lshell[c] = x <= 0 || x >= g.W - 1 || y <= 0 || y >= g.H - 1;      // (also true outside the grid)
+        outc[c] = inside[c] && tx >= T && tx < TXB - T && ty[c] >= T && ty[c] < ROWS - T;
+        o[c] = b * g.sc + (size_t)(inside[c] ? y : 0) * g.pc + (inside[c] ? x : 0);
+#pragma unroll
+        for (int l = 0; l < T; ++l) { lm[l][c] = 0.f; lc[l][c] = 0.f; dv[l][c] = 0.f; }
+        lc[0][c] = inside[c] ? p[o[c]] : 0.f;
+        a_p[c] = inside[c] && g.D > 1 ? p[o[c] + ps] : 0.f;
+        dv[0][c] = inside[c] ? div[o[c]] : 0.f;
+    }
+    for (int z = 0; z < g.D + T - 1; ++z) {
+        float a_next[CY], d_next[CY];
+#pragma unroll
+        for (int c = 0; c < CY; ++c) {      // prefetch plane z+2 of the input and z+1 of div while this plane is worked on
+            a_next[c] = (inside[c] && z + 2 < g.D) ? p[o[c] + (size_t)(z + 2) * ps] : 0.f;
+            d_next[c] = (inside[c] && z + 1 < g.D) ? div[o[c] + (size_t)(z + 1) * ps] : 0.f;
+#pragma unroll
+            for (int l = 0; l < T; ++l) L[l][z & 1][ty[c]][tx] = lc[l][c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CY; ++c) {
+            float up = a_p[c];                                // level s-1 at plane z-s+2, starting with the input at z+1
+#pragma unroll
+            for (int s = 1; s <= T; ++s) {
+                const int zp = z - s + 1;                     // the plane sweep s forms now
+                float r = 0.f;
+                if (zp >= 1 && zp < g.D - 1 && !lshell[c]) {
+                    const float (*Lp)[TXB] = L[s - 1][z & 1];
+                    float sm = Lp[tyu[c]][tx] + Lp[tyd[c]][tx];
+                    sm = sm + Lp[ty[c]][txl];
+                    sm = sm + Lp[ty[c]][txr];
+                    sm = sm + lm[s - 1][c];
+                    sm = sm + up;
+                    sm = sm - dv[s - 1][c];
+                    r = g.sixth * sm;
+                }
+                // level s-1 moves one plane on; `up` for the next sweep is this sweep's fresh value (level s at plane z-s+1)
+                lm[s - 1][c] = lc[s - 1][c];
+                lc[s - 1][c] = up;
+                up = r;
+            }
+            if (z >= T - 1 && outc[c]) pn[o[c] + (size_t)(z - T + 1) * ps] = up;
+#pragma unroll
+            for (int l = T - 1; l > 0; --l) dv[l][c] = dv[l - 1][c];
+            dv[0][c] = d_next[c];
+            a_p[c] = a_next[c];
+        }
+    }
+}
+
+template <int T, int TXB, int TYB, int CY>
+static void launch3_jacobi_xt(const Geom3 &g, const float *cur, float *nxt, const float *div, hipStream_t st) {
+    dim3 block(TXB, TYB), grid(cdiv(g.W, TXB - 2 * T), cdiv(g.H, TYB * CY - 2 * T), g.B);
+    hipLaunchKernelGGL((k3_jacobi_xt<T, TXB, TYB, CY>), grid, block, 0, st, g, cur, nxt, div);
+}
+
 hipError_t launch3_jacobi(const Geom3 &g, float *p, float *p2, const float *div, int iters, hipStream_t st) {
     float *cur = p, *nxt = p2;
     const bool vec = g.W % 4 == 0 && g.pc % 4 == 0 && getenv("SMK_JACOBI3_SCALAR") == nullptr;
     dim3 block(TX3, TY3), grid(cdiv(vec ? g.W / 4 : g.W, TX3), cdiv(g.H, TY3), g.B * g.D);
-    for (int it = 0; it < iters; ++it) {
+    int it = 0;
+    // temporally blocked launches first (SMK_JACOBI3_T = 1, 2, 4 caps the sweeps per launch; default 4), single sweeps for the rest
+    static const int tmax = [] { const char *e = getenv("SMK_JACOBI3_T"); return e ? atoi(e) : 4; }();
+    if (g.B <= 65535) {
+        if (tmax >= 4) {
+            // an even number of launches ends in p without a copy: with iters % 4 == 0 and an odd count, trade one 4-sweep launch for two 2-sweep ones
+            int n4 = iters / 4;
+            if (iters % 4 == 0 && (n4 & 1) && n4 >= 1) --n4;
+            for (int k = 0; k < n4; ++k, it += 4) {
+                launch3_jacobi_xt<4, 64, 16, 2>(g, cur, nxt, div, st);
+                float *t = cur; cur = nxt; nxt = t;
+            }
+        }
+        if (tmax >= 2)
+            for (; it + 2 <= iters; it += 2) {
+                launch3_jacobi_xt<2, 64, 16, 1>(g, cur, nxt, div, st);
+                float *t = cur; cur = nxt; nxt = t;
+            }
+    }
+    for (; it < iters; ++it) {
         if (vec) hipLaunchKernelGGL(k3_jacobi4, grid, block, 0, st, g, cur, nxt, div);
         else hipLaunchKernelGGL(k3_jacobi, grid, block, 0, st, g, cur, nxt, div);
         float *t = cur; cur = nxt; nxt = t;
@@ -323,6 +429,107 @@ hipError_t launch3_advect(const Geom3 &g, int which, const float *field, float *
         case 3: hipLaunchKernelGGL(k3_advect<3>, grid, block, 0, st, g, field, out, u, v, w, frames, fsb); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- the four advections of a step as ONE launch
+// u <- adv(u2; u2, v2, w2), v <- adv(v2; u, v2, w2), w <- adv(w2; u, v, w2), density <- adv(d2; u, v, w) * 0.995 depend on each other only
+// through the velocity SAMPLING, which happens at integer cell indices where it collapses to 0.5 c[lo] + 0.5 c[hi] (vel3_at).  A
+// workgroup owns a TZ x TY x TX tile of cells; it forms the advected u, v, w on the tile + 1 in z / y / x (what the later fields' samples
+// reach: about 30 % redundant points at 8 x 8 x 32) into LDS, with a workgroup barrier between the fields, then the density and the frame.
+// The displacement-dependent eight-tap gathers read u2, v2, w2, d2 -- inputs of the launch -- straight from global memory (L1 / L2: the
+// taps of neighbouring cells coincide).  HBM traffic: four fields in (tile + halo), four fields + the frame out, instead of seventeen
+// field passes; bit-identical to the four-launch form (same expressions per cell).  The extra row of u (y = H), column of v (x = W) and
+// plane of w (z = D) belong to the last tile along that axis.
+template <int TZ, int TY, int TX>
+__global__ __launch_bounds__(512) void k3_advect_fused(Geom3 g, State3 in, State3 out, float *__restrict__ frames, int64_t fsb) {
+    constexpr int EZ = TZ + 1, EY = TY + 1, EX = TX + 1, NE = EZ * EY * EX;
+    __shared__ float Us[NE], Vs[NE], Ws[NE];
+    const int D = g.D, H = g.H, W = g.W;
+    const int ntx = (W + TX - 1) / TX, nty = (H + TY - 1) / TY, ntz = (D + TZ - 1) / TZ;
+    int bid = blockIdx.x;
+    const int tix = bid % ntx; bid /= ntx;
+    const int tiy = bid % nty; bid /= nty;
+    const int tiz = bid % ntz;
+    const int b = bid / ntz;
+    const int x0 = tix * TX, y0 = tiy * TY, z0 = tiz * TZ;
+    const bool lastx = tix == ntx - 1, lasty = tiy == nty - 1, lastz = tiz == ntz - 1;
+    const float *u2 = in.u + b * g.su, *v2 = in.v + b * g.sv, *w2 = in.w + b * g.sw, *d2 = in.d + b * g.sc;
+    // velocity sample from an LDS tile holding the ADVECTED component: the rule of vel3_at in global indices, the values from the tile
+    auto lds_vel = [&](const float *tile, int Dc, int Hc, int Wc, int step, int z, int y, int x) -> float {
+        if (z > Dc - 2 || y > Hc - 2 || x > Wc - 2) return 0.f;
+        const int o = ((z - z0) * EY + (y - y0)) * EX + (x - x0);
+        return 0.5f * tile[o] + 0.5f * tile[o + step];
+    };
+    // one advected value: field f (extents Df, Hf, Wf, pitch) at (z, y, x) with the three velocity samples given
+    auto advect_at = [&](const float *f, int Df, int Hf, int Wf, int pitch, int z, int y, int x, float ui, float vi, float wi) -> float {
+        const float tx = g.dt * ui, ty = g.dt * vi, tz = g.dt * wi;
+        const float px = clampf3((float)x - tx, 0.f, (float)(Wf - 1));
+        const float py = clampf3((float)y - ty, 0.f, (float)(Hf - 1));
+        const float pz = clampf3((float)z - tz, 0.f, (float)(Df - 1));
+        return interp3(f, Df, Hf, Wf, pitch, pz, py, px);
+    };
+    // ---- u on the tile + 1 (extents D, H+1, W)
+    for (int e = threadIdx.x; e < NE; e += 512) {
+        const int ex = e % EX, ey = (e / EX) % EY, ez = e / (EX * EY);
+        const int x = x0 + ex, y = y0 + ey, z = z0 + ez;
+        float r = 0.f;
+        if (z < D && y <= H && x < W) {
+            const float ui = vel3_at<2>(u2, D, H + 1, W, g.pc, z, y, x), vi = vel3_at<1>(v2, D, H, W + 1, g.pv, z, y, x);
+            const float wi = vel3_at<0>(w2, D + 1, H, W, g.pc, z, y, x);
+            r = advect_at(u2, D, H + 1, W, g.pc, z, y, x, ui, vi, wi);
+            if (ez < TZ && ex < TX && (ey < TY || lasty)) out.u[b * g.su + ((size_t)z * (H + 1) + y) * g.pc + x] = r;
+        }
+        Us[e] = r;
+    }
+    __syncthreads();
+    // ---- v on the tile + 1 in z, y (and the extra column x = W in the last x tile): extents D, H, W+1
+    for (int e = threadIdx.x; e < NE; e += 512) {
+        const int ex = e % EX, ey = (e / EX) % EY, ez = e / (EX * EY);
+        const int x = x0 + ex, y = y0 + ey, z = z0 + ez;
+        float r = 0.f;
+        if (z < D && y < H && x <= W && (ex < TX || lastx)) {
+            const float ui = lds_vel(Us, D, H + 1, W, 1, z, y, x), vi = vel3_at<1>(v2, D, H, W + 1, g.pv, z, y, x);
+            const float wi = vel3_at<0>(w2, D + 1, H, W, g.pc, z, y, x);
+            r = advect_at(v2, D, H, W + 1, g.pv, z, y, x, ui, vi, wi);
+            if (ez < TZ && ey < TY) out.v[b * g.sv + ((size_t)z * H + y) * g.pv + x] = r;
+        }
+        Vs[e] = r;
+    }
+    __syncthreads();
+    // ---- w on the tile + 1 in z (the extra plane z = D in the last z tile): extents D+1, H, W
+    for (int e = threadIdx.x; e < NE; e += 512) {
+        const int ex = e % EX, ey = (e / EX) % EY, ez = e / (EX * EY);
+        const int x = x0 + ex, y = y0 + ey, z = z0 + ez;
+        float r = 0.f;
+        if (ex < TX && ey < TY && z <= D && y < H && x < W) {
+            const float ui = lds_vel(Us, D, H + 1, W, 1, z, y, x), vi = lds_vel(Vs, D, H, W + 1, EX, z, y, x);
+            const float wi = vel3_at<0>(w2, D + 1, H, W, g.pc, z, y, x);
+            r = advect_at(w2, D + 1, H, W, g.pc, z, y, x, ui, vi, wi);
+            if (ez < TZ || lastz) out.w[b * g.sw + ((size_t)z * H + y) * g.pc + x] = r;
+        }
+        Ws[e] = r;
+    }
+    __syncthreads();
+    // ---- density on the tile (+ 0.995 decay, frame)
+    for (int e = threadIdx.x; e < TZ * TY * TX; e += 512) {
+        const int ex = e % TX, ey = (e / TX) % TY, ez = e / (TX * TY);
+        const int x = x0 + ex, y = y0 + ey, z = z0 + ez;
+        if (z >= D || y >= H || x >= W) continue;
+        const float ui = lds_vel(Us, D, H + 1, W, 1, z, y, x), vi = lds_vel(Vs, D, H, W + 1, EX, z, y, x);
+        const float wi = lds_vel(Ws, D + 1, H, W, EX * EY, z, y, x);
+        float r = advect_at(d2, D, H, W, g.pc, z, y, x, ui, vi, wi);
+        r = r * 0.995f;                                       // navier_stokes.py:171
+        if (frames) frames[(size_t)b * fsb + ((size_t)z * H + y) * W + x] = r;
+        out.d[b * g.sc + ((size_t)z * H + y) * g.pc + x] = r;
+    }
+}
+
+hipError_t launch3_advect_fused(const Geom3 &g, State3 in, State3 out, float *frames, int64_t fsb, hipStream_t st) {
+    constexpr int TZ = 8, TY = 8, TX = 32;
+    const long long nb = (long long)cdiv(g.W, TX) * cdiv(g.H, TY) * cdiv(g.D, TZ) * g.B;
+    if (nb > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k3_advect_fused<TZ, TY, TX>), dim3((unsigned)nb), dim3(512), 0, st, g, in, out, frames, fsb);
     return hipGetLastError();
 }
 
