@@ -445,6 +445,7 @@ int smk_sim3d_create(const smk_sim3d_desc *d, smk_sim3d **out) {
     SMK_REQUIRE(d->pitch_c >= d->width && d->pitch_v >= d->width + 1, "pitch_c >= W and pitch_v >= W+1");
     SMK_REQUIRE(d->jacobi_iters >= 0, "jacobi_iters >= 0");
     SMK_REQUIRE((int64_t)d->batch * (d->depth + 1) <= 65535, "batch * (depth + 1) <= 65535 (one grid z-slice per plane)");
+    SMK_REQUIRE((int64_t)(d->depth + 1) * (d->height + 1) * d->pitch_v < (1LL << 31), "one grid's field must stay below 2^31 elements (32-bit in-grid offsets)");
     SMK_REQUIRE(d->u && d->v && d->w && d->p && d->density, "null state pointer");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {

@@ -99,32 +99,114 @@ __global__ void k3_buoy_diffuse(Geom3 g, State3 in, State3 out) {
     const int D = g.D, H = g.H, W = g.W;
     const float *u = in.u + b * g.su, *v = in.v + b * g.sv, *w = in.w + b * g.sw, *d = in.d + b * g.sc;
     if (z < D && y <= H && x < W) {
-        auto val = [&](int k, int i, int j) { return u[((size_t)k * (H + 1) + i) * g.pc + j]; };
-        out.u[b * g.su + ((size_t)z * (H + 1) + y) * g.pc + x] = diffuse3_at(val, D, H + 1, W, z, y, x, g.coef_uv);
+        auto val = [&](int k, int i, int j) { return u[(k * (H + 1) + i) * g.pc + j]; };
+        out.u[b * g.su + (z * (H + 1) + y) * g.pc + x] = diffuse3_at(val, D, H + 1, W, z, y, x, g.coef_uv);
     }
     if (z < D && y < H && x <= W) {
         // the buoyancy-updated v that diffusion_step(v) sees: v[:, :, :-1] += dt * (density * 0.1)
         auto val = [&](int k, int i, int j) {
-            float t = v[((size_t)k * H + i) * g.pv + j];
+            float t = v[(k * H + i) * g.pv + j];
             if (j < W) {
-                const float bb = d[((size_t)k * H + i) * g.pc + j] * 0.1f;
+                const float bb = d[(k * H + i) * g.pc + j] * 0.1f;
                 t = t + g.dt * bb;
             }
             return t;
         };
-        out.v[b * g.sv + ((size_t)z * H + y) * g.pv + x] = diffuse3_at(val, D, H, W + 1, z, y, x, g.coef_uv);
+        out.v[b * g.sv + (z * H + y) * g.pv + x] = diffuse3_at(val, D, H, W + 1, z, y, x, g.coef_uv);
     }
     if (y < H && x < W) {
-        auto val = [&](int k, int i, int j) { return w[((size_t)k * H + i) * g.pc + j]; };
-        out.w[b * g.sw + ((size_t)z * H + y) * g.pc + x] = diffuse3_at(val, D + 1, H, W, z, y, x, g.coef_uv);
+        auto val = [&](int k, int i, int j) { return w[(k * H + i) * g.pc + j]; };
+        out.w[b * g.sw + (z * H + y) * g.pc + x] = diffuse3_at(val, D + 1, H, W, z, y, x, g.coef_uv);
     }
     if (z < D && y < H && x < W) {
-        auto val = [&](int k, int i, int j) { return d[((size_t)k * H + i) * g.pc + j]; };
-        out.d[b * g.sc + ((size_t)z * H + y) * g.pc + x] = diffuse3_at(val, D, H, W, z, y, x, g.coef_d);
+        auto val = [&](int k, int i, int j) { return d[(k * H + i) * g.pc + j]; };
+        out.d[b * g.sc + (z * H + y) * g.pc + x] = diffuse3_at(val, D, H, W, z, y, x, g.coef_d);
+    }
+}
+
+// The same stage marching along z: a thread owns the column (y, x) of all four fields and keeps each field's values at planes z-1, z,
+// z+1 in registers, so the front / back neighbours and the centre cost one new load per field and plane; the four lateral neighbours are
+// same-plane loads that the neighbouring threads' own centre loads bring into the L1 (the one-cell-per-thread form above fetches every
+// z-neighbour through the L2: ~5 x the compulsory bytes).  v's extra column x = W rides on the thread of x = W-1; u's extra row y = H and
+// w's extra plane z = D are ordinary iterations.  Per cell the expression trees of diffuse3_at -- bit-identical.
+template <int TXB, int TYB>
+__global__ __launch_bounds__(TXB * TYB) void k3_buoy_diffuse_march(Geom3 g, State3 in, State3 out) {
+    const int b = blockIdx.z, D = g.D, H = g.H, W = g.W;
+    const int x = blockIdx.x * TXB + threadIdx.x, y = blockIdx.y * TYB + threadIdx.y;
+    if (x >= W || y > H) return;
+    const float *u = in.u + b * g.su, *v = in.v + b * g.sv, *w = in.w + b * g.sw, *d = in.d + b * g.sc;
+    float *uo = out.u + b * g.su, *vo = out.v + b * g.sv, *wo = out.w + b * g.sw, *dd = out.d + b * g.sc;
+    const bool row = y < H;                                   // v, w, density exist on rows 0 .. H-1; u also on row H
+    const bool extra = row && x == W - 1;                     // this thread also forms v(:, y, W)
+    const int pu = (H + 1) * g.pc, pvs = H * g.pv, pw = H * g.pc;      // plane strides
+    // lateral index sets (replicate padding)
+    const int yu_u = y > 0 ? y - 1 : 0, yd_u = y < H ? y + 1 : H;                       // u: rows 0 .. H
+    const int yu = y > 0 ? y - 1 : 0, yd = y < H - 1 ? y + 1 : H - 1;                   // v, w, d: rows 0 .. H-1
+    const int xl = x > 0 ? x - 1 : 0, xr = x < W - 1 ? x + 1 : W - 1;                   // u, w, d: columns 0 .. W-1
+    const int xr_v = x + 1;                                                             // v: columns 0 .. W (x <= W-1 here)
+    auto vb = [&](int k, int i, int j) {                      // the buoyancy-updated v that diffusion_step(v) sees
+        float t = v[k * pvs + i * g.pv + j];
+        if (j < W) {
+            const float bb = d[k * pw + i * g.pc + j] * 0.1f;
+            t = t + g.dt * bb;
+        }
+        return t;
+    };
+    auto finish = [](float c, float up, float dn, float lf, float rt, float fr, float bk, float coef) {
+        float lap = up + dn;
+        lap = lap + lf;
+        lap = lap + rt;
+        lap = lap + fr;
+        lap = lap + bk;
+        lap = lap - 6.0f * c;
+        return c + coef * lap;
+    };
+    // planes z-1 (replicated at z = 0), z, z+1
+    float u_c = u[y * g.pc + x], u_m = u_c, u_p;
+    float v_c = row ? vb(0, y, x) : 0.f, v_m = v_c, v_p;
+    float e_c = extra ? v[y * g.pv + W] : 0.f, e_m = e_c, e_p;               // v at column W: no buoyancy there
+    float w_c = row ? w[y * g.pc + x] : 0.f, w_m = w_c, w_p;
+    float d_c = row ? d[y * g.pc + x] : 0.f, d_m = d_c, d_p;
+    for (int z = 0; z <= D; ++z) {
+        const int zu = z + 1 < D ? z + 1 : D - 1;             // next plane of the D-plane fields (replicated at the end)
+        if (z < D) {
+            u_p = u[zu * pu + y * g.pc + x];
+            if (row) {
+                v_p = vb(zu, y, x);
+                d_p = d[zu * pw + y * g.pc + x];
+                if (extra) e_p = v[zu * pvs + y * g.pv + W];
+            }
+        }
+        if (row) w_p = w[(z + 1 <= D ? z + 1 : D) * pw + y * g.pc + x];
+        if (z < D) {
+            const float *uz = u + z * pu;
+            uo[z * pu + y * g.pc + x] = finish(u_c, uz[yu_u * g.pc + x], uz[yd_u * g.pc + x], uz[y * g.pc + xl], uz[y * g.pc + xr], u_m, u_p, g.coef_uv);
+            if (row) {
+                vo[z * pvs + y * g.pv + x] = finish(v_c, vb(z, yu, x), vb(z, yd, x), vb(z, y, xl), vb(z, y, xr_v), v_m, v_p, g.coef_uv);
+                if (extra)          // column W: right neighbour = itself (replicate), left neighbour = this thread's own v_c
+                    vo[z * pvs + y * g.pv + W] = finish(e_c, v[z * pvs + yu * g.pv + W], v[z * pvs + yd * g.pv + W], v_c, e_c, e_m, e_p, g.coef_uv);
+                const float *dz = d + z * pw;
+                dd[z * pw + y * g.pc + x] = finish(d_c, dz[yu * g.pc + x], dz[yd * g.pc + x], dz[y * g.pc + xl], dz[y * g.pc + xr], d_m, d_p, g.coef_d);
+            }
+        }
+        if (row) {
+            const float *wz = w + z * pw;
+            wo[z * pw + y * g.pc + x] = finish(w_c, wz[yu * g.pc + x], wz[yd * g.pc + x], wz[y * g.pc + xl], wz[y * g.pc + xr], w_m, w_p, g.coef_uv);
+        }
+        u_m = u_c; u_c = u_p;
+        v_m = v_c; v_c = v_p; e_m = e_c; e_c = e_p;
+        d_m = d_c; d_c = d_p;
+        w_m = w_c; w_c = w_p;
     }
 }
 
 hipError_t launch3_buoy_diffuse(const Geom3 &g, State3 in, State3 out, hipStream_t st) {
+    static const bool cellwise = getenv("SMK_DIFFUSE3_CELLWISE") != nullptr;      // diagnostic: the one-cell-per-thread form
+    if (!cellwise && g.B <= 65535) {
+        constexpr int TXB = 64, TYB = 4;
+        hipLaunchKernelGGL((k3_buoy_diffuse_march<TXB, TYB>), dim3(cdiv(g.W, TXB), cdiv(g.H + 1, TYB), g.B), dim3(TXB, TYB), 0, st, g, in, out);
+        return hipGetLastError();
+    }
     dim3 grid(cdiv(g.W + 1, TX3), cdiv(g.H + 1, TY3), g.B * (g.D + 1)), block(TX3, TY3);
     hipLaunchKernelGGL(k3_buoy_diffuse, grid, block, 0, st, g, in, out);
     return hipGetLastError();
@@ -364,8 +446,8 @@ hipError_t launch3_grad_subtract(const Geom3 &g, State3 s, const float *p, hipSt
 template <int ACT>
 __device__ __forceinline__ float vel3_at(const float *c, int Dc, int Hc, int Wc, int pitch, int z, int y, int x) {
     if (z > Dc - 2 || y > Hc - 2 || x > Wc - 2) return 0.f;
-    const size_t o = ((size_t)z * Hc + y) * pitch + x;
-    const size_t step = ACT == 2 ? (size_t)1 : (ACT == 1 ? (size_t)pitch : (size_t)Hc * pitch);
+    const int o = (z * Hc + y) * pitch + x;                  // in-grid offsets fit 32 bits (smk_sim3d_create checks the extents)
+    const int step = ACT == 2 ? 1 : (ACT == 1 ? pitch : Hc * pitch);
     return 0.5f * c[o] + 0.5f * c[o + step];
 }
 
@@ -380,8 +462,8 @@ __device__ __forceinline__ float interp3(const float *f, int Df, int Hf, int Wf,
     const float wx0 = (float)x1 - px, wx1 = px - (float)x0;
     const float wy0 = (float)y1 - py, wy1 = py - (float)y0;
     const float wz0 = (float)z1 - pz, wz1 = pz - (float)z0;
-    const size_t r00 = ((size_t)z0 * Hf + y0) * pitch, r01 = ((size_t)z0 * Hf + y1) * pitch;
-    const size_t r10 = ((size_t)z1 * Hf + y0) * pitch, r11 = ((size_t)z1 * Hf + y1) * pitch;
+    const int r00 = (z0 * Hf + y0) * pitch, r01 = (z0 * Hf + y1) * pitch;
+    const int r10 = (z1 * Hf + y0) * pitch, r11 = (z1 * Hf + y1) * pitch;
     float acc = ((wx0 * wy0) * wz0) * f[r00 + x0];
     acc = acc + ((wx1 * wy0) * wz0) * f[r00 + x1];
     acc = acc + ((wx0 * wy1) * wz0) * f[r01 + x0];
@@ -478,7 +560,7 @@ __global__ __launch_bounds__(512) void k3_advect_fused(Geom3 g, State3 in, State
             const float ui = vel3_at<2>(u2, D, H + 1, W, g.pc, z, y, x), vi = vel3_at<1>(v2, D, H, W + 1, g.pv, z, y, x);
             const float wi = vel3_at<0>(w2, D + 1, H, W, g.pc, z, y, x);
             r = advect_at(u2, D, H + 1, W, g.pc, z, y, x, ui, vi, wi);
-            if (ez < TZ && ex < TX && (ey < TY || lasty)) out.u[b * g.su + ((size_t)z * (H + 1) + y) * g.pc + x] = r;
+            if (ez < TZ && ex < TX && (ey < TY || lasty)) out.u[b * g.su + (z * (H + 1) + y) * g.pc + x] = r;
         }
         Us[e] = r;
     }
@@ -492,7 +574,7 @@ __global__ __launch_bounds__(512) void k3_advect_fused(Geom3 g, State3 in, State
             const float ui = lds_vel(Us, D, H + 1, W, 1, z, y, x), vi = vel3_at<1>(v2, D, H, W + 1, g.pv, z, y, x);
             const float wi = vel3_at<0>(w2, D + 1, H, W, g.pc, z, y, x);
             r = advect_at(v2, D, H, W + 1, g.pv, z, y, x, ui, vi, wi);
-            if (ez < TZ && ey < TY) out.v[b * g.sv + ((size_t)z * H + y) * g.pv + x] = r;
+            if (ez < TZ && ey < TY) out.v[b * g.sv + (z * H + y) * g.pv + x] = r;
         }
         Vs[e] = r;
     }
@@ -506,7 +588,7 @@ __global__ __launch_bounds__(512) void k3_advect_fused(Geom3 g, State3 in, State
             const float ui = lds_vel(Us, D, H + 1, W, 1, z, y, x), vi = lds_vel(Vs, D, H, W + 1, EX, z, y, x);
             const float wi = vel3_at<0>(w2, D + 1, H, W, g.pc, z, y, x);
             r = advect_at(w2, D + 1, H, W, g.pc, z, y, x, ui, vi, wi);
-            if (ez < TZ || lastz) out.w[b * g.sw + ((size_t)z * H + y) * g.pc + x] = r;
+            if (ez < TZ || lastz) out.w[b * g.sw + (z * H + y) * g.pc + x] = r;
         }
         Ws[e] = r;
     }
@@ -520,8 +602,8 @@ __global__ __launch_bounds__(512) void k3_advect_fused(Geom3 g, State3 in, State
         const float wi = lds_vel(Ws, D + 1, H, W, EX * EY, z, y, x);
         float r = advect_at(d2, D, H, W, g.pc, z, y, x, ui, vi, wi);
         r = r * 0.995f;                                       // navier_stokes.py:171
-        if (frames) frames[(size_t)b * fsb + ((size_t)z * H + y) * W + x] = r;
-        out.d[b * g.sc + ((size_t)z * H + y) * g.pc + x] = r;
+        if (frames) frames[(size_t)b * fsb + (z * H + y) * W + x] = r;
+        out.d[b * g.sc + (z * H + y) * g.pc + x] = r;
     }
 }
 
