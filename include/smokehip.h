@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 7
+#define SMK_ABI_VERSION 8
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -172,6 +172,19 @@ typedef enum smk_stage3d {
     SMK_STAGE3D_ADVECT_D = 5      /* density advect + 0.995 decay */
 } smk_stage3d;
 int smk_sim3d_run_stage(smk_sim3d *sim, int32_t stage, void *stream);
+
+/* ------------------------------------------------------------------ 3-D encoder pieces (BASELINE configs[4]; SPEC_3D.md section 8)
+ * No reference counterpart (the reference's input_encoder is Conv2d: smokephys_net.py:24-32).  Conv3d runs as an explicit GEMM on the
+ * split-bf16 MFMA linear kernel (smk_linear_forward): these two entry points are the data movement around it.
+ * smk_conv3d_im2col: src [D][H][W][C] fp32 (channels-last; C = 1 is the plain volume; C = 1 or a multiple of 4), zero padding ksize/2
+ *   (ksize odd), output rows for the planes z0 .. z0+nz-1: cols [nz*H*W][kpad], column tap*C + c with tap = (kz*ksize + ky)*ksize + kx,
+ *   columns >= ksize^3 * C zero (kpad >= ksize^3 * C, a multiple of 4; the linear kernel wants a multiple of 64).
+ * smk_pool3d_accumulate: act [nz][H][W][C] -> sums [32*32][C] += the sum over the slab's planes and over each token's (H/32) x (W/32)
+ *   block (H, W multiples of 32): the two adaptive average pools of smokephys_net.py:87-91 with the depth axis pooled to 1, as sums --
+ *   the caller divides by D * (H/32) * (W/32) once. */
+int smk_conv3d_im2col(const float *src, int32_t C, int32_t D, int32_t H, int32_t W, int32_t ksize, int32_t z0, int32_t nz, float *cols,
+                      int32_t kpad, void *stream);
+int smk_pool3d_accumulate(const float *act, int32_t C, int32_t H, int32_t W, int32_t nz, float *sums, void *stream);
 
 /* Stand-alone stateless ops (pure functions of the reference) -------------------------------------- */
 /* NavierStokesSimulator.diffusion_step(field, viscosity) (navier_stokes.py:50-72) on [B][R][pitch]. */

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "chaos.h"
+#include "conv3d.h"
 #include "decoder.h"
 #include "elementwise.h"
 #include "encoder.h"
@@ -633,6 +634,25 @@ int smk_sim3d_run_stage(smk_sim3d *sim, int32_t stage, void *stream) {
     }
     set_error("unknown 3-D stage");
     return SMK_ERR_INVALID;
+}
+
+int smk_conv3d_im2col(const float *src, int32_t C, int32_t D, int32_t H, int32_t W, int32_t ksize, int32_t z0, int32_t nz, float *cols,
+                      int32_t kpad, void *stream) {
+    SMK_REQUIRE(src && cols, "null src/cols");
+    SMK_REQUIRE(C == 1 || C % 4 == 0, "C must be 1 or a multiple of 4");
+    SMK_REQUIRE(D >= 1 && H >= 1 && W >= 1 && ksize >= 1 && (ksize & 1), "D, H, W >= 1; ksize odd");
+    SMK_REQUIRE(z0 >= 0 && nz >= 1 && z0 + nz <= D, "plane range outside the volume");
+    SMK_REQUIRE(kpad >= ksize * ksize * ksize * C && kpad % 4 == 0, "kpad >= ksize^3 * C and a multiple of 4");
+    return check_launch(launch_im2col3d(src, C, D, H, W, ksize, z0, nz, cols, kpad, (hipStream_t)stream), "im2col3d");
+}
+
+int smk_pool3d_accumulate(const float *act, int32_t C, int32_t H, int32_t W, int32_t nz, float *sums, void *stream) {
+    SMK_REQUIRE(act && sums && C >= 1 && nz >= 1, "null act/sums or bad sizes");
+    if (H % 32 != 0 || W % 32 != 0) {
+        set_error("pool3d: H and W must be multiples of 32 (the two adaptive pools then compose to a block mean)");
+        return SMK_ERR_UNSUPPORTED;
+    }
+    return check_launch(launch_pool3d_accum(act, C, H, W, nz, sums, (hipStream_t)stream), "pool3d_accum");
 }
 
 int smk_diffuse(const float *in, float *out, int32_t B, int32_t R, int32_t C, int32_t pitch, double dt, double viscosity,

@@ -1,0 +1,78 @@
+// Conv3d encoder, explicit-GEMM first slice (see conv3d.h; SPEC_3D.md section 8).  Both kernels are pure data movement (HBM-bound):
+// coalesced 16-byte accesses along the channel / tap axis.
+#include "conv3d.h"
+
+namespace smk {
+
+// C = 1 (conv1: 7 x 7 x 7 = 343 taps of a scalar field): one thread per output element, consecutive threads = consecutive taps of one
+// voxel (coalesced stores; the gathered reads of a voxel's window come from the L1 / L2)
+__global__ __launch_bounds__(256) void k_im2col3d_scalar(const float *__restrict__ src, int D, int H, int W, int ks, int z0, long long total,
+                                                         float *__restrict__ cols, int kpad) {
+    const int taps = ks * ks * ks, P = ks / 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long vox = i / kpad;
+        const int k = (int)(i - vox * kpad);
+        float v = 0.f;
+        if (k < taps) {
+            const int x = (int)(vox % W), y = (int)((vox / W) % H), z = z0 + (int)(vox / ((long long)W * H));
+            const int kx = k % ks, ky = (k / ks) % ks, kz = k / (ks * ks);
+            const int xx = x + kx - P, yy = y + ky - P, zz = z + kz - P;
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D) v = src[((size_t)zz * H + yy) * W + xx];
+        }
+        cols[i] = v;
+    }
+}
+
+// C % 4 == 0 (conv2: 27 taps x 64 channels): one thread per float4 of a (voxel, tap) piece -- a piece is C contiguous floats on both sides
+__global__ __launch_bounds__(256) void k_im2col3d_cl(const float *__restrict__ src, int C, int D, int H, int W, int ks, int z0, long long total4,
+                                                     float *__restrict__ cols, int kpad) {
+    const int taps = ks * ks * ks, P = ks / 2, c4n = C / 4, per_vox = kpad / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long vox = i / per_vox;
+        const int q = (int)(i - vox * per_vox), tap = q / c4n, c4 = q - tap * c4n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tap < taps) {
+            const int x = (int)(vox % W), y = (int)((vox / W) % H), z = z0 + (int)(vox / ((long long)W * H));
+            const int kx = tap % ks, ky = (tap / ks) % ks, kz = tap / (ks * ks);
+            const int xx = x + kx - P, yy = y + ky - P, zz = z + kz - P;
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D)
+                v = *reinterpret_cast<const float4 *>(src + (((size_t)zz * H + yy) * W + xx) * C + 4 * c4);
+        }
+        *reinterpret_cast<float4 *>(cols + vox * kpad + 4 * q) = v;
+    }
+}
+
+hipError_t launch_im2col3d(const float *src, int C, int D, int H, int W, int ksize, int z0, int nz, float *cols, int kpad, hipStream_t st) {
+    const long long vox = (long long)nz * H * W;
+    if (C == 1) {
+        const long long total = vox * kpad;
+        const int blocks = (int)((total + 255) / 256 < (1 << 20) ? (total + 255) / 256 : (1 << 20));
+        hipLaunchKernelGGL(k_im2col3d_scalar, dim3(blocks), dim3(256), 0, st, src, D, H, W, ksize, z0, total, cols, kpad);
+    } else {
+        const long long total4 = vox * (kpad / 4);
+        const int blocks = (int)((total4 + 255) / 256 < (1 << 20) ? (total4 + 255) / 256 : (1 << 20));
+        hipLaunchKernelGGL(k_im2col3d_cl, dim3(blocks), dim3(256), 0, st, src, C, D, H, W, ksize, z0, total4, cols, kpad);
+    }
+    return hipGetLastError();
+}
+
+// one workgroup per token (ty, tx) of the 32 x 32 grid, one thread per channel: the block's voxels are walked in a fixed order (plane,
+// row, column), so the sum is deterministic; launches on one stream accumulate slab after slab
+__global__ void k_pool3d_accum(const float *__restrict__ act, int C, int H, int W, int nz, float *__restrict__ sums) {
+    const int tok = blockIdx.x, ty = tok / 32, tx = tok % 32, bh = H / 32, bw = W / 32;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z)
+            for (int i = 0; i < bh; ++i)
+                for (int j = 0; j < bw; ++j)
+                    s += act[(((size_t)z * H + ty * bh + i) * W + tx * bw + j) * C + c];
+        sums[(size_t)tok * C + c] += s;
+    }
+}
+
+hipError_t launch_pool3d_accum(const float *act, int C, int H, int W, int nz, float *sums, hipStream_t st) {
+    hipLaunchKernelGGL(k_pool3d_accum, dim3(1024), dim3(C < 256 ? C : 256), 0, st, act, C, H, W, nz, sums);
+    return hipGetLastError();
+}
+
+}  // namespace smk

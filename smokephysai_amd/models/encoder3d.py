@@ -1,0 +1,88 @@
+"""3-D input encoder on MI355X (BASELINE configs[4]: "MFMA conv3d encoder"), first slice.
+
+The reference's encoder is 2-D (src/models/smokephys_net.py:24-32,87-91); SPEC_3D.md section 8 generalises it axis by axis:
+Conv3d(1, 64, 7, padding 3) + BatchNorm3d + ReLU -> Conv3d(64, 128, 3, padding 1) + BatchNorm3d + ReLU -> the two adaptive average
+pools with the depth axis pooled to 1 -> features [B, 128, 32, 32], i.e. exactly the tensor SmokePhysNet tokenises (smokephys_net.py:95),
+so the rest of the network applies unchanged.  Eval mode (running statistics folded into the weights, as HipEncoder does in 2-D).
+
+Execution: each convolution is an explicit GEMM on the split-bf16 MFMA linear kernel (fp32-class accuracy): `smk_conv3d_im2col`
+gathers the patches of a slab of planes into [voxels, taps x channels], `smk_linear_forward` multiplies with the folded weights (bias +
+ReLU in its epilogue), `smk_pool3d_accumulate` reduces the activated slab into the 32 x 32 token sums.  Activations are channels-last
+[D, H, W, C], which is what the GEMM writes.  The patch matrix makes this slice HBM-bound (27 x the activation bytes for conv2); the fused
+implicit-GEMM kernel (patches formed in LDS, as k_encoder_b16 does in 2-D) is the next step.
+"""
+import torch
+
+from .. import _lib
+from .linear import HipLinear
+
+_KEYS = ("conv1_w", "conv1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
+         "conv2_w", "conv2_b", "bn2_w", "bn2_b", "bn2_mean", "bn2_var")
+
+
+class HipEncoder3D:
+    def __init__(self, weights: dict, device="cuda", eps: float = 1e-5, slab_bytes: int = 2 << 30):
+        self._dev = _lib.require_cuda(device, "HipEncoder3D")
+        self._L = _lib.load()
+        w = {k: torch.as_tensor(weights[k]).detach().to(self._dev, torch.float64) for k in _KEYS}
+        if tuple(w["conv1_w"].shape) != (64, 1, 7, 7, 7) or tuple(w["conv2_w"].shape) != (128, 64, 3, 3, 3):
+            raise ValueError("HipEncoder3D: weights must be Conv3d(1,64,7) / Conv3d(64,128,3) (SPEC_3D.md section 8)")
+        s1 = w["bn1_w"] / torch.sqrt(w["bn1_var"] + eps)
+        s2 = w["bn2_w"] / torch.sqrt(w["bn2_var"] + eps)
+        # column order of smk_conv3d_im2col: tap * C + c, tap = (kz * k + ky) * k + kx
+        w1 = torch.zeros(64, 384, dtype=torch.float64, device=self._dev)
+        w1[:, :343] = w["conv1_w"].reshape(64, 343) * s1[:, None]
+        w2 = (w["conv2_w"].permute(0, 2, 3, 4, 1).reshape(128, 27 * 64) * s2[:, None]).contiguous()
+        b1 = (w["conv1_b"] - w["bn1_mean"]) * s1 + w["bn1_b"]
+        b2 = (w["conv2_b"] - w["bn2_mean"]) * s2 + w["bn2_b"]
+        self._lin1 = HipLinear(w1.float(), b1.float(), device=self._dev)
+        self._lin2 = HipLinear(w2.float(), b2.float(), device=self._dev)
+        self.slab_bytes = int(slab_bytes)
+
+    def _im2col(self, src, C, D, H, W, k, z0, nz, kpad):
+        cols = torch.empty(nz * H * W, kpad, device=self._dev)
+        _lib.check(self._L.smk_conv3d_im2col(src.data_ptr(), C, D, H, W, k, z0, nz, cols.data_ptr(), kpad, _lib.stream_ptr(self._dev)))
+        return cols
+
+    def conv1_activations(self, vol: torch.Tensor) -> torch.Tensor:
+        """One volume [D, H, W] -> relu(bn1(conv1)) channels-last [D, H, W, 64]."""
+        D, H, W = vol.shape
+        a1 = torch.empty(D, H, W, 64, device=self._dev)
+        nz = max(1, min(D, self.slab_bytes // (H * W * 384 * 4)))
+        for z0 in range(0, D, nz):
+            n = min(nz, D - z0)
+            cols = self._im2col(vol, 1, D, H, W, 7, z0, n, 384)
+            self._lin1(cols, activation="relu", out=a1[z0:z0 + n].view(n * H * W, 64))
+        return a1
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B, 1, D, H, W] or [B, D, H, W] float32 -> features [B, 128, 32, 32] (H, W multiples of 32)."""
+        if x.dim() == 5:
+            if x.shape[1] != 1:
+                raise ValueError("the 3-D encoder takes one channel")
+            x = x[:, 0]
+        if x.dim() != 4:
+            raise ValueError("x must be [B, 1, D, H, W] or [B, D, H, W]")
+        x = x.to(self._dev, torch.float32).contiguous()
+        B, D, H, W = x.shape
+        for n in (H, W):
+            if n % 32 or not (n % 128 == 0 or 128 % n == 0):
+                raise ValueError("HipEncoder3D: H and W must be 32, 64 or a multiple of 128 (the two adaptive pools then compose to a "
+                                 "uniform block mean)")
+        out = torch.empty(B, 128, 32, 32, device=self._dev)
+        nz = max(1, min(D, self.slab_bytes // (H * W * 1728 * 4)))
+        for b in range(B):
+            a1 = self.conv1_activations(x[b])
+            sums = torch.zeros(1024, 128, device=self._dev)
+            for z0 in range(0, D, nz):
+                n = min(nz, D - z0)
+                cols = self._im2col(a1, 64, D, H, W, 3, z0, n, 1728)
+                a2 = self._lin2(cols, activation="relu")                                  # [n H W, 128] channels-last
+                _lib.check(self._L.smk_pool3d_accumulate(a2.data_ptr(), 128, H, W, n, sums.data_ptr(), _lib.stream_ptr(self._dev)))
+                del cols, a2
+            out[b] = (sums / float(D * (H // 32) * (W // 32))).t().reshape(128, 32, 32)
+        return out
+
+    def tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """Same features token-major [B, 1024, 128] (= features.flatten(2).transpose(1, 2), smokephys_net.py:95)."""
+        return self(x).flatten(2).transpose(1, 2).contiguous()

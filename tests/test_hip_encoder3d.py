@@ -1,0 +1,81 @@
+"""The 3-D encoder (BASELINE configs[4]: "MFMA conv3d encoder", first slice) through the C ABI -- smk_conv3d_im2col -> smk_linear_forward
+(split-bf16 MFMA) -> smk_pool3d_accumulate -- against oracle/encoder3d.py (fp64 numpy restatement of SPEC_3D.md section 8, itself checked
+against torch's CPU conv3d / batch_norm / adaptive_avg_pool3d in tests/test_oracle_golden.py).  Bar: 1e-4 relative (max-norm), the
+path's float tolerance; the patch matrices are index work and are checked exactly."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle.encoder3d import encoder3d_features
+
+pytestmark = pytest.mark.gpu
+
+from smokephysai_amd import _lib                                  # noqa: E402
+from smokephysai_amd.models import HipEncoder3D                   # noqa: E402
+
+
+def _weights(seed=0):
+    rng = np.random.RandomState(seed)
+    return {k: v.astype(np.float32) for k, v in dict(
+        conv1_w=rng.randn(64, 1, 7, 7, 7) * 0.05, conv1_b=rng.randn(64) * 0.1, bn1_w=rng.rand(64) + 0.5, bn1_b=rng.randn(64) * 0.1,
+        bn1_mean=rng.randn(64) * 0.2, bn1_var=rng.rand(64) + 0.3, conv2_w=rng.randn(128, 64, 3, 3, 3) * 0.03,
+        conv2_b=rng.randn(128) * 0.1, bn2_w=rng.rand(128) + 0.5, bn2_b=rng.randn(128) * 0.1,
+        bn2_mean=rng.randn(128) * 0.2, bn2_var=rng.rand(128) + 0.3).items()}
+
+
+def test_patch_matrices_are_exact():
+    """smk_conv3d_im2col: every entry is a copy of one source element or a padding zero -- exact, for the scalar (7^3) and the
+    channels-last (3^3 x 64) form, for a slab in the middle of the volume and at both ends."""
+    L = _lib.load()
+    rng = np.random.RandomState(1)
+    D, H, W = 6, 10, 12
+    vol = rng.rand(D, H, W).astype(np.float32)
+    a1 = rng.rand(D, H, W, 64).astype(np.float32)
+    st = _lib.stream_ptr(torch.device("cuda", 0))
+    for (src, C, k, kpad) in ((vol, 1, 7, 384), (a1, 64, 3, 1728)):
+        t = torch.from_numpy(src).cuda()
+        P = k // 2
+        padded = np.pad(src.reshape(D, H, W, C), ((P, P), (P, P), (P, P), (0, 0)))
+        for z0, nz in ((0, 2), (2, 3), (4, 2)):
+            cols = torch.full((nz * H * W, kpad), -1.0, device="cuda")
+            _lib.check(L.smk_conv3d_im2col(t.data_ptr(), C, D, H, W, k, z0, nz, cols.data_ptr(), kpad, st))
+            ref = np.zeros((nz, H, W, kpad), np.float32)
+            for kz in range(k):
+                for ky in range(k):
+                    for kx in range(k):
+                        tap = (kz * k + ky) * k + kx
+                        ref[..., tap * C:(tap + 1) * C] = padded[z0 + kz:z0 + kz + nz, ky:ky + H, kx:kx + W]
+            np.testing.assert_array_equal(cols.cpu().numpy().reshape(nz, H, W, kpad), ref)
+
+
+@pytest.mark.parametrize("shape,slab", [((8, 32, 32), 1 << 22), ((6, 64, 64), 1 << 24), ((3, 128, 32), 2 << 30)])
+def test_features_vs_oracle(shape, slab):
+    """Two volumes -> [2, 128, 32, 32]: conv1 activations and the pooled features within 1e-4 of the fp64 oracle (measured ~1e-6: split-bf16
+    operands, fp32 accumulation); small slab budgets force several slabs per volume, i.e. the accumulation across launches."""
+    w = _weights(sum(shape))
+    rng = np.random.RandomState(7)
+    vols = (rng.rand(2, *shape) * 1.5).astype(np.float32)
+    vols[1, :, : shape[1] // 2] = 0.0                               # an empty half: padding and zero activations are exercised
+    enc = HipEncoder3D({k: torch.from_numpy(v) for k, v in w.items()}, slab_bytes=slab)
+    x = torch.from_numpy(vols).cuda()
+    got = enc(x[:, None]).cpu().numpy()
+    assert got.shape == (2, 128, 32, 32)
+    a1 = enc.conv1_activations(x[0]).cpu().numpy()                  # [D, H, W, 64]
+    for b in range(2):
+        ref, ref_a1 = encoder3d_features(vols[b], w)
+        assert rel_err(got[b], ref) < 1e-4, b
+        if b == 0:
+            assert rel_err(np.moveaxis(a1, -1, 0), ref_a1) < 1e-4
+    tok = enc.tokens(x).cpu().numpy()
+    np.testing.assert_array_equal(tok, got.reshape(2, 128, 1024).transpose(0, 2, 1))
+
+
+def test_loud_failures():
+    enc = HipEncoder3D({k: torch.from_numpy(v) for k, v in _weights().items()})
+    with pytest.raises(ValueError):
+        enc(torch.zeros(1, 1, 4, 96, 32, device="cuda"))            # 96: the two adaptive pools do not compose to a uniform block mean
+    with pytest.raises(ValueError):
+        enc(torch.zeros(1, 2, 4, 32, 32, device="cuda"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipEncoder3D({k: torch.from_numpy(v) for k, v in _weights().items()}, device="cpu")

@@ -333,3 +333,25 @@ def test_nd_oracle_3d_instance_properties():
     one = lambda z, y, x: float(ns.interpolate(f, [np.array([c], np.float32) for c in (z, y, x)])[0])
     assert one(3.0, 1.5, 2.5) == 0.0 and one(1.5, 4.0, 2.5) == 0.0 and one(1.5, 2.5, 5.0) == 0.0
     assert one(1.5, 2.5, 3.5) == float(np.float32(f[1:3, 2:4, 3:5].mean()))
+
+
+def test_encoder3d_oracle_matches_torch_cpu_operators():
+    """oracle/encoder3d.py (numpy, fp64: SPEC_3D.md section 8) against the same operator chain evaluated by torch's CPU kernels in fp64 --
+    F.conv3d / F.batch_norm / F.adaptive_avg_pool3d, the third-party arithmetic the reference's own (2-D) encoder runs on."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.encoder3d import encoder3d_features
+    rng = np.random.RandomState(3)
+    w = dict(conv1_w=rng.randn(64, 1, 7, 7, 7) * 0.05, conv1_b=rng.randn(64) * 0.1, bn1_w=rng.rand(64) + 0.5, bn1_b=rng.randn(64) * 0.1,
+             bn1_mean=rng.randn(64) * 0.2, bn1_var=rng.rand(64) + 0.3, conv2_w=rng.randn(128, 64, 3, 3, 3) * 0.03,
+             conv2_b=rng.randn(128) * 0.1, bn2_w=rng.rand(128) + 0.5, bn2_b=rng.randn(128) * 0.1,
+             bn2_mean=rng.randn(128) * 0.2, bn2_var=rng.rand(128) + 0.3)
+    vol = rng.rand(5, 32, 64)
+    feats, a1 = encoder3d_features(vol, w)
+    t = {k: torch.from_numpy(np.asarray(v, np.float64)) for k, v in w.items()}
+    x = torch.from_numpy(vol)[None, None]
+    y = F.relu(F.batch_norm(F.conv3d(x, t["conv1_w"], t["conv1_b"], padding=3), t["bn1_mean"], t["bn1_var"], t["bn1_w"], t["bn1_b"], False, 0.1, 1e-5))
+    assert rel_err(a1, y[0].numpy()) < 1e-12
+    y = F.relu(F.batch_norm(F.conv3d(y, t["conv2_w"], t["conv2_b"], padding=1), t["bn2_mean"], t["bn2_var"], t["bn2_w"], t["bn2_b"], False, 0.1, 1e-5))
+    y = F.adaptive_avg_pool3d(F.adaptive_avg_pool3d(y, (1, 128, 128)), (1, 32, 32))
+    assert feats.shape == (128, 32, 32) and rel_err(feats, y[0, :, 0].numpy()) < 1e-12
