@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 8
+#define SMK_ABI_VERSION 9
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -305,6 +305,13 @@ int smk_linear_wgrad(const float *dy, int64_t ld_dy, const float *x, int64_t ldx
 int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx, void *y, int64_t ldy,
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream);
+
+/* Conv3d(64 -> N, kernel 3, padding 1) + bias + activation as an IMPLICIT GEMM on the split-bf16 MFMA layer kernel -- no patch matrix:
+ * src [D][H][W][64] fp32 channels-last, `lin` a layer handle with in_features = 27 * 64 whose weight columns are tap * 64 + c
+ * (tap = (kz*3 + ky)*3 + kx, i.e. conv.weight.permute(0, 2, 3, 4, 1).reshape(N, 1728)); output rows = the voxels of planes z0 .. z0+nz-1
+ * in memory order, y [nz*H*W][ldy].  One call addresses the planes it reads with 32-bit offsets: (nz + 2) * H * W * 256 < 2^32. */
+int smk_conv3d_cl_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
+                          int32_t activation, void *stream);
 
 /* ChaosAttention.generate_chaos_field's five explicit-Euler Lorenz states (chaos_attention.py:39-59) for noise [3][B] (the three
  * randn(B,1) draws before the 0.1 scale): states [B][5][3].  The gradient-free part of the chaos term, for the training path. */

@@ -969,6 +969,21 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
     return check_launch(launch_linear_x3(lin->l, c, (hipStream_t)stream), "linear_x3");
 }
 
+int smk_conv3d_cl_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
+                          int32_t activation, void *stream) {
+    SMK_REQUIRE(lin && src && y, "null lin/src/y");
+    SMK_REQUIRE(lin->l.K == 27 * 64, "the layer handle must have in_features = 27 * 64 (3 x 3 x 3 taps of 64 channels)");
+    SMK_REQUIRE(D >= 1 && H >= 1 && W >= 1 && z0 >= 0 && nz >= 1 && z0 + nz <= D, "plane range outside the volume");
+    SMK_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)y & 15) == 0 && ldy >= lin->l.N && ldy % 4 == 0, "16-byte aligned src / y, ldy >= out_features");
+    SMK_REQUIRE((int64_t)(nz + 2) * H * W * 256 < (1LL << 32) - 256 && (int64_t)nz * H * W < (1LL << 31) - 256, "slab too large for 32-bit offsets: fewer planes per call");
+    SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_GELU || activation == SMK_ACT_RELU, "activation");
+    DeviceGuard guard(lin->device);
+    if (guard.rc) return guard.rc;
+    const int zlo = z0 > 0 ? z0 - 1 : 0, zhi = z0 + nz + 1 < D ? z0 + nz + 1 : D;
+    return check_launch(launch_conv3d_cl_b16(lin->l, src + (size_t)zlo * H * W * 64, zhi - zlo, H, W, z0 - zlo, nz, y, ldy, activation,
+                                             (hipStream_t)stream), "conv3d_cl_b16");
+}
+
 // ------------------------------------------------------------------ chaos term of ChaosAttention
 int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj_w, const float *proj_b,
                      const float *gate_w, const float *gate_b, double strength, double sigma, double rho, double beta,

@@ -4,22 +4,28 @@
 
 namespace smk {
 
-// C = 1 (conv1: 7 x 7 x 7 = 343 taps of a scalar field): one thread per output element, consecutive threads = consecutive taps of one
-// voxel (coalesced stores; the gathered reads of a voxel's window come from the L1 / L2)
-__global__ __launch_bounds__(256) void k_im2col3d_scalar(const float *__restrict__ src, int D, int H, int W, int ks, int z0, long long total,
+// C = 1 (conv1: 7 x 7 x 7 = 343 taps of a scalar field): one thread per FOUR consecutive taps of one voxel (one 16-byte store; the index
+// arithmetic once per four elements); consecutive threads = consecutive tap quads of one voxel, so a wave writes 1 KiB contiguous and
+// the gathered reads of a voxel's window come from the L1 / L2
+__global__ __launch_bounds__(256) void k_im2col3d_scalar(const float *__restrict__ src, int D, int H, int W, int ks, int z0, long long total4,
                                                          float *__restrict__ cols, int kpad) {
-    const int taps = ks * ks * ks, P = ks / 2;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long vox = i / kpad;
-        const int k = (int)(i - vox * kpad);
-        float v = 0.f;
-        if (k < taps) {
-            const int x = (int)(vox % W), y = (int)((vox / W) % H), z = z0 + (int)(vox / ((long long)W * H));
-            const int kx = k % ks, ky = (k / ks) % ks, kz = k / (ks * ks);
-            const int xx = x + kx - P, yy = y + ky - P, zz = z + kz - P;
-            if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D) v = src[((size_t)zz * H + yy) * W + xx];
+    const int taps = ks * ks * ks, P = ks / 2, per_vox = kpad / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long vox = i / per_vox;
+        const int k0 = (int)(i - vox * per_vox) * 4;
+        const int x = (int)(vox % W), y = (int)((vox / W) % H), z = z0 + (int)(vox / ((long long)W * H));
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            v[e] = 0.f;
+            if (k < taps) {
+                const int kx = k % ks, ky = (k / ks) % ks, kz = k / (ks * ks);
+                const int xx = x + kx - P, yy = y + ky - P, zz = z + kz - P;
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D) v[e] = src[((size_t)zz * H + yy) * W + xx];
+            }
         }
-        cols[i] = v;
+        *reinterpret_cast<float4 *>(cols + vox * kpad + k0) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -45,9 +51,9 @@ __global__ __launch_bounds__(256) void k_im2col3d_cl(const float *__restrict__ s
 hipError_t launch_im2col3d(const float *src, int C, int D, int H, int W, int ksize, int z0, int nz, float *cols, int kpad, hipStream_t st) {
     const long long vox = (long long)nz * H * W;
     if (C == 1) {
-        const long long total = vox * kpad;
-        const int blocks = (int)((total + 255) / 256 < (1 << 20) ? (total + 255) / 256 : (1 << 20));
-        hipLaunchKernelGGL(k_im2col3d_scalar, dim3(blocks), dim3(256), 0, st, src, D, H, W, ksize, z0, total, cols, kpad);
+        const long long total4 = vox * (kpad / 4);
+        const int blocks = (int)((total4 + 255) / 256 < (1 << 20) ? (total4 + 255) / 256 : (1 << 20));
+        hipLaunchKernelGGL(k_im2col3d_scalar, dim3(blocks), dim3(256), 0, st, src, D, H, W, ksize, z0, total4, cols, kpad);
     } else {
         const long long total4 = vox * (kpad / 4);
         const int blocks = (int)((total4 + 255) / 256 < (1 << 20) ? (total4 + 255) / 256 : (1 << 20));

@@ -28,6 +28,10 @@ struct LinearCall {
 hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed = 0,
                                        long long ld = 0, int k_valid = -1);
 hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t st);
+// Conv3d(64 -> N, 3 x 3 x 3, padding 1 inside the slab) as an implicit GEMM (linear.hip, k_linear_b16<NW, true>): slab [Dl][H][W][64]
+// channels-last, output rows = voxels of planes z_off .. z_off+nz-1, weights = a layer handle with K = 27 * 64 (column tap * 64 + c)
+hipError_t launch_conv3d_cl_b16(const LinearDev &l, const float *slab, int Dl, int H, int W, int z_off, int nz, float *y, long long ldy, int act,
+                                hipStream_t st);
 
 // dW = dY^T X (linear.hip): workspace layout and segment count for a problem size
 struct WgradPlan { int nseg; long long rows_pad; size_t off_wq, off_part, off_col, bytes; };

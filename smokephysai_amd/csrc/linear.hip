@@ -126,6 +126,9 @@ struct LinearArgs {
     LinearCall c;
     int tiles_m, tiles_n;
     int swz, stagger, stagger_unit, num_cu;
+    // implicit-GEMM Conv3d (k_linear_b16<NW, true>): x is a channels-last slab [cDl][cH][cW][64], output rows are the voxels of planes
+    // cz_off .. of that slab in memory order; chunk c of the K range is tap c of the 3 x 3 x 3 window (zero outside the slab)
+    int cDl, cH, cW, cz_off;
     unsigned long long *stamps;
     int dbg;              // timing ablations, honoured only by -DSMK_LN_DIAG builds (results are wrong when non-zero): 1 A loads re-read tile 0,
                           // 2 B ring re-reads k-step 0, 4 no epilogue, 8 epilogue stores as whole 128-byte row pieces
@@ -547,7 +550,11 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
 //   Token image in LDS: [128 rows][64 k] bf16 per plane, UNPADDED 128-byte rows with the 16-byte unit u of row r stored at u ^ (r & 7):
 //   conflict-free for this shape's ds_read_b128 (lanes {0-3, 12-15, 20-27} together: 8 rows of one k-group with 8 rows of the next) and
 //   for the 8-byte staging stores, found by search over pitches x swizzles; 65 KB per workgroup instead of 74.
-template <int NW>
+//   CONV: the implicit-GEMM form of a 3 x 3 x 3, 64-channel Conv3d on a channels-last volume (SPEC_3D.md section 8): output row = voxel,
+//   chunk c = tap c, and the chunk's 64 k of a row are the 64 contiguous channels of the voxel at (z + dz, y + dy, x + dx) -- the same
+//   256-byte row piece a linear layer stages, at a shifted address, or zeros outside the volume (the offset is then moved past the buffer's
+//   range, where the hardware returns 0: no branch in the staging path).  No patch matrix ever exists in memory.
+template <int NW, bool CONV = false>
 __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int TM = 128, TN = NW * 32, RP = NW * 4, NP = TM / RP, PLANE = TM * 128;
@@ -581,14 +588,36 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     // ---- token staging (as k_linear_x3, fp32 source): thread = float4 column sc of rows sr, sr + RP, ...
     const int sc = tid & 15, sr = tid >> 4;
     float4 stage[NP];
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.c.x), 0, (int)(((long long)(M - 1) * a.c.ldx + K) * 4), 0x00020000);
-    const int ldxb = (int)a.c.ldx * 4;
+    const unsigned xbytes = CONV ? (unsigned)((long long)a.cDl * a.cH * a.cW * 256) : (unsigned)(((long long)(M - 1) * a.c.ldx + K) * 4);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.c.x), 0, (int)xbytes, 0x00020000);
+    const int ldxb = CONV ? 256 : (int)a.c.ldx * 4;
     const int lane_x = sr * ldxb + sc * 16;
+    // CONV: (x, y, z) of this thread's NP staging rows of the tile being loaded (recomputed when the chunk stream moves to the next tile)
+    int vx[CONV ? NP : 1], vy[CONV ? NP : 1], vz[CONV ? NP : 1];
+    auto conv_coords = [&](int tmx) {
+        if constexpr (CONV) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int m = tmx * TM + RP * j + sr;
+                const int plane = a.cH * a.cW, zr = m / plane, rem = m - zr * plane, yy = rem / a.cW;
+                vz[j] = zr + a.cz_off; vy[j] = yy; vx[j] = rem - yy * a.cW;
+            }
+        }
+    };
     auto stage_load = [&](int tmx, int cx, int j) {
-        const unsigned off = ((unsigned)tmx * TM + RP * j) * (unsigned)ldxb + (unsigned)cx * 256u;    // rows past M read as zero in hardware
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
-        stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        unsigned off;
+        if constexpr (CONV) {
+            const int dz = cx / 9 - 1, dy = (cx / 3) % 3 - 1, dx = cx % 3 - 1;                // wave-uniform (scalar)
+            const bool ok = (unsigned)(vx[j] + dx) < (unsigned)a.cW && (unsigned)(vy[j] + dy) < (unsigned)a.cH && (unsigned)(vz[j] + dz) < (unsigned)a.cDl;
+            const unsigned lin = (unsigned)(((vz[j] + dz) * a.cH + (vy[j] + dy)) * a.cW + (vx[j] + dx));
+            off = ok ? lin * 256u + (unsigned)sc * 16u : 0xfffffff0u;                         // past the buffer: reads as zero in hardware
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0);
+            stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else {
+            off = ((unsigned)tmx * TM + RP * j) * (unsigned)ldxb + (unsigned)cx * 256u;       // rows past M read as zero in hardware
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
+            stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
     };
     // row sr + RP j: RP is a multiple of 8, so (row & 7) = sr & 7 for every piece
     const int st_off = sr * 128 + ((((sc >> 1) ^ (sr & 7))) << 4) + (sc & 1) * 8;
@@ -607,8 +636,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     };
     int ld_tm = tm, ld_c = 0;
     auto advance = [&]() {
-        if (++ld_c == nchunks) { ld_c = 0; ld_tm = ld_tm + tm_step < a.tiles_m ? ld_tm + tm_step : a.tiles_m; }
+        if (++ld_c == nchunks) {
+            ld_c = 0;
+            ld_tm = ld_tm + tm_step < a.tiles_m ? ld_tm + tm_step : a.tiles_m;
+            conv_coords(ld_tm);                              // (past the last tile: rows >= M, whose plane index is outside the slab -> zeros)
+        }
     };
+    conv_coords(ld_tm);
 #pragma unroll
     for (int j = 0; j < NP; ++j) stage_load(ld_tm, ld_c, j);
     advance();
@@ -769,11 +803,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     }
 }
 
-template <int NW>
+template <int NW, bool CONV = false>
 static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
     constexpr int lds = 4 * 128 * 128 + 1024;
-    once_per_device((const void *)k_linear_b16<NW>, [&] {
-        (void)hipFuncSetAttribute((const void *)k_linear_b16<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    once_per_device((const void *)k_linear_b16<NW, CONV>, [&] {
+        (void)hipFuncSetAttribute((const void *)k_linear_b16<NW, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const int nwg_max = (NW == 8 ? 1 : 2) * a.num_cu;        // 8 waves per CU either way
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
@@ -784,8 +818,26 @@ static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
     static int swz_env = -1;
     if (swz_env < 0) { const char *s = getenv("SMK_LINEAR_SWZ"); swz_env = s ? atoi(s) : 1; }
     b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
-    hipLaunchKernelGGL((k_linear_b16<NW>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
+    hipLaunchKernelGGL((k_linear_b16<NW, CONV>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
     return hipGetLastError();
+}
+
+// 3 x 3 x 3 Conv3d of a channels-last 64-channel slab as an implicit GEMM on the layer kernel (K = 27 x 64; weights in the layer layout,
+// column tap * 64 + c): rows = the voxels of planes z_off .. z_off + nz - 1 of the slab [Dl][H][W][64]; y [nz H W][N] + bias, activation
+hipError_t launch_conv3d_cl_b16(const LinearDev &l, const float *slab, int Dl, int H, int W, int z_off, int nz, float *y, long long ldy, int act,
+                                hipStream_t st) {
+    if (l.K != 27 * 64 || (long long)Dl * H * W * 256 >= (1LL << 32) - 256) return hipErrorInvalidValue;
+    LinearArgs a{};
+    a.l = l;
+    a.c.x = slab; a.c.ldx = 64; a.c.y = y; a.c.ldy = ldy; a.c.res = nullptr; a.c.ldr = 0; a.c.padd = nullptr; a.c.rows_per_group = 1; a.c.period = 1;
+    a.c.M = nz * H * W; a.c.act = act; a.c.x_split = 0; a.c.y_split = 0; a.c.nseg = 1;
+    a.cDl = Dl; a.cH = H; a.cW = W; a.cz_off = z_off;
+    a.num_cu = device_num_cu();
+    a.stamps = nullptr; a.dbg = 0; a.swz = 0; a.stagger = 0; a.stagger_unit = 0;
+    const int nw = (l.N >= 256 && (long long)cdiv(a.c.M, 128) * cdiv(l.N, 256) >= a.num_cu) ? 8 : 4;
+    a.tiles_n = cdiv(l.N, nw * 32);
+    a.tiles_m = cdiv(a.c.M, 128);
+    return nw == 8 ? launch_b16<8, true>(a, st) : launch_b16<4, true>(a, st);
 }
 
 hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t st) {

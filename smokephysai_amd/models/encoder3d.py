@@ -5,11 +5,12 @@ Conv3d(1, 64, 7, padding 3) + BatchNorm3d + ReLU -> Conv3d(64, 128, 3, padding 1
 pools with the depth axis pooled to 1 -> features [B, 128, 32, 32], i.e. exactly the tensor SmokePhysNet tokenises (smokephys_net.py:95),
 so the rest of the network applies unchanged.  Eval mode (running statistics folded into the weights, as HipEncoder does in 2-D).
 
-Execution: each convolution is an explicit GEMM on the split-bf16 MFMA linear kernel (fp32-class accuracy): `smk_conv3d_im2col`
-gathers the patches of a slab of planes into [voxels, taps x channels], `smk_linear_forward` multiplies with the folded weights (bias +
-ReLU in its epilogue), `smk_pool3d_accumulate` reduces the activated slab into the 32 x 32 token sums.  Activations are channels-last
-[D, H, W, C], which is what the GEMM writes.  The patch matrix makes this slice HBM-bound (27 x the activation bytes for conv2); the fused
-implicit-GEMM kernel (patches formed in LDS, as k_encoder_b16 does in 2-D) is the next step.
+Execution: both convolutions are GEMMs on the split-bf16 MFMA layer kernel (fp32-class accuracy), activations channels-last
+[D, H, W, C] (what the GEMM writes).  conv1 (343 taps of a scalar field) is an explicit GEMM: `smk_conv3d_im2col` gathers the patches of
+a slab of planes into [voxels, 384], `smk_linear_forward` multiplies with the folded weights (bias + ReLU in its epilogue).  conv2 (98 % of
+the flops) is an IMPLICIT GEMM (`smk_conv3d_cl_forward`, k_linear_b16<NW, true>): chunk c of the layer kernel's K loop is tap c, staged
+from the voxel at the shifted address -- no patch matrix (`conv2_mode="im2col"` keeps the explicit form for A/B runs).
+`smk_pool3d_accumulate` reduces the activated slab into the 32 x 32 token sums.
 """
 import torch
 
@@ -21,7 +22,7 @@ _KEYS = ("conv1_w", "conv1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
 
 
 class HipEncoder3D:
-    def __init__(self, weights: dict, device="cuda", eps: float = 1e-5, slab_bytes: int = 2 << 30):
+    def __init__(self, weights: dict, device="cuda", eps: float = 1e-5, slab_bytes: int = 2 << 30, conv2_mode: str = "implicit"):
         self._dev = _lib.require_cuda(device, "HipEncoder3D")
         self._L = _lib.load()
         w = {k: torch.as_tensor(weights[k]).detach().to(self._dev, torch.float64) for k in _KEYS}
@@ -38,6 +39,9 @@ class HipEncoder3D:
         self._lin1 = HipLinear(w1.float(), b1.float(), device=self._dev)
         self._lin2 = HipLinear(w2.float(), b2.float(), device=self._dev)
         self.slab_bytes = int(slab_bytes)
+        if conv2_mode not in ("implicit", "im2col"):
+            raise ValueError("conv2_mode: 'implicit' (smk_conv3d_cl_forward, no patch matrix) or 'im2col' (explicit GEMM)")
+        self.conv2_mode = conv2_mode
 
     def _im2col(self, src, C, D, H, W, k, z0, nz, kpad):
         cols = torch.empty(nz * H * W, kpad, device=self._dev)
@@ -70,16 +74,27 @@ class HipEncoder3D:
                 raise ValueError("HipEncoder3D: H and W must be 32, 64 or a multiple of 128 (the two adaptive pools then compose to a "
                                  "uniform block mean)")
         out = torch.empty(B, 128, 32, 32, device=self._dev)
-        nz = max(1, min(D, self.slab_bytes // (H * W * 1728 * 4)))
+        implicit = self.conv2_mode == "implicit"
+        # implicit GEMM: no patch matrix; a slab is bounded by the activated output it materialises and by 32-bit offsets into a1
+        if implicit:
+            nz = max(1, min(D, self.slab_bytes // (H * W * 128 * 4), ((1 << 32) - 512) // (H * W * 256) - 2))
+        else:
+            nz = max(1, min(D, self.slab_bytes // (H * W * 1728 * 4)))
         for b in range(B):
             a1 = self.conv1_activations(x[b])
             sums = torch.zeros(1024, 128, device=self._dev)
             for z0 in range(0, D, nz):
                 n = min(nz, D - z0)
-                cols = self._im2col(a1, 64, D, H, W, 3, z0, n, 1728)
-                a2 = self._lin2(cols, activation="relu")                                  # [n H W, 128] channels-last
+                if implicit:
+                    a2 = torch.empty(n * H * W, 128, device=self._dev)
+                    _lib.check(self._L.smk_conv3d_cl_forward(self._lin2._handle, a1.data_ptr(), D, H, W, z0, n, a2.data_ptr(), 128,
+                                                             _lib.SMK_ACT_RELU, _lib.stream_ptr(self._dev)))
+                else:
+                    cols = self._im2col(a1, 64, D, H, W, 3, z0, n, 1728)
+                    a2 = self._lin2(cols, activation="relu")                              # [n H W, 128] channels-last
+                    del cols
                 _lib.check(self._L.smk_pool3d_accumulate(a2.data_ptr(), 128, H, W, n, sums.data_ptr(), _lib.stream_ptr(self._dev)))
-                del cols, a2
+                del a2
             out[b] = (sums / float(D * (H // 32) * (W // 32))).t().reshape(128, 32, 32)
         return out
 

@@ -69,6 +69,10 @@ def test_features_vs_oracle(shape, slab):
             assert rel_err(np.moveaxis(a1, -1, 0), ref_a1) < 1e-4
     tok = enc.tokens(x).cpu().numpy()
     np.testing.assert_array_equal(tok, got.reshape(2, 128, 1024).transpose(0, 2, 1))
+    # the explicit-GEMM form of conv2 (patch matrix + the plain layer kernel): the same products; only the slab sizes, hence the order in
+    # which the pooled partial sums are added, differ
+    ex = HipEncoder3D({k: torch.from_numpy(v) for k, v in w.items()}, slab_bytes=slab, conv2_mode="im2col")
+    assert rel_err(ex(x).cpu().numpy(), got) < 1e-6
 
 
 def test_loud_failures():
