@@ -4,7 +4,7 @@ set -u
 TAG=${1:-sten}; PMC=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
-ARGS="$R/bench.py --steps 100 --warmup 3 --cpu-frames 0 --no-inference --no-alt --no-config1 --no-train-step --no-encode"
+ARGS="$R/bench.py --steps 100 --warmup 3 --cpu-frames 0 --no-inference --no-alt --no-config1 --no-dataset --no-config4 --no-train-step --no-encode"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 if [ -n "$PMC" ]; then

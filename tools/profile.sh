@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$R/bench.py --steps $STEPS --warmup 2 --cpu-frames 0 --no-inference --no-alt --no-config1 --no-train-step --encoder-dtype $DTYPE"
+ARGS="$R/bench.py --steps $STEPS --warmup 2 --cpu-frames 0 --no-inference --no-alt --no-config1 --no-dataset --no-config4 --no-train-step --encoder-dtype $DTYPE"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || echo "fetch pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1 || echo "write pass failed"
