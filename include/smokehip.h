@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 9
+#define SMK_ABI_VERSION 10
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -311,6 +311,11 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
  * (tap = (kz*3 + ky)*3 + kx, i.e. conv.weight.permute(0, 2, 3, 4, 1).reshape(N, 1728)); output rows = the voxels of planes z0 .. z0+nz-1
  * in memory order, y [nz*H*W][ldy].  One call addresses the planes it reads with 32-bit offsets: (nz + 2) * H * W * 256 < 2^32. */
 int smk_conv3d_cl_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
+                          int32_t activation, void *stream);
+/* Conv3d(1 -> N, kernel 7, padding 3) + bias + activation of a SCALAR volume src [D][H][W] as an implicit GEMM on the same kernel (SPEC_3D.md
+ * section 8, conv1): `lin` has in_features = 448 = 56 window rows x 8 kx slots, weight column (kz*7 + ky)*8 + kx (slot kx = 7 and window rows
+ * >= 49 zero); output rows = the voxels of planes z0 .. z0+nz-1, y [nz*H*W][ldy].  H, W <= 1023; (nz + 6) * H * W * 4 < 2^32. */
+int smk_conv3d_s7_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
                           int32_t activation, void *stream);
 
 /* ChaosAttention.generate_chaos_field's five explicit-Euler Lorenz states (chaos_attention.py:39-59) for noise [3][B] (the three

@@ -984,6 +984,21 @@ int smk_conv3d_cl_forward(smk_linear *lin, const float *src, int32_t D, int32_t 
                                              (hipStream_t)stream), "conv3d_cl_b16");
 }
 
+int smk_conv3d_s7_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
+                          int32_t activation, void *stream) {
+    SMK_REQUIRE(lin && src && y, "null lin/src/y");
+    SMK_REQUIRE(lin->l.K == 448, "the layer handle must have in_features = 448 (56 window rows x 8 kx slots)");
+    SMK_REQUIRE(D >= 1 && H >= 1 && W >= 1 && H <= 1023 && W <= 1023 && z0 >= 0 && nz >= 1 && z0 + nz <= D, "plane range outside the volume, or H / W > 1023");
+    SMK_REQUIRE(((uintptr_t)src & 3) == 0 && ((uintptr_t)y & 15) == 0 && ldy >= lin->l.N && ldy % 4 == 0, "aligned src / y, ldy >= out_features");
+    SMK_REQUIRE((int64_t)(nz + 6) * H * W * 4 < (1LL << 32) - 256 && nz + 6 <= 1022 && (int64_t)nz * H * W < (1LL << 31) - 256, "slab too large: fewer planes per call");
+    SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_GELU || activation == SMK_ACT_RELU, "activation");
+    DeviceGuard guard(lin->device);
+    if (guard.rc) return guard.rc;
+    const int zlo = z0 > 3 ? z0 - 3 : 0, zhi = z0 + nz + 3 < D ? z0 + nz + 3 : D;
+    return check_launch(launch_conv3d_s7_b16(lin->l, src + (size_t)zlo * H * W, zhi - zlo, H, W, z0 - zlo, nz, y, ldy, activation,
+                                             (hipStream_t)stream), "conv3d_s7_b16");
+}
+
 // ------------------------------------------------------------------ chaos term of ChaosAttention
 int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj_w, const float *proj_b,
                      const float *gate_w, const float *gate_b, double strength, double sigma, double rho, double beta,

@@ -33,6 +33,10 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
 hipError_t launch_conv3d_cl_b16(const LinearDev &l, const float *slab, int Dl, int H, int W, int z_off, int nz, float *y, long long ldy, int act,
                                 hipStream_t st);
 
+// Conv3d(1 -> N, 7 x 7 x 7, padding 3 inside the slab) of a scalar slab [Dl][H][W] as an implicit GEMM: K = 448 = 56 window rows x 8 kx slots
+hipError_t launch_conv3d_s7_b16(const LinearDev &l, const float *slab, int Dl, int H, int W, int z_off, int nz, float *y, long long ldy, int act,
+                                hipStream_t st);
+
 // dW = dY^T X (linear.hip): workspace layout and segment count for a problem size
 struct WgradPlan { int nseg; long long rows_pad; size_t off_wq, off_part, off_col, bytes; };
 WgradPlan plan_linear_wgrad(long long rows, int out_features, int in_features);

@@ -554,7 +554,12 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
 //   chunk c = tap c, and the chunk's 64 k of a row are the 64 contiguous channels of the voxel at (z + dz, y + dy, x + dx) -- the same
 //   256-byte row piece a linear layer stages, at a shifted address, or zeros outside the volume (the offset is then moved past the buffer's
 //   range, where the hardware returns 0: no branch in the staging path).  No patch matrix ever exists in memory.
-template <int NW, bool CONV = false>
+//   CONV = 2: the 7 x 7 x 7 convolution of a SCALAR volume [Dl][H][W] (SPEC_3D.md section 8, conv1) the same way: the K range is laid out as
+//   56 (kz, ky) window rows x 8 kx slots (row r = kz * 7 + ky; rows >= 49 and slot 7 carry zero weights), chunk c = window rows 8c .. 8c+7,
+//   and a staged 16-byte piece = 4 consecutive kx taps = 4 consecutive x of the input (one unaligned dwordx4 load); elements past the
+//   row's ends are zeroed by selects, window rows outside the volume by the out-of-range offset.  Waves whose 32 output columns lie
+//   beyond N (N = 64: two of four) stage their share of the tile and skip the MFMAs.
+template <int NW, int CONV = 0>
 __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int TM = 128, TN = NW * 32, RP = NW * 4, NP = TM / RP, PLANE = TM * 128;
@@ -588,33 +593,55 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     // ---- token staging (as k_linear_x3, fp32 source): thread = float4 column sc of rows sr, sr + RP, ...
     const int sc = tid & 15, sr = tid >> 4;
     float4 stage[NP];
-    const unsigned xbytes = CONV ? (unsigned)((long long)a.cDl * a.cH * a.cW * 256) : (unsigned)(((long long)(M - 1) * a.c.ldx + K) * 4);
+    const unsigned xbytes = CONV == 1 ? (unsigned)((long long)a.cDl * a.cH * a.cW * 256)
+                          : CONV == 2 ? (unsigned)((long long)a.cDl * a.cH * a.cW * 4)
+                                      : (unsigned)(((long long)(M - 1) * a.c.ldx + K) * 4);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.c.x), 0, (int)xbytes, 0x00020000);
     const int ldxb = CONV ? 256 : (int)a.c.ldx * 4;
     const int lane_x = sr * ldxb + sc * 16;
-    // CONV: (x, y, z) of this thread's NP staging rows of the tile being loaded (recomputed when the chunk stream moves to the next tile)
-    int vx[CONV ? NP : 1], vy[CONV ? NP : 1], vz[CONV ? NP : 1];
+    // CONV: (x, y, z) of this thread's NP staging rows of the tile being loaded, packed x | y << 10 | z << 20 (recomputed when the chunk
+    // stream moves to the next tile)
+    unsigned vxyz[CONV ? NP : 1];
     auto conv_coords = [&](int tmx) {
-        if constexpr (CONV) {
+        if constexpr (CONV != 0) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int m = tmx * TM + RP * j + sr;
                 const int plane = a.cH * a.cW, zr = m / plane, rem = m - zr * plane, yy = rem / a.cW;
-                vz[j] = zr + a.cz_off; vy[j] = yy; vx[j] = rem - yy * a.cW;
+                const int zz = zr + a.cz_off;
+                vxyz[j] = (unsigned)(rem - yy * a.cW) | (unsigned)yy << 10 | (unsigned)(zz > 1023 ? 1023 : zz) << 20;     // (z past the slab: any invalid value)
             }
         }
     };
     auto stage_load = [&](int tmx, int cx, int j) {
-        unsigned off;
-        if constexpr (CONV) {
+        if constexpr (CONV == 1) {
             const int dz = cx / 9 - 1, dy = (cx / 3) % 3 - 1, dx = cx % 3 - 1;                // wave-uniform (scalar)
-            const bool ok = (unsigned)(vx[j] + dx) < (unsigned)a.cW && (unsigned)(vy[j] + dy) < (unsigned)a.cH && (unsigned)(vz[j] + dz) < (unsigned)a.cDl;
-            const unsigned lin = (unsigned)(((vz[j] + dz) * a.cH + (vy[j] + dy)) * a.cW + (vx[j] + dx));
-            off = ok ? lin * 256u + (unsigned)sc * 16u : 0xfffffff0u;                         // past the buffer: reads as zero in hardware
+            const int x = (int)(vxyz[j] & 1023u) + dx, y = (int)((vxyz[j] >> 10) & 1023u) + dy, z = (int)(vxyz[j] >> 20) + dz;
+            const bool ok = (unsigned)x < (unsigned)a.cW && (unsigned)y < (unsigned)a.cH && (unsigned)z < (unsigned)a.cDl;
+            const unsigned lin = (unsigned)((z * a.cH + y) * a.cW + x);
+            const unsigned off = ok ? lin * 256u + (unsigned)sc * 16u : 0xfffffff0u;          // past the buffer: reads as zero in hardware
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0);
             stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else if constexpr (CONV == 2) {
+            const int r = cx * 8 + (sc >> 1);                                                 // window row kz * 7 + ky (>= 49: zero weights)
+            const int kz = r / 7, dz = kz - 3, dy = r - kz * 7 - 3, dx0 = (sc & 1) ? 1 : -3;
+            const int x = (int)(vxyz[j] & 1023u) + dx0, y = (int)((vxyz[j] >> 10) & 1023u) + dy, z = (int)(vxyz[j] >> 20) + dz;
+            const bool ok = r < 49 && (unsigned)y < (unsigned)a.cH && (unsigned)z < (unsigned)a.cDl;
+            const int lin = (z * a.cH + y) * a.cW + x;                                        // may point before the row's start: masked below
+            // a piece that starts before the buffer (lin < 0: only with y = z = 0) would wrap: those elements are masked anyway, so read from 0
+            const unsigned off = ok ? (unsigned)(lin < 0 ? 0 : lin) * 4u : 0xfffffff0u;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0);
+            const int sh = lin < 0 ? -lin : 0;                                                // elements shifted by the clamp to offset 0
+            float e[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            if (sh) {                                                                         // (x + i < 0 for i < sh <= 3: take element i - sh; masked below anyway)
+                const float t0 = e[0], t1 = e[1], t2 = e[2];
+                e[3] = sh == 1 ? t2 : (sh == 2 ? t1 : t0); e[2] = sh == 1 ? t1 : t0; e[1] = t0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = (unsigned)(x + i) < (unsigned)a.cW ? e[i] : 0.f;
+            stage[j] = make_float4(e[0], e[1], e[2], e[3]);
         } else {
-            off = ((unsigned)tmx * TM + RP * j) * (unsigned)ldxb + (unsigned)cx * 256u;       // rows past M read as zero in hardware
+            const unsigned off = ((unsigned)tmx * TM + RP * j) * (unsigned)ldxb + (unsigned)cx * 256u;    // rows past M read as zero in hardware
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
             stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
@@ -704,6 +731,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                     wl[nb] = __builtin_bit_cast(bf16x8, bq[ks][nb * 2 + 1]);
                 }
                 // product-major: consecutive MFMAs go to different accumulators; each accumulator still sums hi*lo, lo*hi, hi*hi in order
+                if (CONV == 2 && !nw_ok) return;             // (a wave with no output columns: staging only)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -803,7 +831,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     }
 }
 
-template <int NW, bool CONV = false>
+template <int NW, int CONV = 0>
 static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
     constexpr int lds = 4 * 128 * 128 + 1024;
     once_per_device((const void *)k_linear_b16<NW, CONV>, [&] {
@@ -826,7 +854,7 @@ static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
 // column tap * 64 + c): rows = the voxels of planes z_off .. z_off + nz - 1 of the slab [Dl][H][W][64]; y [nz H W][N] + bias, activation
 hipError_t launch_conv3d_cl_b16(const LinearDev &l, const float *slab, int Dl, int H, int W, int z_off, int nz, float *y, long long ldy, int act,
                                 hipStream_t st) {
-    if (l.K != 27 * 64 || (long long)Dl * H * W * 256 >= (1LL << 32) - 256) return hipErrorInvalidValue;
+    if (l.K != 27 * 64 || H > 1023 || W > 1023 || Dl > 1022 || (long long)Dl * H * W * 256 >= (1LL << 32) - 256) return hipErrorInvalidValue;
     LinearArgs a{};
     a.l = l;
     a.c.x = slab; a.c.ldx = 64; a.c.y = y; a.c.ldy = ldy; a.c.res = nullptr; a.c.ldr = 0; a.c.padd = nullptr; a.c.rows_per_group = 1; a.c.period = 1;
@@ -837,7 +865,24 @@ hipError_t launch_conv3d_cl_b16(const LinearDev &l, const float *slab, int Dl, i
     const int nw = (l.N >= 256 && (long long)cdiv(a.c.M, 128) * cdiv(l.N, 256) >= a.num_cu) ? 8 : 4;
     a.tiles_n = cdiv(l.N, nw * 32);
     a.tiles_m = cdiv(a.c.M, 128);
-    return nw == 8 ? launch_b16<8, true>(a, st) : launch_b16<4, true>(a, st);
+    return nw == 8 ? launch_b16<8, 1>(a, st) : launch_b16<4, 1>(a, st);
+}
+
+// 7 x 7 x 7 Conv3d of a scalar slab [Dl][H][W] -> N channels as an implicit GEMM (k_linear_b16<4, 2>): weights = a layer handle with
+// K = 448, column (kz * 7 + ky) * 8 + kx (slot kx = 7 and rows >= 49 zero); rows = the voxels of planes z_off .. z_off + nz - 1
+hipError_t launch_conv3d_s7_b16(const LinearDev &l, const float *slab, int Dl, int H, int W, int z_off, int nz, float *y, long long ldy, int act,
+                                hipStream_t st) {
+    if (l.K != 448 || H > 1023 || W > 1023 || Dl > 1022 || (long long)Dl * H * W * 4 >= (1LL << 32) - 256) return hipErrorInvalidValue;
+    LinearArgs a{};
+    a.l = l;
+    a.c.x = slab; a.c.ldx = 64; a.c.y = y; a.c.ldy = ldy; a.c.res = nullptr; a.c.ldr = 0; a.c.padd = nullptr; a.c.rows_per_group = 1; a.c.period = 1;
+    a.c.M = nz * H * W; a.c.act = act; a.c.x_split = 0; a.c.y_split = 0; a.c.nseg = 1;
+    a.cDl = Dl; a.cH = H; a.cW = W; a.cz_off = z_off;
+    a.num_cu = device_num_cu();
+    a.stamps = nullptr; a.dbg = 0; a.swz = 0; a.stagger = 0; a.stagger_unit = 0;
+    a.tiles_n = cdiv(l.N, 128);
+    a.tiles_m = cdiv(a.c.M, 128);
+    return launch_b16<4, 2>(a, st);
 }
 
 hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t st) {

@@ -6,10 +6,10 @@ pools with the depth axis pooled to 1 -> features [B, 128, 32, 32], i.e. exactly
 so the rest of the network applies unchanged.  Eval mode (running statistics folded into the weights, as HipEncoder does in 2-D).
 
 Execution: both convolutions are GEMMs on the split-bf16 MFMA layer kernel (fp32-class accuracy), activations channels-last
-[D, H, W, C] (what the GEMM writes).  conv1 (343 taps of a scalar field) is an explicit GEMM: `smk_conv3d_im2col` gathers the patches of
-a slab of planes into [voxels, 384], `smk_linear_forward` multiplies with the folded weights (bias + ReLU in its epilogue).  conv2 (98 % of
-the flops) is an IMPLICIT GEMM (`smk_conv3d_cl_forward`, k_linear_b16<NW, true>): chunk c of the layer kernel's K loop is tap c, staged
-from the voxel at the shifted address -- no patch matrix (`conv2_mode="im2col"` keeps the explicit form for A/B runs).
+[D, H, W, C] (what the GEMM writes).  Both are IMPLICIT GEMMs -- no patch matrix: conv2 (98 % of the flops; `smk_conv3d_cl_forward`, k_linear_b16<NW, 1>): chunk c of the layer
+kernel's K loop is tap c, staged from the voxel at the shifted address; conv1 (343 taps of a scalar field; `smk_conv3d_s7_forward`,
+k_linear_b16<4, 2>): the K range is 56 (kz, ky) window rows x 8 kx slots and a staged 16-byte piece is 4 consecutive x of the input.
+`conv2_mode="im2col"` keeps the explicit forms (`smk_conv3d_im2col` -> [voxels, taps x channels] -> `smk_linear_forward`) for A/B runs.
 `smk_pool3d_accumulate` reduces the activated slab into the 32 x 32 token sums.
 """
 import torch
@@ -37,11 +37,16 @@ class HipEncoder3D:
         b1 = (w["conv1_b"] - w["bn1_mean"]) * s1 + w["bn1_b"]
         b2 = (w["conv2_b"] - w["bn2_mean"]) * s2 + w["bn2_b"]
         self._lin1 = HipLinear(w1.float(), b1.float(), device=self._dev)
+        # implicit-GEMM layout of conv1: 56 window rows (kz * 7 + ky; 49 used) x 8 kx slots (7 used)
+        w1i = torch.zeros(64, 56, 8, dtype=torch.float64, device=self._dev)
+        w1i[:, :49, :7] = (w["conv1_w"].reshape(64, 49, 7) * s1[:, None, None])
+        self._lin1i = HipLinear(w1i.reshape(64, 448).float(), b1.float(), device=self._dev)
         self._lin2 = HipLinear(w2.float(), b2.float(), device=self._dev)
         self.slab_bytes = int(slab_bytes)
         if conv2_mode not in ("implicit", "im2col"):
-            raise ValueError("conv2_mode: 'implicit' (smk_conv3d_cl_forward, no patch matrix) or 'im2col' (explicit GEMM)")
+            raise ValueError("conv2_mode: 'implicit' (smk_conv3d_cl_forward / smk_conv3d_s7_forward, no patch matrix) or 'im2col' (explicit GEMM)")
         self.conv2_mode = conv2_mode
+        self.conv1_mode = conv2_mode
 
     def _im2col(self, src, C, D, H, W, k, z0, nz, kpad):
         cols = torch.empty(nz * H * W, kpad, device=self._dev)
@@ -52,6 +57,13 @@ class HipEncoder3D:
         """One volume [D, H, W] -> relu(bn1(conv1)) channels-last [D, H, W, 64]."""
         D, H, W = vol.shape
         a1 = torch.empty(D, H, W, 64, device=self._dev)
+        if self.conv1_mode == "implicit" and H <= 1023 and W <= 1023:
+            nz = max(1, min(D, ((1 << 32) - 512) // (H * W * 4) - 6, 1000, ((1 << 31) - 512) // (H * W)))
+            for z0 in range(0, D, nz):
+                n = min(nz, D - z0)
+                _lib.check(self._L.smk_conv3d_s7_forward(self._lin1i._handle, vol.data_ptr(), D, H, W, z0, n, a1[z0:z0 + n].data_ptr(), 64,
+                                                         _lib.SMK_ACT_RELU, _lib.stream_ptr(self._dev)))
+            return a1
         nz = max(1, min(D, self.slab_bytes // (H * W * 384 * 4)))
         for z0 in range(0, D, nz):
             n = min(nz, D - z0)
