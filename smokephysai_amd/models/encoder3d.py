@@ -22,7 +22,8 @@ _KEYS = ("conv1_w", "conv1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
 
 
 class HipEncoder3D:
-    def __init__(self, weights: dict, device="cuda", eps: float = 1e-5, slab_bytes: int = 2 << 30, conv2_mode: str = "implicit"):
+    def __init__(self, weights: dict, device="cuda", eps: float = 1e-5, slab_bytes: int = 2 << 30, conv2_mode: str = "implicit",
+                 a2_bytes: int = 128 << 20):
         self._dev = _lib.require_cuda(device, "HipEncoder3D")
         self._L = _lib.load()
         w = {k: torch.as_tensor(weights[k]).detach().to(self._dev, torch.float64) for k in _KEYS}
@@ -43,6 +44,9 @@ class HipEncoder3D:
         self._lin1i = HipLinear(w1i.reshape(64, 448).float(), b1.float(), device=self._dev)
         self._lin2 = HipLinear(w2.float(), b2.float(), device=self._dev)
         self.slab_bytes = int(slab_bytes)
+        # the activated conv2 slab is written by the GEMM and read back by the pooling launch right behind it: kept within the 256 MB
+        # Infinity Cache it is read from there (512 x 512 planes: one plane per launch; measured 34.4 -> 29.8 ms per 64-plane volume)
+        self.a2_bytes = int(a2_bytes)
         if conv2_mode not in ("implicit", "im2col"):
             raise ValueError("conv2_mode: 'implicit' (smk_conv3d_cl_forward / smk_conv3d_s7_forward, no patch matrix) or 'im2col' (explicit GEMM)")
         self.conv2_mode = conv2_mode
@@ -89,7 +93,7 @@ class HipEncoder3D:
         implicit = self.conv2_mode == "implicit"
         # implicit GEMM: no patch matrix; a slab is bounded by the activated output it materialises and by 32-bit offsets into a1
         if implicit:
-            nz = max(1, min(D, self.slab_bytes // (H * W * 128 * 4), ((1 << 32) - 512) // (H * W * 256) - 2))
+            nz = max(1, min(D, min(self.slab_bytes, self.a2_bytes) // (H * W * 128 * 4), ((1 << 32) - 512) // (H * W * 256) - 2))
         else:
             nz = max(1, min(D, self.slab_bytes // (H * W * 1728 * 4)))
         for b in range(B):

@@ -10,7 +10,7 @@ w = {k: torch.from_numpy(v.astype(np.float32)) for k, v in dict(
     conv2_b=rng.randn(128) * 0.1, bn2_w=rng.rand(128) + 0.5, bn2_b=rng.randn(128) * 0.1,
     bn2_mean=rng.randn(128) * 0.2, bn2_var=rng.rand(128) + 0.3).items()}
 D, H, W = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 512, 512)
-enc = HipEncoder3D(w)
+enc = HipEncoder3D(w, a2_bytes=int(os.environ.get('A2_MB', '128')) << 20)
 x = torch.rand(1, D, H, W, device="cuda")
 enc(x); torch.cuda.synchronize()
 t0 = time.perf_counter(); a1 = enc.conv1_activations(x[0]); torch.cuda.synchronize(); t1 = time.perf_counter()
