@@ -25,6 +25,26 @@ def test_committed_bench_line_has_the_contract_keys():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
 
 
+def test_round3_bench_line_has_the_new_blocks():
+    """The driver-like line of the round-3 build (profiles/r03/bench_steps20_driverlike.json): the contract keys plus this round's blocks --
+    cpu_baseline on every granted core, the dataset and configs[4] legs, the train step on a one-rank RCCL group, the effective warm-up."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03", "bench_steps20_driverlike.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "dataset", "config4", "train_step", "effective_warmup_steps", "inference_ms_per_frame"):
+        assert k in d, k
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1
+    assert abs(d["value"] - 64 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-6
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == cb["host_cores_available"] >= 1 and cb["single_thread"]["cores"] == 1 and cb["kind"] == "port"
+    ts = d["train_step"]
+    assert ts["rccl_ranks"] == 1 and ts["ddp_wrapped"] is True and "error" not in ts and "1 rank(s)" in ts["note"]
+    c4 = d["config4"]
+    assert c4["algorithmic_bytes_per_step"] == 8 * 64 * 512 * 512 * 4.0 * (37 + 3 * 20)
+    assert abs(c4["ms_per_step"] - (c4["ms_sim_per_step"] + 8 * c4["ms_encode_per_volume"])) < 1e-6
+    assert d["dataset"]["unit"] == "samples/s" and d["dataset"]["value"] > d["dataset"]["cpu_port"]["value"]
+    assert d["effective_warmup_steps"]["headline_leg"] == 5
+
+
 def test_bench_cli_defaults_are_the_baseline_config():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, check=True).stdout
     for flag in ("--gpus", "--steps", "--warmup", "--grid", "--batch", "--jacobi", "--encoder-dtype"):
