@@ -551,6 +551,15 @@ def main(argv=None):
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run):
         raise SystemExit(self_launch(args, argv))
 
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL prints a five-line version banner when a
+    # process group is created), so fd 1 is pointed at stderr for the life of the process and the line goes to a duplicate of the real stdout
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -729,7 +738,7 @@ def main(argv=None):
                 if rank == 0:
                     out["train_step"] = dict(ts_partial, error=f"abandoned after {args.train_step_limit:.0f} s (watchdog) in stage "
                                                                 f"{ts_partial.get('stage')!r}; the keys beside this one were measured before the part that did not return")
-                    print(json.dumps(out), flush=True)
+                    emit(out)
                 os._exit(3)
         dog = threading.Timer(args.train_step_limit, abandon)
         dog.daemon = True
@@ -747,7 +756,7 @@ def main(argv=None):
         if rank == 0:
             out["train_step"] = ts
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized():
         tdist.destroy_process_group()

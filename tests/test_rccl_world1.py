@@ -121,8 +121,8 @@ def test_bench_train_step_leg_runs_on_rccl_at_n1():
         env.pop(k, None)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
-    assert len(lines) == 1
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:600]      # ONE JSON line: RCCL's version banner must not reach stdout
     ts = json.loads(lines[0])["train_step"]
     assert "error" not in ts, ts
     assert ts["rccl_ranks"] == 1 and ts["ddp_wrapped"] is True and ts["collective_backend"].startswith("rccl"), ts
