@@ -212,11 +212,11 @@ def config4_leg(dev, steps=6):
                                  "note": "pass-model bytes 4*(37+3J) per cell (SPEC_3D.md section 7) over the measured time; the kernels move fewer "
                                          "(four Jacobi sweeps per launch, one advection launch), so like the 2-D figure this is work done per "
                                          "second in the survey's unit, not a bound on the pins"},
-            "roofline_encoder": {"bound": "mfma", "kernel": "conv1: smk_conv3d_im2col + k_linear_b16 (explicit GEMM); conv2: k_linear_b16<NW, CONV> (implicit GEMM, no patch matrix); k_pool3d_accum",
+            "roofline_encoder": {"bound": "mfma", "kernel": "conv1: k_linear_b16<4,2>, conv2: k_linear_b16<4,1> (implicit GEMMs on the split-bf16 layer kernel, no patch matrix); k_pool3d_accum",
                                  "achieved": enc_flop / (ms_enc * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s",
                                  "frac": enc_flop / (ms_enc * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16x3"],
-                                 "note": "first slice: within 1e-6 of the fp64 oracle; conv1's patch matrix (25.8 GB per volume) and the unfused "
-                                         "activation round trips (a1 4.3 GB, a2 8.6 GB per volume) are what the fused kernel of DESIGN section 9 removes"}}
+                                 "note": "first slice: within 1e-6 of the fp64 oracle; the x3 split executes 3 MFMA products per counted multiply; the "
+                                         "unfused activation round trips (a1 4.3 GB, a2 8.6 GB per volume) are what the fused kernel of DESIGN section 9 removes"}}
 
 
 def hbm_copy_gbs(dev):
