@@ -62,8 +62,36 @@ hipError_t launch_im2col3d(const float *src, int C, int D, int H, int W, int ksi
     return hipGetLastError();
 }
 
-// one workgroup per token (ty, tx) of the 32 x 32 grid, one thread per channel: the block's voxels are walked in a fixed order (plane,
-// row, column), so the sum is deterministic; launches on one stream accumulate slab after slab
+// one workgroup per token (ty, tx) of the 32 x 32 grid; a thread owns four consecutive channels (16-byte loads) of every G-th voxel of the
+// token's block, G = 256 / (C / 4) voxel groups per workgroup; the groups' partial sums are added in group order through LDS, and a thread
+// walks its voxels in a fixed order (plane, row, column): the result is deterministic.  Launches on one stream accumulate slab after slab.
+__global__ __launch_bounds__(256) void k_pool3d_accum4(const float *__restrict__ act, int C, int H, int W, int nz, float *__restrict__ sums) {
+    __shared__ float4 part[256];
+    const int tok = blockIdx.x, ty = tok / 32, tx = tok % 32, bh = H / 32, bw = W / 32;
+    const int c4n = C / 4, G = 256 / c4n, c4 = threadIdx.x % c4n, grp = threadIdx.x / c4n;
+    const int nvox = nz * bh * bw;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grp < G)
+        for (int q = grp; q < nvox; q += G) {
+            const int j = q % bw, i = (q / bw) % bh, z = q / (bw * bh);
+            const float4 v = *reinterpret_cast<const float4 *>(act + (((size_t)z * H + ty * bh + i) * W + tx * bw + j) * C + 4 * c4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0) {
+        for (int k = 1; k < G; ++k) {
+            const float4 o = part[k * c4n + c4];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(sums + (size_t)tok * C + 4 * c4);
+        float4 cur = *dst;
+        cur.x += s.x; cur.y += s.y; cur.z += s.z; cur.w += s.w;
+        *dst = cur;
+    }
+}
+
+// generic channel counts: one thread per channel
 __global__ void k_pool3d_accum(const float *__restrict__ act, int C, int H, int W, int nz, float *__restrict__ sums) {
     const int tok = blockIdx.x, ty = tok / 32, tx = tok % 32, bh = H / 32, bw = W / 32;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -77,7 +105,10 @@ __global__ void k_pool3d_accum(const float *__restrict__ act, int C, int H, int 
 }
 
 hipError_t launch_pool3d_accum(const float *act, int C, int H, int W, int nz, float *sums, hipStream_t st) {
-    hipLaunchKernelGGL(k_pool3d_accum, dim3(1024), dim3(C < 256 ? C : 256), 0, st, act, C, H, W, nz, sums);
+    if (C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0)
+        hipLaunchKernelGGL(k_pool3d_accum4, dim3(1024), dim3(256), 0, st, act, C, H, W, nz, sums);
+    else
+        hipLaunchKernelGGL(k_pool3d_accum, dim3(1024), dim3(C < 256 ? C : 256), 0, st, act, C, H, W, nz, sums);
     return hipGetLastError();
 }
 

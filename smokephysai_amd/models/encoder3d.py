@@ -44,6 +44,7 @@ class HipEncoder3D:
         self._lin1i = HipLinear(w1i.reshape(64, 448).float(), b1.float(), device=self._dev)
         self._lin2 = HipLinear(w2.float(), b2.float(), device=self._dev)
         self.slab_bytes = int(slab_bytes)
+        self._bufs = {}
         # the activated conv2 slab is written by the GEMM and read back by the pooling launch right behind it: kept within the 256 MB
         # Infinity Cache it is read from there (512 x 512 planes: one plane per launch; measured 34.4 -> 29.8 ms per 64-plane volume)
         self.a2_bytes = int(a2_bytes)
@@ -51,6 +52,15 @@ class HipEncoder3D:
             raise ValueError("conv2_mode: 'implicit' (smk_conv3d_cl_forward / smk_conv3d_s7_forward, no patch matrix) or 'im2col' (explicit GEMM)")
         self.conv2_mode = conv2_mode
         self.conv1_mode = conv2_mode
+
+    def _buffer(self, name, shape):
+        """Activation buffers are kept between calls (a 512 x 512 x 64 volume's conv1 output is 4.3 GB: a fresh allocation per call costs
+        more than the convolution)."""
+        buf = self._bufs.get(name)
+        if buf is None or tuple(buf.shape) != tuple(shape):
+            self._bufs.pop(name, None)
+            buf = self._bufs[name] = torch.empty(*shape, device=self._dev)
+        return buf
 
     def _im2col(self, src, C, D, H, W, k, z0, nz, kpad):
         cols = torch.empty(nz * H * W, kpad, device=self._dev)
@@ -60,7 +70,7 @@ class HipEncoder3D:
     def conv1_activations(self, vol: torch.Tensor) -> torch.Tensor:
         """One volume [D, H, W] -> relu(bn1(conv1)) channels-last [D, H, W, 64]."""
         D, H, W = vol.shape
-        a1 = torch.empty(D, H, W, 64, device=self._dev)
+        a1 = self._buffer("a1", (D, H, W, 64))
         if self.conv1_mode == "implicit" and H <= 1023 and W <= 1023:
             nz = max(1, min(D, ((1 << 32) - 512) // (H * W * 4) - 6, 1000, ((1 << 31) - 512) // (H * W)))
             for z0 in range(0, D, nz):
@@ -102,7 +112,7 @@ class HipEncoder3D:
             for z0 in range(0, D, nz):
                 n = min(nz, D - z0)
                 if implicit:
-                    a2 = torch.empty(n * H * W, 128, device=self._dev)
+                    a2 = self._buffer("a2", (nz * H * W, 128))[:n * H * W]
                     _lib.check(self._L.smk_conv3d_cl_forward(self._lin2._handle, a1.data_ptr(), D, H, W, z0, n, a2.data_ptr(), 128,
                                                              _lib.SMK_ACT_RELU, _lib.stream_ptr(self._dev)))
                 else:
