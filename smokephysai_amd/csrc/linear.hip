@@ -559,7 +559,10 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
 //   and a staged 16-byte piece = 4 consecutive kx taps = 4 consecutive x of the input (one unaligned dwordx4 load); elements past the
 //   row's ends are zeroed by selects, window rows outside the volume by the out-of-range offset.  Waves whose 32 output columns lie
 //   beyond N (N = 64: two of four) stage their share of the tile and skip the MFMAs.
-template <int NW, int CONV = 0>
+//   R: depth of the weight ring in 32-k steps.  R = 2 requests step s+1 at the start of step s (768 matrix-pipe cycles ahead for the two
+//   waves of a SIMD: about an L2 round trip under load); R = 4 requests step s+3 (the chunk loop is unrolled twice so that the slots stay
+//   compile-time indices; needs an even number of 64-k chunks).
+template <int NW, int CONV = 0, int R = 2>
 __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int TM = 128, TN = NW * 32, RP = NW * 4, NP = TM / RP, PLANE = TM * 128;
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     const int lane_b = nw_ok ? (g >> 1) * (N * 64) + (ncol0 + l16) * 32 + (g & 1) * 16 : 0;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.l.wq), 0, K * N * 4, 0x00020000);
     const int step_bytes = N * 128, part_bytes = N * 32;     // one 32-k step = two k16 blocks x (hi | lo) planes of N x 32 bytes
-    uint4 bq[2][4];                                          // [ring slot = step parity][nb * 2 + part]
+    uint4 bq[R][4];                                          // [ring slot = 32-k step mod R][nb * 2 + part]
     auto load_b = [&](int slot, int kn) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -588,7 +591,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                 bq[slot][nb * 2 + part] = make_uint4(v[0], v[1], v[2], v[3]);
             }
     };
-    load_b(0, 0);
+#pragma unroll
+    for (int k = 0; k < R - 1; ++k) load_b(k, k < nks ? k : k - nks);
 
     // ---- token staging (as k_linear_x3, fp32 source): thread = float4 column sc of rows sr, sr + RP, ...
     const int sc = tid & 15, sr = tid >> 4;
@@ -697,7 +701,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     int buf = 0;
     load_a(0, 0, ahA, alA);
 
+#ifdef SMK_LN_STAMPS
+    unsigned long long sum_k = 0, sum_e = 0, ntl = 0;
+    LN_STAMP(t_begin);
+    LN_RSTAMP(r_begin);
+#endif
     for (; tm < a.tiles_m; tm += tm_step) {
+#ifdef SMK_LN_STAMPS
+        LN_STAMP(t_k0);
+#endif
         f32x4 acc[2][8];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -705,13 +717,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
             for (int t = 0; t < 8; ++t) acc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
-        for (int c = 0; c < nchunks; ++c) {
-            auto unit = [&](auto U) {
-                constexpr int u = decltype(U)::value, ks = u >> 1, h = u & 1;
-                if (h == 0) {                               // all four weight loads of the NEXT 32-k step, behind this step's first MFMAs
-                    int kn = c * 2 + ks + 1;
+        for (int c = 0; c < nchunks; c += R / 2) {
+            // PU = 4 * (chunk of this iteration: 0, or 1 with R = 4) + unit; cc = that chunk's index
+            auto unit = [&](auto PU, int cc) {
+                constexpr int pu = decltype(PU)::value, u = pu & 3, ks = u >> 1, h = u & 1, slot = (2 * (pu >> 2) + ks) % R;
+                if (h == 0) {                               // all four weight loads of 32-k step s + R - 1, behind this step's first MFMAs
+                    int kn = cc * 2 + ks + R - 1;
                     kn = kn >= nks ? kn - nks : kn;          // wraps: the next tile uses the same weights
-                    load_b(ks ^ 1, __builtin_amdgcn_readfirstlane(kn));
+                    load_b((slot + R - 1) % R, __builtin_amdgcn_readfirstlane(kn));
                 }
                 constexpr int P0 = (NP * 3 + 7) / 8, P1 = (NP * 6 + 7) / 8;
                 constexpr int pbeg = u == 0 ? 0 : u == 1 ? P0 : u == 2 ? P1 : NP, pend = u == 0 ? P0 : u == 1 ? P1 : NP;
@@ -727,8 +740,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                 bf16x8 wh[2], wl[2];
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    wh[nb] = __builtin_bit_cast(bf16x8, bq[ks][nb * 2]);
-                    wl[nb] = __builtin_bit_cast(bf16x8, bq[ks][nb * 2 + 1]);
+                    wh[nb] = __builtin_bit_cast(bf16x8, bq[slot][nb * 2]);
+                    wl[nb] = __builtin_bit_cast(bf16x8, bq[slot][nb * 2 + 1]);
                 }
                 // product-major: consecutive MFMAs go to different accumulators; each accumulator still sums hi*lo, lo*hi, hi*hi in order
                 if (CONV == 2 && !nw_ok) return;             // (a wave with no output columns: staging only)
@@ -765,13 +778,23 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            unit(std::integral_constant<int, 0>{});
-            unit(std::integral_constant<int, 1>{});
-            unit(std::integral_constant<int, 2>{});
-            unit(std::integral_constant<int, 3>{});
+            unit(std::integral_constant<int, 0>{}, c);
+            unit(std::integral_constant<int, 1>{}, c);
+            unit(std::integral_constant<int, 2>{}, c);
+            unit(std::integral_constant<int, 3>{}, c);
             buf ^= 1;
+            if constexpr (R == 4) {
+                unit(std::integral_constant<int, 4>{}, c + 1);
+                unit(std::integral_constant<int, 5>{}, c + 1);
+                unit(std::integral_constant<int, 6>{}, c + 1);
+                unit(std::integral_constant<int, 7>{}, c + 1);
+                buf ^= 1;
+            }
         }
 
+#ifdef SMK_LN_STAMPS
+        LN_STAMP(t_k1);
+#endif
         // ---- epilogue: acc[nb][t][i] = token row t*16 + l16, output column ncol0 + nb*16 + 4g + i
         if (nw_ok) {
             const int row0 = tm * TM, ncol = ncol0 + 4 * g;
@@ -828,14 +851,26 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                 }
             }
         }
+#ifdef SMK_LN_STAMPS
+        LN_STAMP(t_e);
+        sum_k += t_k1 - t_k0; sum_e += t_e - t_k1; ++ntl;
+#endif
     }
+#ifdef SMK_LN_STAMPS
+    LN_STAMP(t_end);
+    LN_RSTAMP(r_end);
+    if (a.stamps && lane == 0) {
+        unsigned long long *rec = a.stamps + (((size_t)blockIdx.x * NW + wave) & 4095) * 8;
+        rec[0] = sum_k; rec[1] = sum_e; rec[2] = t_end - t_begin; rec[3] = r_end - r_begin; rec[4] = ntl; rec[5] = 0; rec[6] = 0; rec[7] = 0;
+    }
+#endif
 }
 
-template <int NW, int CONV = 0>
+template <int NW, int CONV = 0, int R = 2>
 static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
     constexpr int lds = 4 * 128 * 128 + 1024;
-    once_per_device((const void *)k_linear_b16<NW, CONV>, [&] {
-        (void)hipFuncSetAttribute((const void *)k_linear_b16<NW, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    once_per_device((const void *)k_linear_b16<NW, CONV, R>, [&] {
+        (void)hipFuncSetAttribute((const void *)k_linear_b16<NW, CONV, R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const int nwg_max = (NW == 8 ? 1 : 2) * a.num_cu;        // 8 waves per CU either way
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
@@ -846,7 +881,7 @@ static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
     static int swz_env = -1;
     if (swz_env < 0) { const char *s = getenv("SMK_LINEAR_SWZ"); swz_env = s ? atoi(s) : 1; }
     b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
-    hipLaunchKernelGGL((k_linear_b16<NW, CONV>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
+    hipLaunchKernelGGL((k_linear_b16<NW, CONV, R>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
     return hipGetLastError();
 }
 
@@ -929,10 +964,12 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     // full 128-row tiles of fp32 activations: the 16x16x32-shape kernel (SMK_LINEAR_SHAPE=32 keeps the 32x32x16 one for A/B runs)
     static int shape_env = -1;
     if (shape_env < 0) { const char *s = getenv("SMK_LINEAR_SHAPE"); shape_env = s ? atoi(s) : 16; }
-    if (shape_env != 32 && mb == 4 && !c.x_split && !c.y_split && c.nseg == 1 && !a.stamps && !dbg && (!c.padd || c.rows_per_group % 128 == 0)) {
-        return nw == 8 ? launch_b16<8>(a, st) : launch_b16<4>(a, st);
-    }
-    if (c.x_split) {
+    if (shape_env != 32 && mb == 4 && !c.x_split && !c.y_split && c.nseg == 1 && !dbg && (!c.padd || c.rows_per_group % 128 == 0)) {
+        static int ring_env = -1;
+        if (ring_env < 0) { const char *s = getenv("SMK_LINEAR_RING"); ring_env = s ? atoi(s) : 4; }
+        if (ring_env == 4 && (l.K / 64) % 2 == 0 && l.K >= 128) e = nw == 8 ? launch_b16<8, 0, 4>(a, st) : launch_b16<4, 0, 4>(a, st);
+        else e = nw == 8 ? launch_b16<8>(a, st) : launch_b16<4>(a, st);
+    } else if (c.x_split) {
         if (nw == 8) e = launch_mb<4, 8, true>(a, st);
         else if (mb == 4) e = launch_mb<4, 4, true>(a, st);
         else if (mb == 2) e = launch_mb<2, 4, true>(a, st);
