@@ -345,3 +345,37 @@ def test_uneven_shards_run_equal_step_counts(tmp_path):
     res = torch.load(out)
     assert set(res["train"]) == {"total_loss", "recon_loss", "physics_loss", "chaos_loss"}
     assert all(np.isfinite(v) for v in res["train"].values())
+
+
+def _one_rank_worker(rank, port, out_path):
+    """A ONE-rank process group (gloo here; RCCL on the GPU box, tests/test_rccl_world1.py): init_distributed(force=True) must create it,
+    wrap_ddp(force=True) must wrap, and both exchange forms must leave the gradients exactly as the bare model computes them."""
+    import torch.distributed as dist
+    from smokephysai_amd.utils.distributed import ddp_bucket_report, init_distributed, wrap_ddp
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    assert init_distributed("gloo") == (0, 1, 0) and not dist.is_initialized()          # unforced: no group for one process
+    assert init_distributed("gloo", force=True) == (0, 1, 0) and dist.is_initialized() and dist.get_world_size() == 1
+    res = {}
+    for mode in ("bare", "rccl", "direct"):
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.GELU(), torch.nn.Linear(64, 8))
+        assert wrap_ddp(m, "cpu") is m                                                  # unforced: a one-rank group leaves the model bare
+        d = m if mode == "bare" else wrap_ddp(m, "cpu", grad_exchange=mode, force=True)
+        if mode != "bare":
+            assert isinstance(d, torch.nn.parallel.DistributedDataParallel) and ddp_bucket_report(d)["world_size"] == 1
+        x = torch.randn(16, 32, generator=torch.Generator().manual_seed(5))
+        d(x).square().mean().backward()
+        res[mode] = torch.cat([p.grad.flatten() for p in m.parameters()])
+    dist.destroy_process_group()
+    torch.save({k: v for k, v in res.items()}, out_path)
+
+
+def test_forced_one_rank_group_wraps_and_changes_nothing(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "one_rank.pt")
+    mp.spawn(_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["rccl"], res["bare"]) and torch.equal(res["direct"], res["bare"]) and float(res["bare"].abs().sum()) > 0
