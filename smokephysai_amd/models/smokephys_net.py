@@ -281,14 +281,19 @@ class SmokePhysNet(nn.Module):
                 encoder_dtype: Optional[str] = None) -> dict:
         """x: [B,1,H,W].  chaos_noise (optional): [num_layers,3,B,1] standard-normal draws replacing the reference's
         in-forward torch.randn (chaos_attention.py:50-52) so results can be pinned."""
-        B = x.shape[0]
-        pool_size = 32
         dt = encoder_dtype or self.encoder_dtype
         if self._encoder_route(x) == "hip" and dt in ("bf16x3", "bf16"):
             # the bf16 MFMA kernels write the token-major layout feature_proj consumes (smokephys_net.py:95) directly
             flattened = self.hip_encoder().tokens(x, input_dim=self.input_dim, dtype=dt)
         else:
             flattened = self.encode_frames(x, encoder_dtype).flatten(2).transpose(1, 2)
+        return self.forward_tokens(flattened, return_features, chaos_noise)
+
+    def forward_tokens(self, flattened: torch.Tensor, return_features: bool = False, chaos_noise: Optional[torch.Tensor] = None) -> dict:
+        """Everything behind the encoder (smokephys_net.py:95-122): tokens [B, 1024, input_channels] -> the forward's result dict.
+        forward() ends here; forward_volumes() enters here with the 3-D encoder's tokens."""
+        B = flattened.shape[0]
+        pool_size = 32
         if self._hip_body_ok(flattened):
             features, output_features = self._body_hip(flattened.contiguous(), chaos_noise, pool_size)
         else:
@@ -310,6 +315,12 @@ class SmokePhysNet(nn.Module):
         if return_features:
             results["intermediate_features"] = features
         return results
+
+    def forward_volumes(self, volumes: torch.Tensor, encoder3d, return_features: bool = False,
+                        chaos_noise: Optional[torch.Tensor] = None) -> dict:
+        """BASELINE configs[4]: volumes [B, 1, D, H, W] through the 3-D encoder (models/encoder3d.HipEncoder3D, SPEC_3D.md section 8: the
+        depth axis is pooled to 1, so it emits the [B, 1024, 128] tokens the 2-D encoder emits) and then the unchanged network."""
+        return self.forward_tokens(encoder3d.tokens(volumes), return_features, chaos_noise)
 
 
 class ChaosTransformerLayer(nn.Module):

@@ -83,3 +83,27 @@ def test_loud_failures():
         enc(torch.zeros(1, 2, 4, 32, 32, device="cuda"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         HipEncoder3D({k: torch.from_numpy(v) for k, v in _weights().items()}, device="cpu")
+
+
+def test_full_network_on_volumes():
+    """configs[4] end to end: volumes [B, 1, D, H, W] -> HipEncoder3D tokens -> the unchanged SmokePhysNet body and heads
+    (SmokePhysNet.forward_volumes).  The 3-D encoder emits the tensor the 2-D encoder emits, so the result must equal forward_tokens on
+    those tokens, and the libsmokehip body must stay within 1e-4 of the PyTorch-ROCm fp32 body on them."""
+    from smokephysai_amd.models import SmokePhysNet
+    torch.manual_seed(0)
+    model = SmokePhysNet().cuda().eval()
+    enc = HipEncoder3D({k: torch.from_numpy(v) for k, v in _weights(3).items()})
+    g = torch.Generator(device="cuda").manual_seed(1)
+    vol = torch.rand(2, 1, 4, 64, 32, device="cuda", generator=g)
+    noise = torch.randn(len(model.chaos_layers), 3, 2, 1, device="cuda", generator=g)
+    with torch.no_grad():
+        out = model.forward_volumes(vol, enc, chaos_noise=noise)
+        tok = enc.tokens(vol)
+        same = model.forward_tokens(tok, chaos_noise=noise)
+        model.linear_dtype = "f32"
+        ref = model.forward_tokens(tok, chaos_noise=noise)
+        model.linear_dtype = "bf16x3"
+    assert out["reconstructed"].shape == (2, 1, 128, 128) and out["physics_features"].shape == (2, 3)
+    for k in ref:
+        assert torch.equal(out[k], same[k]), k
+        assert rel_err(out[k].cpu().numpy(), ref[k].cpu().numpy()) < 1e-4, k
