@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 10
+#define SMK_ABI_VERSION 11
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -317,6 +317,13 @@ int smk_conv3d_cl_forward(smk_linear *lin, const float *src, int32_t D, int32_t 
  * >= 49 zero); output rows = the voxels of planes z0 .. z0+nz-1, y [nz*H*W][ldy].  H, W <= 1023; (nz + 6) * H * W * 4 < 2^32. */
 int smk_conv3d_s7_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
                           int32_t activation, void *stream);
+/* The same Conv3d(64 -> 128, kernel 3, padding 1) + bias + activation (SMK_ACT_NONE or SMK_ACT_RELU) of a whole volume, fused with the DEPTH
+ * half of the token pooling (SPEC_3D.md section 8 pools the depth axis to 1): zsum [H][W][128] = sum over z of act(conv(src)[z] + bias), planes
+ * added in z order (deterministic).  A workgroup marches an 8 x 16 column of voxels along z with three planes of its halo tile in LDS, so
+ * every voxel is staged once per plane instead of once per tap, and the activated convolution output is never written; follow with
+ * smk_pool3d_accumulate(zsum, 128, H, W, 1, sums).  `lin` as for smk_conv3d_cl_forward with out_features = 128; H % 8 == 0, W % 16 == 0,
+ * H * W * 256 < 2^31. */
+int smk_conv3d_cl_zsum_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, float *zsum, int32_t activation, void *stream);
 
 /* ChaosAttention.generate_chaos_field's five explicit-Euler Lorenz states (chaos_attention.py:39-59) for noise [3][B] (the three
  * randn(B,1) draws before the 0.1 scale): states [B][5][3].  The gradient-free part of the chaos term, for the training path. */

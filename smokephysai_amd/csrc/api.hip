@@ -984,6 +984,18 @@ int smk_conv3d_cl_forward(smk_linear *lin, const float *src, int32_t D, int32_t 
                                              (hipStream_t)stream), "conv3d_cl_b16");
 }
 
+int smk_conv3d_cl_zsum_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, float *zsum, int32_t activation, void *stream) {
+    SMK_REQUIRE(lin && src && zsum, "null lin/src/zsum");
+    SMK_REQUIRE(lin->l.K == 27 * 64 && lin->l.N == 128, "the layer handle must be 27 * 64 -> 128 (3 x 3 x 3 taps of 64 channels, 128 outputs)");
+    SMK_REQUIRE(D >= 1 && H >= 8 && W >= 16 && H % 8 == 0 && W % 16 == 0, "H must be a multiple of 8 and W of 16 (the 8 x 16 voxel column a workgroup marches)");
+    SMK_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)zsum & 15) == 0, "16-byte aligned src / zsum");
+    SMK_REQUIRE((int64_t)H * W * 256 < (1LL << 31), "a plane must stay below 2^31 bytes (32-bit offsets within a plane)");
+    SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_RELU, "activation: none or ReLU");
+    DeviceGuard guard(lin->device);
+    if (guard.rc) return guard.rc;
+    return check_launch(launch_conv3d_march(lin->l, src, D, H, W, zsum, activation, (hipStream_t)stream), "conv3d_march");
+}
+
 int smk_conv3d_s7_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
                           int32_t activation, void *stream) {
     SMK_REQUIRE(lin && src && y, "null lin/src/y");

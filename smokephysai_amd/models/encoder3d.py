@@ -22,7 +22,7 @@ _KEYS = ("conv1_w", "conv1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
 
 
 class HipEncoder3D:
-    def __init__(self, weights: dict, device="cuda", eps: float = 1e-5, slab_bytes: int = 2 << 30, conv2_mode: str = "implicit",
+    def __init__(self, weights: dict, device="cuda", eps: float = 1e-5, slab_bytes: int = 2 << 30, conv2_mode: str = "march",
                  a2_bytes: int = 128 << 20):
         self._dev = _lib.require_cuda(device, "HipEncoder3D")
         self._L = _lib.load()
@@ -48,10 +48,11 @@ class HipEncoder3D:
         # the activated conv2 slab is written by the GEMM and read back by the pooling launch right behind it: kept within the 256 MB
         # Infinity Cache it is read from there (512 x 512 planes: one plane per launch; measured 34.4 -> 29.8 ms per 64-plane volume)
         self.a2_bytes = int(a2_bytes)
-        if conv2_mode not in ("implicit", "im2col"):
-            raise ValueError("conv2_mode: 'implicit' (smk_conv3d_cl_forward / smk_conv3d_s7_forward, no patch matrix) or 'im2col' (explicit GEMM)")
+        if conv2_mode not in ("march", "implicit", "im2col"):
+            raise ValueError("conv2_mode: 'march' (smk_conv3d_cl_zsum_forward: conv2 marched along z with its input planes in LDS, depth pooling "
+                             "fused), 'implicit' (smk_conv3d_cl_forward: implicit GEMM, no patch matrix) or 'im2col' (explicit GEMM)")
         self.conv2_mode = conv2_mode
-        self.conv1_mode = conv2_mode
+        self.conv1_mode = "im2col" if conv2_mode == "im2col" else "implicit"
 
     def _buffer(self, name, shape):
         """Activation buffers are kept between calls (a 512 x 512 x 64 volume's conv1 output is 4.3 GB: a fresh allocation per call costs
@@ -100,7 +101,8 @@ class HipEncoder3D:
                 raise ValueError("HipEncoder3D: H and W must be 32, 64 or a multiple of 128 (the two adaptive pools then compose to a "
                                  "uniform block mean)")
         out = torch.empty(B, 128, 32, 32, device=self._dev)
-        implicit = self.conv2_mode == "implicit"
+        march = self.conv2_mode == "march" and H * W * 256 < (1 << 31)           # (H % 8, W % 16 hold: multiples of 32)
+        implicit = self.conv2_mode == "implicit" or (self.conv2_mode == "march" and not march)
         # implicit GEMM: no patch matrix; a slab is bounded by the activated output it materialises and by 32-bit offsets into a1
         if implicit:
             nz = max(1, min(D, min(self.slab_bytes, self.a2_bytes) // (H * W * 128 * 4), ((1 << 32) - 512) // (H * W * 256) - 2))
@@ -109,7 +111,12 @@ class HipEncoder3D:
         for b in range(B):
             a1 = self.conv1_activations(x[b])
             sums = torch.zeros(1024, 128, device=self._dev)
-            for z0 in range(0, D, nz):
+            if march:
+                zsum = self._buffer("zsum", (H * W, 128))
+                _lib.check(self._L.smk_conv3d_cl_zsum_forward(self._lin2._handle, a1.data_ptr(), D, H, W, zsum.data_ptr(), _lib.SMK_ACT_RELU,
+                                                              _lib.stream_ptr(self._dev)))
+                _lib.check(self._L.smk_pool3d_accumulate(zsum.data_ptr(), 128, H, W, 1, sums.data_ptr(), _lib.stream_ptr(self._dev)))
+            for z0 in range(0, D, nz) if not march else ():
                 n = min(nz, D - z0)
                 if implicit:
                     a2 = self._buffer("a2", (nz * H * W, 128))[:n * H * W]

@@ -73,6 +73,35 @@ def test_features_vs_oracle(shape, slab):
     # which the pooled partial sums are added, differ
     ex = HipEncoder3D({k: torch.from_numpy(v) for k, v in w.items()}, slab_bytes=slab, conv2_mode="im2col")
     assert rel_err(ex(x).cpu().numpy(), got) < 1e-6
+    # ... and the implicit-GEMM form on the layer kernel (the default is the z-marching kernel with the depth pooling fused)
+    im = HipEncoder3D({k: torch.from_numpy(v) for k, v in w.items()}, slab_bytes=slab, conv2_mode="implicit")
+    assert enc.conv2_mode == "march"
+    assert rel_err(im(x).cpu().numpy(), got) < 1e-6
+
+
+@pytest.mark.parametrize("D", [1, 2, 5])
+def test_march_kernel_depth_edges_and_zsum(D):
+    """smk_conv3d_cl_zsum_forward alone, against the fp64 oracle's conv2 on the same (random, signed) channels-last input: depths 1 and 2
+    (planes z-1 / z+1 / z+2 of the ring outside the volume), walls in x and y on every tile, no activation and ReLU."""
+    from oracle.encoder3d import conv3d
+    from smokephysai_amd import _lib
+    from smokephysai_amd.models.linear import HipLinear
+    rng = np.random.RandomState(D)
+    H, W = 16, 48
+    a1 = rng.randn(D, H, W, 64).astype(np.float32)
+    w2 = (rng.randn(128, 64, 3, 3, 3) * 0.05).astype(np.float32)
+    b2 = rng.randn(128).astype(np.float32)
+    lin = HipLinear(torch.from_numpy(w2).permute(0, 2, 3, 4, 1).reshape(128, 1728).contiguous(), torch.from_numpy(b2), device="cuda")
+    L = _lib.load()
+    src = torch.from_numpy(a1).cuda()
+    ref = conv3d(np.moveaxis(a1, -1, 0).astype(np.float64), w2.astype(np.float64), b2.astype(np.float64), 1)      # [128, D, H, W]
+    for act, f in ((_lib.SMK_ACT_NONE, lambda t: t), (_lib.SMK_ACT_RELU, lambda t: np.maximum(t, 0.0))):
+        zsum = torch.full((H, W, 128), float("nan"), device="cuda")
+        _lib.check(L.smk_conv3d_cl_zsum_forward(lin._handle, src.data_ptr(), D, H, W, zsum.data_ptr(), act, _lib.stream_ptr(src.device)))
+        want = np.moveaxis(f(ref).sum(axis=1), 0, -1)                 # [H, W, 128]
+        assert rel_err(zsum.cpu().numpy(), want) < 1e-5, (D, act)
+    with pytest.raises(RuntimeError):
+        _lib.check(L.smk_conv3d_cl_zsum_forward(lin._handle, src.data_ptr(), D, 12, W, zsum.data_ptr(), 0, _lib.stream_ptr(src.device)))
 
 
 def test_loud_failures():
