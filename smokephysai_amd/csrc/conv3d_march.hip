@@ -17,6 +17,7 @@
 // Arithmetic: the split-bf16 x3 form (lo*hi + hi*lo + hi*hi, fp32 accumulation), taps in the order (kz, ky, kx) -- as the layer kernel.
 #include "conv3d.h"
 #include "linear.h"
+#include <type_traits>
 
 namespace smk {
 
@@ -30,20 +31,39 @@ constexpr int M3_SLOT = 2 * M3_PART, M3_LDS = 3 * M3_SLOT;    // hi | lo; three 
 constexpr int M3_ITEMS = M3_APIX * 8, M3_NIT = (M3_ITEMS + 255) / 256;      // staging item = (voxel, group of 8 channels): 1,440 -> 6 per thread
 constexpr unsigned M3_OOB = 0x80000000u;                      // an offset past every plane's range: the buffer load returns zeros
 
+#ifdef SMK_M3_STAMPS      /* diagnostic build only (tools/README.md): s_memtime phase stamps of wave 0 into a debug buffer */
+#define M3_STAMP(v) unsigned long long v; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define M3_RSTAMP(v) unsigned long long v; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define M3_STAMP_ARG , unsigned long long *stamps
+#else
+#define M3_STAMP(v)
+#define M3_RSTAMP(v)
+#define M3_STAMP_ARG
+#endif
+
+#ifndef M3_RD_EVERY
+#define M3_RD_EVERY 2         /* the next unit's 8 fragment reads: one per this many MFMAs from the unit's start (one wave per SIMD: LDS latency is exposed) */
+#endif
+#ifndef M3_AHEAD
+#define M3_AHEAD 3            /* 32-k steps between a weight fragment's request and its use (ring of 6 slots) */
+#endif
 __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict__ a1, int D, int H, int W, const unsigned short *__restrict__ wq,
                                                          const float *__restrict__ bias, float *__restrict__ zsum, int tiles_x, int ntiles,
-                                                         int relu) {
+                                                         int relu M3_STAMP_ARG) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int AH = M3_AHEAD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, kg = lane >> 4;
     const int o0 = wave * 32 + px;                                            // N tile 0; tile 1 = + 16
     const float b2a = bias[o0], b2b = bias[o0 + 16];
 
-    // ---- weight ring (k_linear_b16's addressing with N = 128): 32-k step ks = tap * 2 + half; four 16-byte loads per lane and step
+    // ---- weight ring (k_linear_b16's addressing with N = 128): 32-k step ks = tap * 2 + half, 54 per plane; four 16-byte loads per lane and
+    //      step.  Six slots = the six k-steps of a body (three taps), so slot indices are compile-time; a fragment is requested AH steps early
+    //      (one wave per SIMD: nobody else covers an L2 round trip, and the waits also cover the plane loads issued before them)
     const int lane_b = (kg >> 1) * (128 * 64) + o0 * 32 + (kg & 1) * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(wq), 0, 27 * 64 * 128 * 4, 0x00020000);
-    uint4 bq[2][2][2];                                                        // [slot][nt][hi | lo]
+    uint4 bq[6][2][2];                                                        // [slot][nt][hi | lo]
     auto load_b = [&](int slot, int kn) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -53,10 +73,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
                 bq[slot][nt][part] = make_uint4(v[0], v[1], v[2], v[3]);
             }
     };
-    load_b(0, 0);
+#pragma unroll
+    for (int k = 0; k < AH; ++k) load_b(k, k);
 
     const unsigned plane_bytes = (unsigned)H * (unsigned)W * 256u;
     const int c16[2] = {kg << 4, (4 + kg) << 4};
+#ifdef SMK_M3_STAMPS
+    unsigned long long sm[6] = {0, 0, 0, 0, 0, 0};
+    M3_STAMP(t_begin);
+    M3_RSTAMP(r_begin);
+#endif
 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
@@ -64,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
 
         // ---- this thread's staging items: voxel p of the halo tile, channel group g (32 bytes of the voxel's 256)
         unsigned goff[M3_NIT];
-        int loff[M3_NIT];
+        int loff0[M3_NIT];
 #pragma unroll
         for (int j = 0; j < M3_NIT; ++j) {
             int idx = tid + 256 * j;
@@ -73,8 +99,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
             const int ii = r0 - 1 + row, jj = c0 - 1 + pc;
             const bool in = ii >= 0 && ii < H && jj >= 0 && jj < W;
             goff[j] = in ? (unsigned)(ii * W + jj) * 256u + (unsigned)g * 32u : M3_OOB;
-            loff[j] = p * 128 + ((g ^ (p & 7)) << 4);
+            loff0[j] = p * 128 + ((g ^ (p & 7)) << 4);
         }
+        const bool last_item = tid + 256 * (M3_NIT - 1) < M3_ITEMS;           // the sixth item exists for 160 of the 256 threads
         float v[M3_NIT][8];
         auto stage_load = [&](int z) {
             if (z >= 0 && z < D) {
@@ -97,26 +124,26 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
                     for (int c = 0; c < 8; ++c) v[j][c] = 0.f;
             }
         };
-        auto stage_store = [&](int slot) {
-            unsigned char *base = smem + slot * M3_SLOT;
+        auto store_item = [&](unsigned char *base, const float (&x)[8], int off, bool ok) {
+            m3_bf16x8 vh, vl;
 #pragma unroll
-            for (int j = 0; j < M3_NIT; ++j)
-                if (tid + 256 * j < M3_ITEMS) {
-                    m3_bf16x8 vh, vl;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const __bf16 h = (__bf16)v[j][c];
-                        vh[c] = h;
-                        vl[c] = (__bf16)(v[j][c] - (float)h);
-                    }
-                    *reinterpret_cast<m3_bf16x8 *>(base + loff[j]) = vh;
-                    *reinterpret_cast<m3_bf16x8 *>(base + M3_PART + loff[j]) = vl;
-                }
+            for (int c = 0; c < 8; ++c) {
+                const __bf16 h = (__bf16)x[c];
+                vh[c] = h;
+                vl[c] = (__bf16)(x[c] - (float)h);
+            }
+            if (ok) {
+                *reinterpret_cast<m3_bf16x8 *>(base + off) = vh;
+                *reinterpret_cast<m3_bf16x8 *>(base + M3_PART + off) = vl;
+            }
         };
         // planes -1 (zeros), 0, 1 -> slots 0, 1, 2
-        stage_load(-1); stage_store(0);
-        stage_load(0);  stage_store(1);
-        stage_load(1);  stage_store(2);
+#pragma unroll
+        for (int pz = -1; pz < 2; ++pz) {
+            stage_load(pz);
+#pragma unroll
+            for (int j = 0; j < M3_NIT; ++j) store_item(smem + (pz + 1) * M3_SLOT, v[j], loff0[j], j < M3_NIT - 1 || last_item);
+        }
         __syncthreads();
 
         m3_f32x4 zs[8][2];
@@ -125,63 +152,63 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) zs[mt][nt] = m3_f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // A addressing (k_encoder_b16): halo voxel p = (mt + ki) * 18 + px + kj, unit = g ^ (p & 7), p & 7 = (px + kj + 2 (mt + ki)) & 7
+        auto tap_consts = [&](int ki, int kj, int (&om)[4]) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) om[m] = ((px + kj) << 7) ^ (((px + kj + 2 * (m + ki)) & 7) << 4);
+        };
+        auto load_a = [&](int sbase, int ki, int half, int hm, const int (&om)[4], m3_bf16x8 (&ah)[4], m3_bf16x8 (&al)[4]) {
+            const unsigned char *ph = smem + sbase + ki * (M3_AW * 128);                         // wave-uniform part
+            // the lo fragments first: a unit's first eight MFMAs are the lo * hi products
+#pragma unroll
+            for (int m = 0; m < 4; ++m) al[m] = *reinterpret_cast<const m3_bf16x8 *>(ph + M3_PART + (om[m] ^ c16[half]) + (4 * hm + m) * (M3_AW * 128));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ah[m] = *reinterpret_cast<const m3_bf16x8 *>(ph + (om[m] ^ c16[half]) + (4 * hm + m) * (M3_AW * 128));
+        };
+        m3_bf16x8 ahA[4], alA[4], ahB[4], alB[4];
+        int om[4];
         int s0 = 0;                                                           // slot of plane z - 1
+        tap_consts(0, 0, om);
+        load_a(0, 0, 0, 0, om, ahA, alA);                                     // (kz, ki, kj) = (0, 0, 0) of plane 0's outputs
+
 #pragma unroll 1
         for (int z = 0; z < D; ++z) {
-            stage_load(z + 2);                                                // lands under the tap loop
+            M3_STAMP(t0);
+            stage_load(z + 2);                                                // lands under the first taps; stored from (kz = 1, ki = 0) on
+            M3_STAMP(t1);
 
-            m3_f32x4 acc[8][2];
+            m3_f32x4 acc[8][2];                                               // starts at the bias
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = m3_f32x4{0.f, 0.f, 0.f, 0.f};
-
-            // A addressing (k_encoder_b16): halo voxel p = (mt + ki) * 18 + px + kj, unit = g ^ (p & 7), p & 7 = (px + kj + 2 (mt + ki)) & 7
-            auto tap_consts = [&](int ki, int kj, int (&om)[4]) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) om[m] = ((px + kj) << 7) ^ (((px + kj + 2 * (m + ki)) & 7) << 4);
-            };
-            auto load_a = [&](int sbase, int ki, int half, int hm, const int (&om)[4], m3_bf16x8 (&ah)[4], m3_bf16x8 (&al)[4]) {
-                const unsigned char *ph = smem + sbase + ki * (M3_AW * 128);                     // wave-uniform part
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int off = (om[m] ^ c16[half]) + (4 * hm + m) * (M3_AW * 128);
-                    ah[m] = *reinterpret_cast<const m3_bf16x8 *>(ph + off);
-                    al[m] = *reinterpret_cast<const m3_bf16x8 *>(ph + M3_PART + off);
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float bb = nt ? b2b : b2a;
+                    acc[mt][nt] = m3_f32x4{bb, bb, bb, bb};
                 }
-            };
-            m3_bf16x8 ahA[4], alA[4], ahB[4], alB[4];
-            int om[4];
-            int kz = 0, ki = 0, kj = 0, sbase = s0 * M3_SLOT;
-            tap_consts(0, 0, om);
-            load_a(sbase, 0, 0, 0, om, ahA, alA);
-#pragma unroll 1
-            for (int tap = 0; tap < 27; ++tap) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int half = u >> 1, hm = u & 1, slot = half;
-                    if (hm == 0) {                             // k-step ks + 1 into the other slot, at the k-step's start (wraps to the next plane's step 0)
-                        int kn = tap * 2 + half + 1;
+            unsigned char *const wr_base = smem + s0 * M3_SLOT;               // plane z + 2 replaces plane z - 1
+
+            // one body = the three taps kj = 0, 1, 2 of (kz, ki): 12 units of 24 MFMAs, 6 k-steps.  STORE: one staging item of plane z + 2 is
+            // split and written under the MFMAs of the body's fifth unit.
+            auto body = [&](auto STORE_T, int it, int sbase, int ki, int sbase_n, int ki_n) {
+                constexpr int SJ = decltype(STORE_T)::value;                  // staging item stored under this body, or -1
+                constexpr bool STORE = SJ >= 0;
+                auto unit = [&](auto PU) {
+                    constexpr int pu = decltype(PU)::value, kj = pu >> 2, u = pu & 3, half = u >> 1, hm = u & 1, q = 2 * kj + half;
+                    if (hm == 0) {                             // k-step ks + AH, at this k-step's start (wraps into the next plane's steps)
+                        int kn = it * 6 + q + AH;
                         kn = kn >= 54 ? kn - 54 : kn;
-                        load_b(slot ^ 1, __builtin_amdgcn_readfirstlane(kn));
+                        load_b((q + AH) % 6, __builtin_amdgcn_readfirstlane(kn));
                     }
-                    if (u < 3) {
-                        if (u & 1) load_a(sbase, ki, (u + 1) >> 1, (u + 1) & 1, om, ahA, alA);
-                        else load_a(sbase, ki, (u + 1) >> 1, (u + 1) & 1, om, ahB, alB);
-                    } else if (tap < 26) {                     // first unit of the next tap (u = 3 is odd: set A)
-                        kj = kj == 2 ? 0 : kj + 1;
-                        if (kj == 0) {
-                            ki = ki == 2 ? 0 : ki + 1;
-                            if (ki == 0) {
-                                ++kz;
-                                int s = s0 + kz;
-                                s = s >= 3 ? s - 3 : s;
-                                sbase = __builtin_amdgcn_readfirstlane(s * M3_SLOT);
-                            }
-                        }
-                        tap_consts(ki, kj, om);
-                        load_a(sbase, ki, 0, 0, om, ahA, alA);
+                    if (pu < 11) {
+                        constexpr int nu = (pu + 1) & 3, nkj = (pu + 1) >> 2;
+                        if (nu == 0) tap_consts(ki, nkj, om);
+                        if (pu & 1) load_a(sbase, ki, nu >> 1, nu & 1, om, ahA, alA);
+                        else load_a(sbase, ki, nu >> 1, nu & 1, om, ahB, alB);
+                    } else {                                   // the next body's first unit (pu = 11 is odd: set A); past tap 26: the next plane's
+                        tap_consts(ki_n, 0, om);
+                        load_a(sbase_n, ki_n, 0, 0, om, ahA, alA);
                     }
+                    if constexpr (SJ >= 0 && pu == 4) store_item(wr_base, v[SJ], loff0[SJ], SJ < M3_NIT - 1 || last_item);
                     // product-major: consecutive MFMAs go to different accumulators; each accumulator sums lo*hi, hi*lo, hi*hi in that order
 #pragma unroll
                     for (int pr = 0; pr < 3; ++pr)
@@ -189,24 +216,54 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
                         for (int m = 0; m < 4; ++m)
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt) {
-                                const m3_bf16x8 bh = __builtin_bit_cast(m3_bf16x8, bq[slot][nt][0]);
-                                const m3_bf16x8 bl = __builtin_bit_cast(m3_bf16x8, bq[slot][nt][1]);
+                                const m3_bf16x8 bh = __builtin_bit_cast(m3_bf16x8, bq[q][nt][0]);
+                                const m3_bf16x8 bl = __builtin_bit_cast(m3_bf16x8, bq[q][nt][1]);
                                 m3_f32x4 &c = acc[4 * hm + m][nt];
-                                const m3_bf16x8 ah = (u & 1) ? ahB[m] : ahA[m], al = (u & 1) ? alB[m] : alA[m];
+                                const m3_bf16x8 ah = (pu & 1) ? ahB[m] : ahA[m], al = (pu & 1) ? alB[m] : alA[m];
                                 if (pr == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
                                 else if (pr == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
                                 else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
                             }
-                    // 24 MFMAs: the next unit's 8 fragment reads one per third MFMA, the k-step's 4 weight loads behind its first MFMAs
+                    // 24 MFMAs: the next unit's 8 fragment reads early in the unit, the k-step's 4 weight loads between them; a
+                    // staged item's split arithmetic (about 3 vector instructions per value) spread over the gaps, its two writes at the end
 #pragma unroll
                     for (int i = 0; i < 24; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        else if (hm == 0 && (i == 1 || i == 2 || i == 4 || i == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        if (i % M3_RD_EVERY == 0 && i / M3_RD_EVERY < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        else if (hm == 0 && (i == 1 || i == 3 || i == 5 || i == 7)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        if (STORE && pu == 4) {
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                            if (i == 23) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
+                };
+                unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{}); unit(std::integral_constant<int, 2>{});
+                unit(std::integral_constant<int, 3>{}); unit(std::integral_constant<int, 4>{}); unit(std::integral_constant<int, 5>{});
+                unit(std::integral_constant<int, 6>{}); unit(std::integral_constant<int, 7>{}); unit(std::integral_constant<int, 8>{});
+                unit(std::integral_constant<int, 9>{}); unit(std::integral_constant<int, 10>{}); unit(std::integral_constant<int, 11>{});
+            };
+            const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;  // slots of planes z, z + 1
+            // kz = 0: plane z - 1, still being read -- no stores
+#pragma unroll 1
+            for (int ki = 0; ki < 3; ++ki) {
+                const int ki_n = ki == 2 ? 0 : ki + 1;
+                const int sb_n = __builtin_amdgcn_readfirstlane((ki == 2 ? s1 : s0) * M3_SLOT);
+                body(std::integral_constant<int, -1>{}, ki, s0 * M3_SLOT, ki, sb_n, ki_n);
             }
+            M3_STAMP(t2);
+            __syncthreads();                                   // every wave is done with plane z - 1; the stores of plane z + 1 (previous step) are visible
+            M3_STAMP(t3);
+            // kz = 1, 2: planes z, z + 1; the six items of plane z + 2 go into plane z - 1's slot, one per body (unrolled: the item is a
+            // compile-time register set -- a rotating one made hipcc copy the loaded registers, i.e. wait for HBM, right behind the loads)
+            const int b1 = s1 * M3_SLOT, b2 = s2 * M3_SLOT;
+            body(std::integral_constant<int, 0>{}, 3, b1, 0, b1, 1);
+            body(std::integral_constant<int, 1>{}, 4, b1, 1, b1, 2);
+            body(std::integral_constant<int, 2>{}, 5, b1, 2, b2, 0);
+            body(std::integral_constant<int, 3>{}, 6, b2, 0, b2, 1);
+            body(std::integral_constant<int, 4>{}, 7, b2, 1, b2, 2);
+            body(std::integral_constant<int, 5>{}, 8, b2, 2, b1, 0);           // after tap 26: plane z, the next output plane's first input
+            M3_STAMP(t4);
 
             // ---- this plane's activations into the depth sums.  Lane: channel o0 (nt 0) / o0 + 16 (nt 1), voxels (row mt, columns 4 kg .. 4 kg + 3)
 #pragma unroll
@@ -215,15 +272,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float y = acc[mt][nt][i] + (nt ? b2b : b2a);
+                        float y = acc[mt][nt][i];
                         y = (relu && !(y > 0.f)) ? 0.f : y;
                         zs[mt][nt][i] += y;
                     }
-
-            __syncthreads();                                   // every wave is done with plane z - 1
-            stage_store(s0);                                   // plane z + 2 (zeros past the volume) takes its slot
-            __syncthreads();
-            s0 = s0 == 2 ? 0 : s0 + 1;
+            s0 = s1;
+#ifdef SMK_M3_STAMPS
+            M3_STAMP(t5);
+            sm[0] += t1 - t0; sm[1] += t2 - t1; sm[2] += t3 - t2; sm[3] += t4 - t3; sm[4] += t5 - t4;
+#endif
         }
 
 #pragma unroll
@@ -233,7 +290,17 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     zsum[((size_t)(r0 + mt) * W + c0 + 4 * kg + i) * 128 + o0 + 16 * nt] = zs[mt][nt][i];
+        __syncthreads();                                       // the next tile's prologue rewrites every slot
     }
+#ifdef SMK_M3_STAMPS
+    M3_STAMP(t_end);
+    M3_RSTAMP(r_end);
+    if (stamps && tid == 0) {
+        unsigned long long *rec = stamps + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) rec[i] = sm[i];
+        rec[6] = t_end - t_begin; rec[7] = r_end - r_begin;
+    }
+#endif
 }
 
 hipError_t launch_conv3d_march(const LinearDev &l, const float *a1, int D, int H, int W, float *zsum, int act, hipStream_t st) {
@@ -245,8 +312,26 @@ hipError_t launch_conv3d_march(const LinearDev &l, const float *a1, int D, int H
     });
     const int tiles_x = W / M3_TW, ntiles = tiles_x * (H / M3_TH);
     const int ncu = device_num_cu();
+#ifdef SMK_M3_STAMPS
+    static unsigned long long *stamps = nullptr;
+    if (!stamps) (void)hipMalloc(&stamps, 1024 * 8 * sizeof(unsigned long long));
+    const int nwg = ntiles < ncu ? ntiles : ncu;
+    hipLaunchKernelGGL(k_conv3d_march, dim3(nwg), dim3(256), M3_LDS, st, a1, D, H, W, l.wq, l.bias, zsum, tiles_x, ntiles, act == 2 ? 1 : 0, stamps);
+    if (getenv("SMK_M3_STAMPS_PRINT")) {
+        static unsigned long long host[1024 * 8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(host, stamps, (size_t)nwg * 64, hipMemcpyDeviceToHost);
+        double s[8] = {0};
+        for (int w = 0; w < nwg; ++w)
+            for (int i = 0; i < 8; ++i) s[i] += (double)host[w * 8 + i] / nwg;
+        const double steps = (double)D * ((ntiles + nwg - 1) / nwg);
+        fprintf(stderr, "m3 stamps (cycles per z step, wave 0): load-issue %.0f  taps kz0 %.0f  barrier %.0f  taps kz1,2 %.0f  epilogue %.0f  (-) %.0f | kernel %.0f cycles, %.3f ms, clock %.2f GHz\n",
+                s[0] / steps, s[1] / steps, s[2] / steps, s[3] / steps, s[4] / steps, s[5] / steps, s[6], s[7] / 1e5, s[6] / (s[7] * 10.0) );
+    }
+#else
     hipLaunchKernelGGL(k_conv3d_march, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), M3_LDS, st, a1, D, H, W, l.wq, l.bias, zsum, tiles_x, ntiles,
                        act == 2 ? 1 : 0);
+#endif
     return hipGetLastError();
 }
 
