@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 11
+#define SMK_ABI_VERSION 12
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -324,6 +324,12 @@ int smk_conv3d_s7_forward(smk_linear *lin, const float *src, int32_t D, int32_t 
  * smk_pool3d_accumulate(zsum, 128, H, W, 1, sums).  `lin` as for smk_conv3d_cl_forward with out_features = 128; H % 8 == 0, W % 16 == 0,
  * H * W * 256 < 2^31. */
 int smk_conv3d_cl_zsum_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, float *zsum, int32_t activation, void *stream);
+/* Conv3d(1 -> 64, kernel 7, padding 3) + bias + activation (SMK_ACT_NONE or SMK_ACT_RELU) of a whole scalar volume src [D][H][W] into the
+ * channels-last activations a1 [D][H][W][64], marched along z: the weights stay in registers, each input plane of a workgroup's 14 x 22 halo
+ * tile is expanded once into a table of ready MFMA fragments in LDS (no gather and no split arithmetic in the loop).  `lin`: in_features =
+ * 448 = 7 kz x 8 ky slots x 8 kx slots, weight column (kz*8 + ky)*8 + kx (slot 7 of ky and of kx zero), out_features = 64.
+ * H % 8 == 0, W % 16 == 0, H * W * 256 < 2^31. */
+int smk_conv3d_s7_march_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, float *a1, int32_t activation, void *stream);
 
 /* ChaosAttention.generate_chaos_field's five explicit-Euler Lorenz states (chaos_attention.py:39-59) for noise [3][B] (the three
  * randn(B,1) draws before the 0.1 scale): states [B][5][3].  The gradient-free part of the chaos term, for the training path. */

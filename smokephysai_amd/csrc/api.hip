@@ -996,6 +996,18 @@ int smk_conv3d_cl_zsum_forward(smk_linear *lin, const float *src, int32_t D, int
     return check_launch(launch_conv3d_march(lin->l, src, D, H, W, zsum, activation, (hipStream_t)stream), "conv3d_march");
 }
 
+int smk_conv3d_s7_march_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, float *a1, int32_t activation, void *stream) {
+    SMK_REQUIRE(lin && src && a1, "null lin/src/a1");
+    SMK_REQUIRE(lin->l.K == 448 && lin->l.N == 64, "the layer handle must be 448 -> 64 (7 kz x 8 ky slots x 8 kx slots, 64 outputs)");
+    SMK_REQUIRE(D >= 1 && H >= 8 && W >= 16 && H % 8 == 0 && W % 16 == 0, "H must be a multiple of 8 and W of 16 (the 8 x 16 voxel column a workgroup marches)");
+    SMK_REQUIRE(((uintptr_t)src & 3) == 0 && ((uintptr_t)a1 & 15) == 0, "aligned src / a1");
+    SMK_REQUIRE((int64_t)H * W * 256 < (1LL << 31), "a plane of the output must stay below 2^31 bytes");
+    SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_RELU, "activation: none or ReLU");
+    DeviceGuard guard(lin->device);
+    if (guard.rc) return guard.rc;
+    return check_launch(launch_conv3d_s7_march(lin->l, src, D, H, W, a1, activation, (hipStream_t)stream), "conv3d_s7_march");
+}
+
 int smk_conv3d_s7_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
                           int32_t activation, void *stream) {
     SMK_REQUIRE(lin && src && y, "null lin/src/y");

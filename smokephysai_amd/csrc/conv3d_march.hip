@@ -303,6 +303,168 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv3d_s7_march: configs[4]'s FIRST convolution -- Conv3d(1 -> 64, 7 x 7 x 7, padding 3) + bias + ReLU of a scalar volume [D][H][W] into
+// the channels-last activations [D][H][W][64] -- as the same kind of march.  The implicit-GEMM form on the layer kernel (linear.hip, CONV = 2)
+// gathers and splits every (voxel, window row) piece from global memory once per output voxel, uses two of its four waves (N = 64), and is
+// bound by that staging (6.1 ms per 512 x 512 x 64 volume for 0.74 counted TFLOP).  Here:
+//   K layout   8 ky slots x 8 kx slots per kz (7 x 7 used; slot 7 of either carries zero weights): K = 448, a 32-k step = the 4 window rows
+//              ky = 4 (s & 1) .. + 3 of kz = s >> 1, 14 steps -- so the input plane of a step is wave-uniform (a scalar slot base).
+//   weights    IN REGISTERS for the whole kernel: wave w owns output channels 16 w .. 16 w + 15, i.e. 14 steps x (hi | lo) fragments = 112
+//              registers, loaded once from the layer handle's layout (N = 64, K = 448).
+//   operand    an MFMA A fragment of output voxel (y, x), window row (kz, ky) is the 8 consecutive inputs x[z + kz - 3][y + ky - 3][x - 3 .. x + 4]:
+//              a sliding window.  Each input plane of the 14 x 22 halo tile is expanded ONCE, when it enters the ring, into a table of
+//              ready fragments [14 rows][16 positions] x (16 B hi | 16 B lo) = 7 KB; seven planes (z - 3 .. z + 3) = 50 KB of LDS, two
+//              workgroups per CU.  A fragment fetch is then one aligned ds_read_b128 per part -- no gather, no split arithmetic in the loop.
+//              Rows of a table are 256 B, so the four k groups of a read (four window rows) fall on disjoint 16-lane bank sets.
+//   loop       per output plane and wave 14 steps x 8 tile rows x 3 products = 336 MFMAs on 224 fragment reads: the LDS pipe (each wave reads
+//              every fragment: 896 KB per plane and workgroup = 7 k cycles at 128 B/clk) bounds it, not the matrix pipe (5.4 k).
+// Arithmetic: split-bf16 x3, fp32 accumulation from the bias, window rows in (kz, ky) order.
+constexpr int S7_ROWS = M3_TH + 6, S7_PART = S7_ROWS * 16 * 16, S7_PLANE = 2 * S7_PART, S7_LDS = 7 * S7_PLANE;      // 3,584 / 7,168 / 50,176 B
+constexpr int S7_STEPS = 14, S7_PD = 4, S7_FENCE = 1000;                        // 32-k steps; fragment pairs in flight ahead of their MFMAs
+
+__global__ __launch_bounds__(256, 2) void k_conv3d_s7_march(const float *__restrict__ x, int D, int H, int W, const unsigned short *__restrict__ wq,
+                                                            const float *__restrict__ bias, float *__restrict__ a1, int tiles_x, int ntiles,
+                                                            int relu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, kg = lane >> 4;
+    const int o = wave * 16 + px;
+    const float bo = bias[o];
+
+    // ---- this wave's weights: layer layout [K/16][hi|lo][64][16] (linear.h), 32-k step s = k16 blocks 2s, 2s+1; lane group kg = 8 k of the step
+    m3_bf16x8 wh[S7_STEPS], wl[S7_STEPS];
+    {
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(wq), 0, 448 * 64 * 4, 0x00020000);
+        const int lane_b = (kg >> 1) * (64 * 64) + o * 32 + (kg & 1) * 16;
+#pragma unroll
+        for (int s = 0; s < S7_STEPS; ++s) {
+            const m3_u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, s * 8192, 0);
+            const m3_u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, s * 8192 + 2048, 0);
+            wh[s] = __builtin_bit_cast(m3_bf16x8, h);
+            wl[s] = __builtin_bit_cast(m3_bf16x8, l);
+        }
+    }
+    // window row of (step s, group kg): kz = s >> 1, ky = 4 (s & 1) + kg (slot 7: zero weights -- any valid row)
+    const int lane_a[2] = {kg * 256 + px * 16, (kg == 3 ? 6 : 4 + kg) * 256 + px * 16};
+    const unsigned plane_bytes = (unsigned)H * (unsigned)W * 4u;
+    const size_t a1_plane = (size_t)H * W * 64;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int r0 = ty * M3_TH, c0 = tx * M3_TW;
+        // ---- table builder: thread f < 224 = fragment (halo row f >> 4, position f & 15) = inputs (r0 - 3 + row, c0 - 3 + pos + 0 .. 7)
+        unsigned goff0, gmask = 0;                                            // byte offset of element 0; bit e = element e lies inside the plane
+        {
+            const int row = (tid >> 4) < S7_ROWS ? (tid >> 4) : S7_ROWS - 1, pos = tid & 15;
+            const int yy = r0 - 3 + row, xx0 = c0 - 3 + pos;
+            goff0 = (unsigned)((yy * W + xx0) * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gmask |= (yy >= 0 && yy < H && xx0 + e >= 0 && xx0 + e < W) ? 1u << e : 0u;
+        }
+        float nx[8];
+        auto plane_load = [&](int p) {
+            if (p >= 0 && p < D) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)p * H * W), 0, (int)plane_bytes,
+                                                                                     0x00020000);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) nx[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((gmask >> e & 1u) ? goff0 + 4u * e : M3_OOB), 0, 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) nx[e] = 0.f;
+            }
+        };
+        auto plane_store = [&](int slot) {
+            m3_bf16x8 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 h = (__bf16)nx[e];
+                vh[e] = h;
+                vl[e] = (__bf16)(nx[e] - (float)h);
+            }
+            if (tid < S7_ROWS * 16) {
+                *reinterpret_cast<m3_bf16x8 *>(smem + slot * S7_PLANE + tid * 16) = vh;
+                *reinterpret_cast<m3_bf16x8 *>(smem + slot * S7_PLANE + S7_PART + tid * 16) = vl;
+            }
+        };
+        // planes -3 .. 3 -> slots 0 .. 6 (slot of plane p = (p + 3) % 7)
+#pragma unroll 1
+        for (int p = -3; p <= 3; ++p) {
+            plane_load(p);
+            plane_store(p + 3);
+        }
+        __syncthreads();
+
+        int zb = 0;                                                           // slot of plane z - 3
+#pragma unroll 1
+        for (int z = 0; z < D; ++z) {
+            plane_load(z + 4);                                                // lands under the MFMAs
+            int sbase[7];                                                     // scalar: LDS offset of input plane z - 3 + kz
+#pragma unroll
+            for (int kz = 0; kz < 7; ++kz) {
+                const int sl = zb + kz;
+                sbase[kz] = __builtin_amdgcn_readfirstlane((sl >= 7 ? sl - 7 : sl) * S7_PLANE);
+            }
+            m3_f32x4 acc[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) acc[mt] = m3_f32x4{bo, bo, bo, bo};
+            // iteration n = (step n >> 3, tile row n & 7): fragment pair read S7_PD iterations ahead
+            m3_bf16x8 fh[S7_PD], fl[S7_PD];
+            auto frag = [&](int n, m3_bf16x8 &h, m3_bf16x8 &l) {
+                const unsigned char *pa = smem + sbase[n >> 4] + lane_a[(n >> 3) & 1] + (n & 7) * 256;
+                l = *reinterpret_cast<const m3_bf16x8 *>(pa + S7_PART);
+                h = *reinterpret_cast<const m3_bf16x8 *>(pa);
+            };
+#pragma unroll
+            for (int n = 0; n < S7_PD; ++n) frag(n, fh[n], fl[n]);
+#pragma unroll
+            for (int n = 0; n < S7_STEPS * 8; ++n) {
+                const int s = n >> 3, mt = n & 7;
+                const m3_bf16x8 h = fh[n % S7_PD], l = fl[n % S7_PD];
+                if (n + S7_PD < S7_STEPS * 8) frag(n + S7_PD, fh[n % S7_PD], fl[n % S7_PD]);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, wh[s], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, wl[s], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, wh[s], acc[mt], 0, 0, 0);
+                // fenced every few iterations: left alone hipcc hoists a dozen reads to the top and spills lane constants, whose reloads then
+                // wait behind the plane loads
+                if (n % S7_FENCE == S7_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- a1[z][r0 + mt][c0 + 4 kg + i][o] = relu(acc): a scalar row pointer + one lane offset
+            const int lane_o = 4 * kg * 64 + o;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                float *prow = a1 + (size_t)z * a1_plane + ((size_t)(r0 + mt) * W + c0) * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float y = acc[mt][i];
+                    y = (relu && !(y > 0.f)) ? 0.f : y;
+                    prow[lane_o + i * 64] = y;
+                }
+            }
+            __syncthreads();                                   // every wave is done with plane z - 3
+            plane_store(zb);                                   // plane z + 4 takes its slot
+            __syncthreads();
+            zb = zb == 6 ? 0 : zb + 1;
+        }
+    }
+}
+
+hipError_t launch_conv3d_s7_march(const LinearDev &l, const float *x, int D, int H, int W, float *a1, int act, hipStream_t st) {
+    if (l.K != 448 || l.N != 64 || D < 1 || H < M3_TH || W < M3_TW || H % M3_TH || W % M3_TW || (long long)H * W * 256 >= (1LL << 31) ||
+        (act != 0 && act != 2))
+        return hipErrorInvalidValue;
+    once_per_device((const void *)k_conv3d_s7_march, [&] {
+        (void)hipFuncSetAttribute((const void *)k_conv3d_s7_march, hipFuncAttributeMaxDynamicSharedMemorySize, S7_LDS);
+    });
+    const int tiles_x = W / M3_TW, ntiles = tiles_x * (H / M3_TH);
+    const int nwg = 2 * device_num_cu();
+    hipLaunchKernelGGL(k_conv3d_s7_march, dim3(ntiles < nwg ? ntiles : nwg), dim3(256), S7_LDS, st, x, D, H, W, l.wq, l.bias, a1, tiles_x, ntiles,
+                       act == 2 ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3d_march(const LinearDev &l, const float *a1, int D, int H, int W, float *zsum, int act, hipStream_t st) {
     if (l.K != 27 * 64 || l.N != 128 || D < 1 || H < M3_TH || W < M3_TW || H % M3_TH || W % M3_TW || (long long)H * W * 256 >= (1LL << 31) ||
         (act != 0 && act != 2))

@@ -40,6 +40,9 @@ hipError_t launch_conv3d_s7_b16(const LinearDev &l, const float *slab, int Dl, i
 // the 3 x 3 x 3 convolution of a whole channels-last volume marched along z, depth-summed (conv3d_march.hip): zsum [H][W][128]
 hipError_t launch_conv3d_march(const LinearDev &l, const float *a1, int D, int H, int W, float *zsum, int act, hipStream_t st);
 
+// the 7 x 7 x 7 convolution of a whole scalar volume marched along z (conv3d_march.hip): a1 [D][H][W][64]; weights K = 448 = (kz, 8 ky, 8 kx)
+hipError_t launch_conv3d_s7_march(const LinearDev &l, const float *x, int D, int H, int W, float *a1, int act, hipStream_t st);
+
 // dW = dY^T X (linear.hip): workspace layout and segment count for a problem size
 struct WgradPlan { int nseg; long long rows_pad; size_t off_wq, off_part, off_col, bytes; };
 WgradPlan plan_linear_wgrad(long long rows, int out_features, int in_features);

@@ -42,6 +42,10 @@ class HipEncoder3D:
         w1i = torch.zeros(64, 56, 8, dtype=torch.float64, device=self._dev)
         w1i[:, :49, :7] = (w["conv1_w"].reshape(64, 49, 7) * s1[:, None, None])
         self._lin1i = HipLinear(w1i.reshape(64, 448).float(), b1.float(), device=self._dev)
+        # marched form of conv1 (smk_conv3d_s7_march_forward): 7 kz x 8 ky slots x 8 kx slots
+        w1m = torch.zeros(64, 7, 8, 8, dtype=torch.float64, device=self._dev)
+        w1m[:, :, :7, :7] = w["conv1_w"].reshape(64, 7, 7, 7) * s1[:, None, None, None]
+        self._lin1m = HipLinear(w1m.reshape(64, 448).float(), b1.float(), device=self._dev)
         self._lin2 = HipLinear(w2.float(), b2.float(), device=self._dev)
         self.slab_bytes = int(slab_bytes)
         self._bufs = {}
@@ -52,7 +56,7 @@ class HipEncoder3D:
             raise ValueError("conv2_mode: 'march' (smk_conv3d_cl_zsum_forward: conv2 marched along z with its input planes in LDS, depth pooling "
                              "fused), 'implicit' (smk_conv3d_cl_forward: implicit GEMM, no patch matrix) or 'im2col' (explicit GEMM)")
         self.conv2_mode = conv2_mode
-        self.conv1_mode = "im2col" if conv2_mode == "im2col" else "implicit"
+        self.conv1_mode = conv2_mode
 
     def _buffer(self, name, shape):
         """Activation buffers are kept between calls (a 512 x 512 x 64 volume's conv1 output is 4.3 GB: a fresh allocation per call costs
@@ -72,7 +76,11 @@ class HipEncoder3D:
         """One volume [D, H, W] -> relu(bn1(conv1)) channels-last [D, H, W, 64]."""
         D, H, W = vol.shape
         a1 = self._buffer("a1", (D, H, W, 64))
-        if self.conv1_mode == "implicit" and H <= 1023 and W <= 1023:
+        if self.conv1_mode == "march" and H % 8 == 0 and W % 16 == 0 and H * W * 256 < (1 << 31):
+            _lib.check(self._L.smk_conv3d_s7_march_forward(self._lin1m._handle, vol.data_ptr(), D, H, W, a1.data_ptr(), _lib.SMK_ACT_RELU,
+                                                           _lib.stream_ptr(self._dev)))
+            return a1
+        if self.conv1_mode != "im2col" and H <= 1023 and W <= 1023:
             nz = max(1, min(D, ((1 << 32) - 512) // (H * W * 4) - 6, 1000, ((1 << 31) - 512) // (H * W)))
             for z0 in range(0, D, nz):
                 n = min(nz, D - z0)

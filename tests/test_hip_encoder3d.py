@@ -104,6 +104,29 @@ def test_march_kernel_depth_edges_and_zsum(D):
         _lib.check(L.smk_conv3d_cl_zsum_forward(lin._handle, src.data_ptr(), D, 12, W, zsum.data_ptr(), 0, _lib.stream_ptr(src.device)))
 
 
+@pytest.mark.parametrize("D", [1, 4, 9])
+def test_conv1_march_kernel_depth_edges(D):
+    """smk_conv3d_s7_march_forward alone against the fp64 oracle's conv1 (7 x 7 x 7, padding 3) on a signed random volume: depths below, at and
+    above the ring's seven planes, every tile touching a wall in x or y, both activations."""
+    from oracle.encoder3d import conv3d
+    from smokephysai_amd.models.linear import HipLinear
+    rng = np.random.RandomState(10 + D)
+    H, W = 16, 32
+    vol = rng.randn(D, H, W).astype(np.float32)
+    w1 = (rng.randn(64, 1, 7, 7, 7) * 0.05).astype(np.float32)
+    b1 = rng.randn(64).astype(np.float32)
+    w1m = torch.zeros(64, 7, 8, 8)
+    w1m[:, :, :7, :7] = torch.from_numpy(w1[:, 0])
+    lin = HipLinear(w1m.reshape(64, 448).contiguous(), torch.from_numpy(b1), device="cuda")
+    L = _lib.load()
+    src = torch.from_numpy(vol).cuda()
+    ref = conv3d(vol[None].astype(np.float64), w1.astype(np.float64), b1.astype(np.float64), 3)      # [64, D, H, W]
+    for act, f in ((_lib.SMK_ACT_NONE, lambda t: t), (_lib.SMK_ACT_RELU, lambda t: np.maximum(t, 0.0))):
+        a1 = torch.full((D, H, W, 64), float("nan"), device="cuda")
+        _lib.check(L.smk_conv3d_s7_march_forward(lin._handle, src.data_ptr(), D, H, W, a1.data_ptr(), act, _lib.stream_ptr(src.device)))
+        assert rel_err(a1.cpu().numpy(), np.moveaxis(f(ref), 0, -1)) < 1e-5, (D, act)
+
+
 def test_loud_failures():
     enc = HipEncoder3D({k: torch.from_numpy(v) for k, v in _weights().items()})
     with pytest.raises(ValueError):
