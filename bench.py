@@ -160,9 +160,9 @@ def dataset_leg(dev, N=128, samples=512, cpu_budget_s=8.0):
 
 
 def config4_leg(dev, steps=6):
-    """BASELINE configs[4], the stepper half (the conv3d encoder is not built yet): 8 grids of 512 x 512 x 64, Jacobi-20, SPEC_3D.md
-    semantics, through smk_sim3d_step.  HIP events on the launch stream; roofline = SPEC_3D.md section 7's pass-model bytes,
-    4 (37 + 3 J) per cell and step, against HBM 8 TB/s."""
+    """BASELINE configs[4]: 8 grids of 512 x 512 x 64, Jacobi-20, SPEC_3D.md semantics, through smk_sim3d_step (HIP events on the launch
+    stream; roofline = SPEC_3D.md section 7's pass-model bytes, 4 (37 + 3 J) per cell and step, against HBM 8 TB/s), then the conv3d
+    encoder (SPEC_3D.md section 8) on all 8 emitted volumes."""
     from smokephysai_amd.physics import NavierStokesSimulator3D
     B, D, H, W, J = 8, 64, 512, 512, 20
     sim = NavierStokesSimulator3D((D, H, W), device=dev, batch_size=B, jacobi_iters=J)
@@ -183,8 +183,7 @@ def config4_leg(dev, steps=6):
     cells = B * D * H * W
     alg = cells * 4.0 * (37 + 3 * J)
     gbs = alg / (ms * 1e-3) / 1e9
-    # the encoder (SPEC_3D.md section 8; explicit-GEMM first slice) on ONE of the emitted volumes: it is 100 x the stepper's time per
-    # volume, so one volume is timed and the step's figure is 8 x that
+    # the encoder (SPEC_3D.md section 8) on the step's 8 emitted volumes (one volume first, untimed: buffers, first-use setup)
     from smokephysai_amd.models import HipEncoder3D
     g = torch.Generator().manual_seed(0)
     w = {"conv1_w": torch.randn(64, 1, 7, 7, 7, generator=g) * 0.05, "conv1_b": torch.randn(64, generator=g) * 0.1,
@@ -196,10 +195,10 @@ def config4_leg(dev, steps=6):
     enc(frame[:1])
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    feats = enc(frame[:1])
+    feats = enc(frame)
     torch.cuda.synchronize(dev)
-    ms_enc = (time.perf_counter() - t0) * 1e3
-    assert torch.isfinite(feats).all()
+    ms_enc = (time.perf_counter() - t0) * 1e3 / B
+    assert feats.shape == (B, 128, 32, 32) and torch.isfinite(feats).all()
     enc_flop = 2.0 * D * H * W * (343 * 64 + 27 * 64 * 128)
     ms_total = ms + B * ms_enc
     return {"workload": f"configs[4]: {W}x{H}x{D} grid, batch {B}, Jacobi-{J} (SPEC_3D.md), conv3d encoder -> [B,128,32,32]",
@@ -212,11 +211,12 @@ def config4_leg(dev, steps=6):
                                  "note": "pass-model bytes 4*(37+3J) per cell (SPEC_3D.md section 7) over the measured time; the kernels move fewer "
                                          "(four Jacobi sweeps per launch, one advection launch), so like the 2-D figure this is work done per "
                                          "second in the survey's unit, not a bound on the pins"},
-            "roofline_encoder": {"bound": "mfma", "kernel": "conv1: k_linear_b16<4,2>, conv2: k_linear_b16<4,1> (implicit GEMMs on the split-bf16 layer kernel, no patch matrix); k_pool3d_accum",
+            "roofline_encoder": {"bound": "mfma", "kernel": "conv1: k_conv3d_s7_march (weights in registers, fragment tables in LDS), conv2 + depth pooling: k_conv3d_march "
+                                                            "(three input planes in LDS, 27 taps per plane from there); k_pool3d_accum on the depth sums",
                                  "achieved": enc_flop / (ms_enc * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s",
                                  "frac": enc_flop / (ms_enc * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16x3"],
-                                 "note": "first slice: within 1e-6 of the fp64 oracle; the x3 split executes 3 MFMA products per counted multiply; the "
-                                         "unfused activation round trips (a1 4.3 GB, a2 8.6 GB per volume) are what the fused kernel of DESIGN section 9 removes"}}
+                                 "note": "within 1e-6 of the fp64 oracle; the x3 split executes 3 MFMA products per counted multiply (frac 0.33 = the matrix "
+                                         "pipe full); all 8 volumes timed; conv1's output (4.3 GB per volume) is the one activation still written to HBM"}}
 
 
 def hbm_copy_gbs(dev):

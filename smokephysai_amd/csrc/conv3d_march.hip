@@ -103,25 +103,20 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
         }
         const bool last_item = tid + 256 * (M3_NIT - 1) < M3_ITEMS;           // the sixth item exists for 160 of the 256 threads
         float v[M3_NIT][8];
-        auto stage_load = [&](int z) {
-            if (z >= 0 && z < D) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a1 + (size_t)z * H * W * 64), 0,
-                                                                                     (int)plane_bytes, 0x00020000);
+        auto stage_load = [&](int z) {                        // a plane outside the volume: every offset out of range -> zeros, no branch
+            const bool inside = z >= 0 && z < D;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a1 + (size_t)(inside ? z : 0) * H * W * 64), 0,
+                                                                                 (int)plane_bytes, 0x00020000);
 #pragma unroll
-                for (int j = 0; j < M3_NIT; ++j) {
-                    const m3_u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[j], 0, 0);
-                    const m3_u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(goff[j] + 16u), 0, 0);
+            for (int j = 0; j < M3_NIT; ++j) {
+                const unsigned off = inside ? goff[j] : M3_OOB;
+                const m3_u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+                const m3_u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16u), 0, 0);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        v[j][c] = __uint_as_float(q0[c]);
-                        v[j][4 + c] = __uint_as_float(q1[c]);
-                    }
+                for (int c = 0; c < 4; ++c) {
+                    v[j][c] = __uint_as_float(q0[c]);
+                    v[j][4 + c] = __uint_as_float(q1[c]);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < M3_NIT; ++j)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) v[j][c] = 0.f;
             }
         };
         auto store_item = [&](unsigned char *base, const float (&x)[8], int off, bool ok) {
@@ -266,16 +261,22 @@ __global__ __launch_bounds__(256, 1) void k_conv3d_march(const float *__restrict
             M3_STAMP(t4);
 
             // ---- this plane's activations into the depth sums.  Lane: channel o0 (nt 0) / o0 + 16 (nt 1), voxels (row mt, columns 4 kg .. 4 kg + 3)
+            // (the activation switch outside the loop: a per-element select on it serialises through vcc -- 2.1 k cycles instead of 0.5 k)
+            if (relu) {
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+                for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float y = acc[mt][nt][i];
-                        y = (relu && !(y > 0.f)) ? 0.f : y;
-                        zs[mt][nt][i] += y;
-                    }
+                        for (int i = 0; i < 4; ++i) zs[mt][nt][i] += __builtin_fmaxf(acc[mt][nt][i], 0.f);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) zs[mt][nt][i] += acc[mt][nt][i];
+            }
             s0 = s1;
 #ifdef SMK_M3_STAMPS
             M3_STAMP(t5);
@@ -437,11 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3d_s7_march(const float *__restr
             for (int mt = 0; mt < 8; ++mt) {
                 float *prow = a1 + (size_t)z * a1_plane + ((size_t)(r0 + mt) * W + c0) * 64;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float y = acc[mt][i];
-                    y = (relu && !(y > 0.f)) ? 0.f : y;
-                    prow[lane_o + i * 64] = y;
-                }
+                for (int i = 0; i < 4; ++i) prow[lane_o + i * 64] = relu ? __builtin_fmaxf(acc[mt][i], 0.f) : acc[mt][i];
             }
             __syncthreads();                                   // every wave is done with plane z - 3
             plane_store(zb);                                   // plane z + 4 takes its slot
