@@ -1,16 +1,17 @@
-"""3-D input encoder on MI355X (BASELINE configs[4]: "MFMA conv3d encoder"), first slice.
+"""3-D input encoder on MI355X (BASELINE configs[4]: "MFMA conv3d encoder").
 
 The reference's encoder is 2-D (src/models/smokephys_net.py:24-32,87-91); SPEC_3D.md section 8 generalises it axis by axis:
 Conv3d(1, 64, 7, padding 3) + BatchNorm3d + ReLU -> Conv3d(64, 128, 3, padding 1) + BatchNorm3d + ReLU -> the two adaptive average
 pools with the depth axis pooled to 1 -> features [B, 128, 32, 32], i.e. exactly the tensor SmokePhysNet tokenises (smokephys_net.py:95),
 so the rest of the network applies unchanged.  Eval mode (running statistics folded into the weights, as HipEncoder does in 2-D).
 
-Execution: both convolutions are GEMMs on the split-bf16 MFMA layer kernel (fp32-class accuracy), activations channels-last
-[D, H, W, C] (what the GEMM writes).  Both are IMPLICIT GEMMs -- no patch matrix: conv2 (98 % of the flops; `smk_conv3d_cl_forward`, k_linear_b16<NW, 1>): chunk c of the layer
-kernel's K loop is tap c, staged from the voxel at the shifted address; conv1 (343 taps of a scalar field; `smk_conv3d_s7_forward`,
-k_linear_b16<4, 2>): the K range is 56 (kz, ky) window rows x 8 kx slots and a staged 16-byte piece is 4 consecutive x of the input.
-`conv2_mode="im2col"` keeps the explicit forms (`smk_conv3d_im2col` -> [voxels, taps x channels] -> `smk_linear_forward`) for A/B runs.
-`smk_pool3d_accumulate` reduces the activated slab into the 32 x 32 token sums.
+Execution (csrc/conv3d_march.hip): both convolutions on split-bf16 MFMAs (fp32-class accuracy), activations channels-last [D, H, W, C].
+conv1 (`smk_conv3d_s7_march_forward`): a workgroup marches an 8 x 16 column of voxels along z, weights in registers, each input plane expanded
+once into a table of ready MFMA fragments in LDS.  conv2 (`smk_conv3d_cl_zsum_forward`): the same march with three input planes in LDS, all
+27 taps read from there, `relu(conv + bias)` summed over z in registers -- the depth half of the pooling -- so the activated conv2 output is
+never written; `smk_pool3d_accumulate` reduces the depth sums to the 32 x 32 token sums.
+`conv2_mode="implicit"` keeps the first form built (both convolutions as implicit GEMMs on the layer kernel: `smk_conv3d_cl_forward`,
+`smk_conv3d_s7_forward`), `"im2col"` the explicit one (`smk_conv3d_im2col` -> [voxels, taps x channels] -> `smk_linear_forward`), for A/B runs.
 """
 import torch
 
