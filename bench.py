@@ -159,14 +159,16 @@ def dataset_leg(dev, N=128, samples=512, cpu_budget_s=8.0):
             "reference_on_8_cores_in_build_container": "1.43 s per sample at 128^2 (BASELINE.md: actual reference code)"}
 
 
-def config4_leg(dev, steps=6):
+def config4_leg(dev, steps=6, rank=0, world=1, dist=None, backend="nccl"):
     """BASELINE configs[4]: 8 grids of 512 x 512 x 64, Jacobi-20, SPEC_3D.md semantics, through smk_sim3d_step (HIP events on the launch
     stream; roofline = SPEC_3D.md section 7's pass-model bytes, 4 (37 + 3 J) per cell and step, against HBM 8 TB/s), then the conv3d
-    encoder (SPEC_3D.md section 8) on all 8 emitted volumes."""
+    encoder (SPEC_3D.md section 8) on all emitted volumes.  N > 1 (configs[4] is quoted on 8 GPUs): the 8 volumes shard over the ranks with
+    no data-path collective (8 / N per GPU; every rank runs this leg), each component is the MAX over ranks."""
     from smokephysai_amd.physics import NavierStokesSimulator3D
-    B, D, H, W, J = 8, 64, 512, 512, 20
+    B_total, D, H, W, J = 8, 64, 512, 512, 20
+    B = B_total // world
     sim = NavierStokesSimulator3D((D, H, W), device=dev, batch_size=B, jacobi_iters=J)
-    rng = np.random.RandomState(4)
+    rng = np.random.RandomState(4 + rank)
     sim.add_smoke_sources([(b, int(rng.randint(40, W - 40)), int(rng.randint(40, H - 40)), int(rng.randint(10, D - 10)), 8,
                             float(rng.uniform(0.5, 2.0))) for b in range(B) for _ in range(3)])
     frame = torch.empty(B, D, H, W, device=dev)
@@ -194,16 +196,24 @@ def config4_leg(dev, steps=6):
     enc = HipEncoder3D(w, device=dev)
     enc(frame[:1])
     torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     feats = enc(frame)
     torch.cuda.synchronize(dev)
     ms_enc = (time.perf_counter() - t0) * 1e3 / B
     assert feats.shape == (B, 128, 32, 32) and torch.isfinite(feats).all()
+    if dist is not None:
+        t = torch.tensor([ms, ms_enc], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms, ms_enc = float(t[0].item()), float(t[1].item())
+        gbs = alg / (ms * 1e-3) / 1e9
     enc_flop = 2.0 * D * H * W * (343 * 64 + 27 * 64 * 128)
     ms_total = ms + B * ms_enc
-    return {"workload": f"configs[4]: {W}x{H}x{D} grid, batch {B}, Jacobi-{J} (SPEC_3D.md), conv3d encoder -> [B,128,32,32]",
-            "value": B / (ms_total * 1e-3), "unit": "volumes/s (simulated + encoded)", "ms_per_step": ms_total,
-            "ms_sim_per_step": ms, "sim_only_volumes_per_s": B / (ms * 1e-3), "ms_encode_per_volume": ms_enc, "steps": steps, "dtype": "f32 stencil + bf16x3 GEMM",
+    return {"workload": f"configs[4]: {W}x{H}x{D} grid, batch {B_total} ({B} per GPU), Jacobi-{J} (SPEC_3D.md), conv3d encoder -> [B,128,32,32]",
+            "value": B_total / (ms_total * 1e-3), "unit": "volumes/s (simulated + encoded, whole job)", "ms_per_step": ms_total, "n_gpus": world,
+            "volumes_per_gpu": B, "parallelism": f"independent volumes sharded over {world} GPU(s), no data-path collective; times = max over ranks",
+            "ms_sim_per_step": ms, "sim_only_volumes_per_s": B_total / (ms * 1e-3), "ms_encode_per_volume": ms_enc, "steps": steps, "dtype": "f32 stencil + bf16x3 GEMM",
             "cells_per_step": cells, "algorithmic_bytes_per_step": alg,
             "launches_per_step": "4 + ceil(J / 4): buoyancy+diffusion (z-marching), divergence, Jacobi in 4-sweep temporally blocked launches, "
                                  "gradient subtraction, the four advections as one launch",
@@ -651,6 +661,10 @@ def main(argv=None):
         leg_order.append("alt")
     elapsed, ms_sim, ms_enc = timed(args.encoder_dtype)
     leg_order.append("headline")
+    config4_sharded = None
+    if world > 1 and 8 % world == 0 and not args.no_config4 and not args.no_encode:
+        config4_sharded = config4_leg(dev, rank=rank, world=world, dist=dist, backend=backend)      # every rank: 8 / N volumes each
+        leg_order.append("config4")
 
     out = None
     if rank == 0:
@@ -710,6 +724,8 @@ def main(argv=None):
             out["dataset"] = dataset_leg(dev)
         if world == 1 and not args.no_config4:
             out["config4"] = config4_leg(dev)
+        elif config4_sharded is not None:
+            out["config4"] = config4_sharded
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
         # what the device had run when the headline's timed region began: the W warm-up steps of the headline leg itself plus the full
@@ -717,7 +733,7 @@ def main(argv=None):
         out["effective_warmup_steps"] = {"headline_leg": W, "config1_leg_before": (W + K) if config1 is not None else 0,
                                          "alt_leg_before": (W + K) if alt is not None else 0,
                                          "total_steps_before_timed_region": W + ((W + K) if config1 is not None else 0) + ((W + K) if alt is not None else 0)}
-        out["leg_order"] = leg_order + [k for k in ("inference_ms_per_frame", "dataset", "config4", "cpu_baseline") if k in out] + (["train_step"] if args.train_step else [])
+        out["leg_order"] = leg_order + [k for k in ("inference_ms_per_frame", "dataset", "config4", "cpu_baseline") if k in out and k not in leg_order] + (["train_step"] if args.train_step else [])
 
     exit_code = 0
     if args.train_step:

@@ -40,6 +40,7 @@ def test_round3_bench_line_has_the_new_blocks():
     assert ts["rccl_ranks"] == 1 and ts["ddp_wrapped"] is True and "error" not in ts and "1 rank(s)" in ts["note"]
     c4 = d["config4"]
     assert c4["algorithmic_bytes_per_step"] == 8 * 64 * 512 * 512 * 4.0 * (37 + 3 * 20)
+    assert c4["n_gpus"] == 1 and c4["volumes_per_gpu"] == 8
     assert abs(c4["ms_per_step"] - (c4["ms_sim_per_step"] + 8 * c4["ms_encode_per_volume"])) < 1e-6
     assert d["dataset"]["unit"] == "samples/s" and d["dataset"]["value"] > d["dataset"]["cpu_port"]["value"]
     assert d["effective_warmup_steps"]["headline_leg"] == 5

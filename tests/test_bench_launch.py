@@ -73,6 +73,10 @@ def test_self_launched_two_ranks_gloo_rehearsal():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # configs[4] (quoted on 8 GPUs) shards its 8 volumes over the ranks: 4 each here, no collective on the data path
+    c4 = d["config4"]
+    assert c4["n_gpus"] == 2 and c4["volumes_per_gpu"] == 4 and c4["value"] > 0
+    assert abs(c4["ms_per_step"] - (c4["ms_sim_per_step"] + 4 * c4["ms_encode_per_volume"])) < 1e-6
     ts = d["train_step"]
     assert "error" not in ts, ts
     assert ts["ranks"] == 2 and ts["global_batch"] == 8 and ts["ms_per_step"] > 0
