@@ -159,11 +159,9 @@ def dataset_leg(dev, N=128, samples=512, cpu_budget_s=8.0):
             "reference_on_8_cores_in_build_container": "1.43 s per sample at 128^2 (BASELINE.md: actual reference code)"}
 
 
-def config4_leg(dev, steps=6, rank=0, world=1, dist=None, backend="nccl"):
-    """BASELINE configs[4]: 8 grids of 512 x 512 x 64, Jacobi-20, SPEC_3D.md semantics, through smk_sim3d_step (HIP events on the launch
-    stream; roofline = SPEC_3D.md section 7's pass-model bytes, 4 (37 + 3 J) per cell and step, against HBM 8 TB/s), then the conv3d
-    encoder (SPEC_3D.md section 8) on all emitted volumes.  N > 1 (configs[4] is quoted on 8 GPUs): the 8 volumes shard over the ranks with
-    no data-path collective (8 / N per GPU; every rank runs this leg), each component is the MAX over ranks."""
+def config4_measure(dev, steps=6, rank=0, world=1):
+    """This rank's share of configs[4] (8 / world volumes of 512 x 512 x 64, Jacobi-20, SPEC_3D.md): ms per stepper step (HIP events on the
+    launch stream) and ms per encoded volume (all of the step's volumes through HipEncoder3D).  No collective in here."""
     from smokephysai_amd.physics import NavierStokesSimulator3D
     B_total, D, H, W, J = 8, 64, 512, 512, 20
     B = B_total // world
@@ -182,10 +180,7 @@ def config4_leg(dev, steps=6, rank=0, world=1, dist=None, backend="nccl"):
     torch.cuda.synchronize(dev)
     assert torch.isfinite(frame).all() and float(frame.abs().sum()) > 0
     ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]))
-    cells = B * D * H * W
-    alg = cells * 4.0 * (37 + 3 * J)
-    gbs = alg / (ms * 1e-3) / 1e9
-    # the encoder (SPEC_3D.md section 8) on the step's 8 emitted volumes (one volume first, untimed: buffers, first-use setup)
+    # the encoder (SPEC_3D.md section 8) on the step's emitted volumes (one volume first, untimed: buffers, first-use setup)
     from smokephysai_amd.models import HipEncoder3D
     g = torch.Generator().manual_seed(0)
     w = {"conv1_w": torch.randn(64, 1, 7, 7, 7, generator=g) * 0.05, "conv1_b": torch.randn(64, generator=g) * 0.1,
@@ -196,18 +191,21 @@ def config4_leg(dev, steps=6, rank=0, world=1, dist=None, backend="nccl"):
     enc = HipEncoder3D(w, device=dev)
     enc(frame[:1])
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
     t0 = time.perf_counter()
     feats = enc(frame)
     torch.cuda.synchronize(dev)
     ms_enc = (time.perf_counter() - t0) * 1e3 / B
     assert feats.shape == (B, 128, 32, 32) and torch.isfinite(feats).all()
-    if dist is not None:
-        t = torch.tensor([ms, ms_enc], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms, ms_enc = float(t[0].item()), float(t[1].item())
-        gbs = alg / (ms * 1e-3) / 1e9
+    return ms, ms_enc
+
+
+def config4_block(ms, ms_enc, steps=6, world=1):
+    """The `config4` block of the bench line from the (max-over-ranks) component times."""
+    B_total, D, H, W, J = 8, 64, 512, 512, 20
+    B = B_total // world
+    cells = B * D * H * W
+    alg = cells * 4.0 * (37 + 3 * J)
+    gbs = alg / (ms * 1e-3) / 1e9
     enc_flop = 2.0 * D * H * W * (343 * 64 + 27 * 64 * 128)
     ms_total = ms + B * ms_enc
     return {"workload": f"configs[4]: {W}x{H}x{D} grid, batch {B_total} ({B} per GPU), Jacobi-{J} (SPEC_3D.md), conv3d encoder -> [B,128,32,32]",
@@ -218,15 +216,37 @@ def config4_leg(dev, steps=6, rank=0, world=1, dist=None, backend="nccl"):
             "launches_per_step": "4 + ceil(J / 4): buoyancy+diffusion (z-marching), divergence, Jacobi in 4-sweep temporally blocked launches, "
                                  "gradient subtraction, the four advections as one launch",
             "roofline_stencil": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "note": "pass-model bytes 4*(37+3J) per cell (SPEC_3D.md section 7) over the measured time; the kernels move fewer "
+                                 "note": "per GPU: pass-model bytes 4*(37+3J) per cell (SPEC_3D.md section 7) over the measured time; the kernels move fewer "
                                          "(four Jacobi sweeps per launch, one advection launch), so like the 2-D figure this is work done per "
                                          "second in the survey's unit, not a bound on the pins"},
             "roofline_encoder": {"bound": "mfma", "kernel": "conv1: k_conv3d_s7_march (weights in registers, fragment tables in LDS), conv2 + depth pooling: k_conv3d_march "
                                                             "(three input planes in LDS, 27 taps per plane from there); k_pool3d_accum on the depth sums",
                                  "achieved": enc_flop / (ms_enc * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s",
                                  "frac": enc_flop / (ms_enc * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16x3"],
-                                 "note": "within 1e-6 of the fp64 oracle; the x3 split executes 3 MFMA products per counted multiply (frac 0.33 = the matrix "
-                                         "pipe full); all 8 volumes timed; conv1's output (4.3 GB per volume) is the one activation still written to HBM"}}
+                                 "note": "per GPU; within 1e-6 of the fp64 oracle; the x3 split executes 3 MFMA products per counted multiply (frac 0.33 = the matrix "
+                                         "pipe full); every volume of the step timed; conv1's output (4.3 GB per volume) is the one activation still written to HBM"}}
+
+
+def config4_leg(dev, steps=6, rank=0, world=1, dist=None, backend="nccl"):
+    """BASELINE configs[4]: 8 grids of 512 x 512 x 64, Jacobi-20, SPEC_3D.md semantics, through smk_sim3d_step, then the conv3d encoder
+    (SPEC_3D.md section 8) on all emitted volumes.  N > 1 (configs[4] is quoted on 8 GPUs): the 8 volumes shard over the ranks with no
+    data-path collective (8 / N per GPU; every rank runs this leg); each component is the MAX over ranks.  A rank whose share fails still
+    takes part in the one collective of the leg (a failure flag travels with the times), so the others never wait for it."""
+    err = None
+    ms = ms_enc = 0.0
+    try:
+        ms, ms_enc = config4_measure(dev, steps, rank, world)
+    except Exception as e:        # noqa: BLE001 -- reported in the block; the headline line must still be printed
+        if dist is None:
+            raise
+        err = f"rank {rank}: {type(e).__name__}: {e}"
+    if dist is not None:
+        t = torch.tensor([ms, ms_enc, 0.0 if err is None else 1.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t[2].item()) > 0:
+            return {"error": err or "another rank failed in its share of the leg", "n_gpus": world}
+        ms, ms_enc = float(t[0].item()), float(t[1].item())
+    return config4_block(ms, ms_enc, steps, world)
 
 
 def hbm_copy_gbs(dev):
@@ -667,6 +687,7 @@ def main(argv=None):
         leg_order.append("config4")
 
     out = None
+    secondary_rc = 0
     if rank == 0:
         frames_total = world * B * K
         stencil_bytes = B * N * N * 4.0 * (27 + 3 * J)          # algorithmic bytes per stencil pass
@@ -716,18 +737,27 @@ def main(argv=None):
         attach_counters(out, args.encoder_dtype)
         if world == 1:
             out["hbm_copy_measured_GBs"] = hbm_copy_gbs(dev)
+        # secondary legs: a failure in one is reported in its block (and in the exit code); the headline line is still printed
+        def secondary(name, fn):
+            try:
+                out[name] = fn()
+                return 0
+            except Exception as e:        # noqa: BLE001
+                out[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                return 4
         if world == 1 and not args.no_encode and not args.no_inference:
-            out["inference_ms_per_frame"] = inference_ms(dev, N, frame, args.encoder_dtype)
+            secondary_rc |= secondary("inference_ms_per_frame", lambda: inference_ms(dev, N, frame, args.encoder_dtype))
         if config1 is not None:
             out["config1"] = config1
         if world == 1 and not args.no_dataset:
-            out["dataset"] = dataset_leg(dev)
+            secondary_rc |= secondary("dataset", lambda: dataset_leg(dev))
         if world == 1 and not args.no_config4:
-            out["config4"] = config4_leg(dev)
+            secondary_rc |= secondary("config4", lambda: config4_leg(dev))
         elif config4_sharded is not None:
             out["config4"] = config4_sharded
+            secondary_rc |= 4 if "error" in config4_sharded else 0
         if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(N, J, weights, args.cpu_frames)
+            secondary_rc |= secondary("cpu_baseline", lambda: cpu_baseline(N, J, weights, args.cpu_frames))
         # what the device had run when the headline's timed region began: the W warm-up steps of the headline leg itself plus the full
         # secondary legs in front of it (a fresh process's first launches run slower while the clocks ramp; README "leg order")
         out["effective_warmup_steps"] = {"headline_leg": W, "config1_leg_before": (W + K) if config1 is not None else 0,
@@ -735,7 +765,7 @@ def main(argv=None):
                                          "total_steps_before_timed_region": W + ((W + K) if config1 is not None else 0) + ((W + K) if alt is not None else 0)}
         out["leg_order"] = leg_order + [k for k in ("inference_ms_per_frame", "dataset", "config4", "cpu_baseline") if k in out and k not in leg_order] + (["train_step"] if args.train_step else [])
 
-    exit_code = 0
+    exit_code = secondary_rc if rank == 0 else 0
     if args.train_step:
         # A collective that never completes on one rank would hang every rank: a watchdog on each rank abandons the leg at the same
         # deadline.  Rank 0 still prints the headline line it holds (with the partial train_step block), and then EVERY rank exits
