@@ -7,13 +7,17 @@
 //   tile     8 x 16 voxels of one plane; 4 waves, wave w = output channels 32w .. 32w+31 (2 N tiles) x all 128 voxels (8 M tiles of one
 //            16-voxel row): 64 accumulator registers, unit = 24 MFMAs (4 M tiles x 2 N tiles x 3 products) as in k_encoder_b16.
 //   ring     slot of plane p = (p + 1) % 3; 3 x 2 x 23,040 B = 138,240 B of LDS -> one workgroup (one wave per SIMD) per CU.  Plane z+2 is
-//            requested from HBM BEFORE output plane z's tap loop (48 registers per thread: one wave per SIMD has 512) and split + stored into
-//            the slot of plane z-1 behind it, between two barriers (about 3 % of a z step).
+//            requested from HBM BEFORE output plane z's taps (48 registers per thread: one wave per SIMD has 512) and its six staging items per
+//            thread are split and written into plane z-1's slot UNDER the MFMAs of the (kz = 1, 2) tap bodies, one item per body; the one
+//            barrier per plane sits after the kz = 0 taps (the last readers of plane z-1; it also publishes the previous plane's stores).
+//   loop     bodies of three taps (kx = 0, 1, 2 of one (kz, ky)): 12 units of 24 MFMAs, 6 32-k steps.  The next unit's 8 fragment reads are
+//            issued in the first 16 MFMAs of a unit (one wave per SIMD: nothing else hides LDS latency), lo fragments first.
 //   weights  the layer handle's pre-split layout [K/16][hi|lo][128][16] (K = 27 x 64, column tap * 64 + c), streamed from L2 through a ring
-//            of two 32-k steps exactly as k_linear_b16 does.
-//   output   zsum[y][x][o] = sum over z of relu(conv + bias): accumulated in 64 more registers in z order (deterministic), written once per
-//            tile; smk_pool3d_accumulate (one "plane") then forms the 32 x 32 token sums.  The activated conv2 output (8.6 GB per 512 x 512 x 64
-//            volume) is never written.
+//            of six slots (= a body's six steps, so slot indices are compile-time), each fragment requested M3_AHEAD = 3 steps early.
+//   output   zsum[y][x][o] = sum over z of relu(conv + bias): accumulators start at the bias, relu(acc) is added into 64 more registers in
+//            z order (deterministic), written once per tile; smk_pool3d_accumulate (one "plane") then forms the 32 x 32 token sums.  The
+//            activated conv2 output (8.6 GB per 512 x 512 x 64 volume) is never written.
+//   measured 48.9 k cycles per plane and workgroup for 41.5 k of MFMA issue (-DSMK_M3_STAMPS); 13.2 ms per volume at 1.7-1.95 GHz: power-limited.
 // Arithmetic: the split-bf16 x3 form (lo*hi + hi*lo + hi*hi, fp32 accumulation), taps in the order (kz, ky, kx) -- as the layer kernel.
 #include "conv3d.h"
 #include "linear.h"
