@@ -161,17 +161,23 @@ def test_full_network_on_volumes():
         assert rel_err(out[k].cpu().numpy(), ref[k].cpu().numpy()) < 1e-4, k
 
 
-def test_config4_full_size_volume_implicit_equals_explicit_gemm():
+def test_config4_full_size_volume_three_forms_agree():
     """One 512 x 512 x 64 volume (configs[4]'s size: 16.8 M voxels, conv1 output 4.3 GB, i.e. byte offsets past 2^32 inside the volume): the
-    implicit-GEMM convolutions (shifted addressing inside the layer kernel, 32-bit offsets per slab) against the explicit ones (patch matrix
-    from smk_conv3d_im2col -- checked exactly above -- times the plain layer kernel).  Two different data paths through the same arithmetic:
-    the features must agree to summation-order accuracy, and every token must be finite and non-trivial."""
+    z-marching kernels (per-plane buffer resources, 2,048 tile columns, the full 64-plane ring walk), the implicit-GEMM convolutions (shifted
+    addressing inside the layer kernel, 32-bit offsets per slab) and the explicit ones (patch matrix from smk_conv3d_im2col -- checked exactly
+    above -- times the plain layer kernel).  Three different data paths through the same arithmetic: the features must agree to
+    summation-order accuracy, and every token must be finite and non-trivial."""
     w = {k: torch.from_numpy(v) for k, v in _weights(11).items()}
     g = torch.Generator(device="cuda").manual_seed(4)
     vol = torch.rand(1, 64, 512, 512, device="cuda", generator=g)
     vol[0, :, 300:, :] = 0.0                                        # an empty region: zero activations and the volume's walls both occur
-    imp = HipEncoder3D(w)(vol)
+    enc = HipEncoder3D(w)
+    assert enc.conv2_mode == "march"
+    mar = enc(vol).clone()
+    del enc
+    imp = HipEncoder3D(w, conv2_mode="implicit")(vol).clone()
     exp = HipEncoder3D(w, conv2_mode="im2col", slab_bytes=1 << 30)(vol)
-    assert imp.shape == (1, 128, 32, 32) and torch.isfinite(imp).all()
+    assert mar.shape == (1, 128, 32, 32) and torch.isfinite(mar).all()
+    assert rel_err(mar.cpu().numpy(), exp.cpu().numpy()) < 1e-6
     assert rel_err(imp.cpu().numpy(), exp.cpu().numpy()) < 1e-6
-    assert float(imp.std()) > 0 and float((imp[0, :, :12] - imp[0, :, 20:]).abs().max()) > 0
+    assert float(mar.std()) > 0 and float((mar[0, :, :12] - mar[0, :, 20:]).abs().max()) > 0
