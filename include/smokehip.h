@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 12
+#define SMK_ABI_VERSION 13
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -426,6 +426,14 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
 int smk_attention(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
                   int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
                   void *stream);
+/* The same attention with a workspace: when the grid of smk_attention would leave most CUs idle (B * H * L / 128 workgroups: 64 at batch 1 of
+ * the model's shape), the keys of each query block are dealt to 2-8 workgroups whose partial (output, max, sum) states a second launch merges
+ * in split order (deterministic).  smk_attention_workspace_bytes: the bytes that split needs for this problem on the current device (0: no
+ * split would be made -- pass none).  A workspace that is null or too small, or a split-bf16 output, runs the unsplit kernel. */
+int64_t smk_attention_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t head_dim);
+int smk_attention_ws(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
+                     int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
+                     void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Training form of smk_attention (chaos_attention.py:102-112 under autograd, train.py:88-89): the same forward with fp32 output,
  * plus lse [B][L][H] = log2 sum_j 2^(scale * log2(e) * q_i.k_j) per (token, head) -- the softmax normaliser the backward

@@ -1067,6 +1067,17 @@ int smk_ffn_elementwise(int32_t op, const float *a, const float *b, float *out, 
 int smk_attention(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
                   int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
                   void *stream) {
+    return smk_attention_ws(q, k, v, out, B, L, H, head_dim, ldq, ldk, ldv, ldo, scale, out_format, nullptr, 0, stream);
+}
+
+int64_t smk_attention_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t head_dim) {
+    if (B < 1 || H < 1 || L < 128 || head_dim != 64 || L % 128 != 0) return 0;
+    return (int64_t)attention_workspace_bytes(B, L, H);
+}
+
+int smk_attention_ws(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
+                     int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
+                     void *workspace, int64_t workspace_bytes, void *stream) {
     SMK_REQUIRE(q && k && v && out, "null q/k/v/out");
     SMK_REQUIRE(B >= 1 && H >= 1 && L >= 128, "B >= 1, H >= 1, L >= 128");
     if (head_dim != 64 || L % 128 != 0) {
@@ -1085,6 +1096,11 @@ int smk_attention(const float *q, const float *k, const float *v, void *out, int
     a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo;
     a.B = B; a.L = L; a.H = H;
     a.scale_log2e = (float)(scale * 1.4426950408889634074);
+    if (workspace && out_format == SMK_FMT_F32) {            // enough for the split the launcher would choose, or none at all
+        const int64_t need = (int64_t)attention_workspace_bytes(B, L, H);
+        SMK_REQUIRE(((uintptr_t)workspace & 15) == 0, "16-byte aligned workspace");
+        if (need > 0 && workspace_bytes >= need) a.ws = (float *)workspace;
+    }
     return check_launch(launch_attention_x3(a, (hipStream_t)stream), "attention_x3");
 }
 

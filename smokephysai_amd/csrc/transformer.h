@@ -23,8 +23,14 @@ struct AttnArgs {
     float scale_log2e;                   // softmax scale * log2(e), folded into Q
     int o_split;                         // o in SMK_FMT_SPLIT_BF16 (dense rows)
     float *lse = nullptr;                // optional [B][L][H]: log2 of sum_j exp2(score_ij * scale * log2 e) -- saved for the backward
+    // small grids (fewer workgroups than CUs): the keys of one (batch, head, query block) are dealt to nsplit workgroups; each writes its
+    // un-normalised partial output and its (running max, sum) to the workspace, k_attention_combine merges them in split order
+    float *ws = nullptr;                 // [nsplit][B L][H 64] partial outputs, then [nsplit][B L][H][2] (max, sum); attention_workspace_bytes
+    int nsplit = 1;                      // set by the launcher
 };
 hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st);
+// bytes of workspace with which launch_attention_x3 splits the keys over workgroups for this problem on the current device (0: it would not)
+size_t attention_workspace_bytes(int B, int L, int H);
 
 // Backward of the same attention (autograd of chaos_attention.py:102-112 with the chaos term folded into q): dq, dk, dv from q, k, v,
 // the output gradient, the forward's log-sum-exp and delta = rowsum(dout * out).

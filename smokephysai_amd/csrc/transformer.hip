@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
     // 8 XCDs round-robin; needs gridDim.x % 8 == 0, else the plain order)
     const int vid = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int nqb = a.L / AT_QB;
-    const int qb = vid % nqb, bh = vid / nqb, head = bh % a.H, b = bh / a.H;
-    const int NT = a.L / AT_KV / KS, T0 = grp * NT;          // this wave group's key tiles: T0 .. T0 + NT - 1
+    const int split = vid % a.nsplit, vq = vid / a.nsplit;   // (nsplit > 1: the splits of one query block are neighbours on one XCD)
+    const int qb = vq % nqb, bh = vq / nqb, head = bh % a.H, b = bh / a.H;
+    const int NT = a.L / AT_KV / KS / a.nsplit, T0 = (split * KS + grp) * NT;          // this wave group's key tiles: T0 .. T0 + NT - 1
 
     // ---- Q fragments (B operand: column = query r, k = d 16s + 8hh + j), pre-scaled, split
     bf16x8 qh[4], ql[4];
@@ -333,6 +334,22 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const size_t orow = (size_t)b * a.L + qb * AT_QB + wave * 32 + r;
+    if (a.nsplit > 1) {   // this split's partial state: O un-normalised, (max, sum) in log2 units
+        const size_t rows = (size_t)a.B * a.L, prow = (size_t)split * rows + orow;
+        float *wp = a.ws + prow * ((size_t)a.H * 64) + head * 64 + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                *reinterpret_cast<float4 *>(wp + 32 * db + 8 * q4) =
+                    make_float4(oacc[db][4 * q4], oacc[db][4 * q4 + 1], oacc[db][4 * q4 + 2], oacc[db][4 * q4 + 3]);
+        if (hh == 0) {
+            float *ml = a.ws + (size_t)a.nsplit * rows * ((size_t)a.H * 64) + (prow * a.H + head) * 2;
+            ml[0] = m_run;
+            ml[1] = l_tot;
+        }
+        return;
+    }
     if (a.lse && hh == 0) a.lse[orow * a.H + head] = m_run + __builtin_amdgcn_logf(l_tot);      // v_log_f32 is log2
     if (a.o_split) {   // SMK_FMT_SPLIT_BF16: feature group (64 head + 32 db + 8 q4) / 8, this lane's half (4 hi | 4 lo)
         __bf16 *os = reinterpret_cast<__bf16 *>(a.o) + orow * (2 * (size_t)a.ldo) + (head * 8) * 16 + 4 * hh;
@@ -362,8 +379,59 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
                 make_float4(oacc[db][4 * q4] * inv, oacc[db][4 * q4 + 1] * inv, oacc[db][4 * q4 + 2] * inv, oacc[db][4 * q4 + 3] * inv);
 }
 
-hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
+// merge of the nsplit partial states of a split-key launch, in split order (deterministic): thread = (row, head, 4 consecutive d)
+__global__ __launch_bounds__(256) void k_attention_combine(const float *__restrict__ ws, float *__restrict__ o, float *__restrict__ lse,
+                                                           long long rows, int H, int ldo, int nsplit) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * H * 16) return;
+    const int q4 = (int)(idx & 15), head = (int)((idx >> 4) % H);
+    const long long row = (idx >> 4) / H;
+    const float *ml = ws + (size_t)nsplit * rows * ((size_t)H * 64);
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, ml[(((size_t)s * rows + row) * H + head) * 2]);
+    float l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+        const size_t prow = (size_t)s * rows + row;
+        const float w = __builtin_amdgcn_exp2f(ml[(prow * H + head) * 2] - m);
+        l += ml[(prow * H + head) * 2 + 1] * w;
+        const float4 p = *reinterpret_cast<const float4 *>(ws + prow * ((size_t)H * 64) + head * 64 + 4 * q4);
+        acc.x += p.x * w; acc.y += p.y * w; acc.z += p.z * w; acc.w += p.w * w;
+    }
+    const float inv = 1.0f / l;
+    *reinterpret_cast<float4 *>(o + row * ldo + head * 64 + 4 * q4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    if (lse && q4 == 0) lse[row * H + head] = m + __builtin_amdgcn_logf(l);
+}
+
+// how many workgroups share the keys of one query block: grows while the grid still fits one 512-thread workgroup per CU and every wave
+// group keeps at least one whole key tile
+static int attention_nsplit(int B, int L, int H, int num_cu) {
+    const int nwg = B * H * (L / AT_QB);
+    int n = 1;
+    while (n < 8 && nwg * n * 2 <= num_cu && (L / AT_KV) % (n * 2 * 2) == 0) n *= 2;
+    static int force = -1;
+    if (force < 0) { const char *sv = getenv("SMK_ATTN_SPLIT"); force = sv ? atoi(sv) : 0; }       // diagnostic: 1 = never split
+    return force == 1 ? 1 : n;
+}
+size_t attention_workspace_bytes(int B, int L, int H) {
+    const int n = attention_nsplit(B, L, H, device_num_cu());
+    return n > 1 ? (size_t)n * B * L * H * (64 + 2) * sizeof(float) : 0;
+}
+
+hipError_t launch_attention_x3(const AttnArgs &a0, hipStream_t st) {
     const int num_cu = device_num_cu();
+    AttnArgs a = a0;
+    a.nsplit = (a.ws && !a.o_split) ? attention_nsplit(a.B, a.L, a.H, num_cu) : 1;
+    if (a.nsplit > 1) {
+        once_per_device((const void *)k_attention_x3<2>, [&] {
+            (void)hipFuncSetAttribute((const void *)k_attention_x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS);
+        });
+        const long long rows = (long long)a.B * a.L;
+        hipLaunchKernelGGL(k_attention_x3<2>, dim3(a.B * a.H * (a.L / AT_QB) * a.nsplit), dim3(512), 2 * AT_LDS, st, a);
+        hipLaunchKernelGGL(k_attention_combine, dim3((unsigned)((rows * a.H * 16 + 255) / 256)), dim3(256), 0, st, a.ws, a.o, a.lse, rows, a.H,
+                           a.ldo, a.nsplit);
+        return hipGetLastError();
+    }
     once_per_device((const void *)k_attention_x3<1>, [&] {
         (void)hipFuncSetAttribute((const void *)k_attention_x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
         (void)hipFuncSetAttribute((const void *)k_attention_x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS);

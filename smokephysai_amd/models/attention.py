@@ -31,13 +31,19 @@ def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: 
     ld_max = max(q.stride(1), k.stride(1), v.stride(1), ldo)
     bmax = max(1, (MAX_QKV_ELEMS - 1) // (L * ld_max))       # larger batches go in batch chunks (independent problems)
     o_batch_bytes = L * D * 4 if out_split else out.stride(0) * 4
+    L_ = _lib.load()
+    # small batches (one frame: 64 workgroups for 256 CUs): the keys are split over workgroups and merged by a second launch; the library
+    # says how much workspace that takes for this problem (0: it would not split)
+    ws_bytes = 0 if out_split else int(L_.smk_attention_workspace_bytes(min(B, bmax), L, num_heads, d))
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes > 0 else None
     b0 = 0
     while b0 < B:
         nb = min(bmax, B - b0)
-        _lib.check(_lib.load().smk_attention(q.data_ptr() + b0 * q.stride(0) * 4, k.data_ptr() + b0 * k.stride(0) * 4,
-                                            v.data_ptr() + b0 * v.stride(0) * 4, out.data_ptr() + b0 * o_batch_bytes, nb, L,
-                                            num_heads, d, q.stride(1), k.stride(1), v.stride(1), ldo, float(scale),
-                                            int(out_split), _lib.stream_ptr(dev)))
+        _lib.check(L_.smk_attention_ws(q.data_ptr() + b0 * q.stride(0) * 4, k.data_ptr() + b0 * k.stride(0) * 4,
+                                       v.data_ptr() + b0 * v.stride(0) * 4, out.data_ptr() + b0 * o_batch_bytes, nb, L,
+                                       num_heads, d, q.stride(1), k.stride(1), v.stride(1), ldo, float(scale),
+                                       int(out_split), ws.data_ptr() if ws is not None and nb == min(B, bmax) else None, ws_bytes,
+                                       _lib.stream_ptr(dev)))
         b0 += nb
     return out
 

@@ -260,6 +260,11 @@ class SmokePhysNet(nn.Module):
         chaos-gate chain on smk_chaos_addend, LayerNorm on smk_layernorm.  Returns (features [B,L,D], decoded [B,L,C])."""
         B, L, _ = tokens.shape
         body = self._hip_body
+        if chaos_noise is None:
+            # every layer's three randn(B, 1) draws (chaos_attention.py:50-52) as ONE generator launch: drawn per layer they are 18 launches
+            # plus 18 device copies per forward (randn into a view goes through a temporary) -- 0.11 ms of a 0.77 ms batch-1 forward.  Still
+            # standard-normal and fresh per call; only the position in the generator's stream differs from per-layer draws.
+            chaos_noise = torch.randn(len(self.chaos_layers), 3, B, 1, device=tokens.device, dtype=torch.float32)
         x = body.linear("feature_proj", self.feature_proj)(tokens, periodic_add=self._pos_embed(pool_size),
                                                            rows_per_group=B * L)
         for li, layer in enumerate(self.chaos_layers):

@@ -66,6 +66,35 @@ def test_attention_matches_fp64_softmax_attention(B, L, H, spread, tol):
     assert e_hip < tol, (e_hip, e_sdpa)
 
 
+@pytest.mark.parametrize("B,L,H", [(1, 1024, 8), (2, 1024, 8), (1, 512, 8), (1, 2048, 2)])
+def test_attention_split_keys_for_small_grids(B, L, H, monkeypatch):
+    """Grids that would leave most CUs idle (one frame of the model's shape: 64 workgroups) deal the keys of a query block to several
+    workgroups and merge their (output, max, sum) states in a second launch: against the fp64 reference, against the unsplit kernel
+    (SMK_ATTN_SPLIT=1 is read once per process, so the unsplit result comes from the workspace-less entry point), and run to run."""
+    from smokephysai_amd import _lib
+    from smokephysai_amd.models.attention import hip_attention
+    Lh = _lib.load()
+    ws = int(Lh.smk_attention_workspace_bytes(B, L, H, 64))
+    assert ws > 0, "this shape is expected to split on a 256-CU device"
+    assert int(Lh.smk_attention_workspace_bytes(64, 1024, 8, 64)) == 0          # the full batch fills the chip: no split
+    g = torch.Generator(device="cuda").manual_seed(B * 7 + L + H)
+    D = H * 64
+    q = torch.randn(B, L, D, device="cuda", generator=g) * 2.0
+    k = torch.randn(B, L, D, device="cuda", generator=g)
+    k[:, :, :] *= torch.linspace(0.2, 2.0, L, device="cuda")[None, :, None]      # later keys score higher: the splits' maxima differ
+    v = torch.randn(B, L, D, device="cuda", generator=g)
+    out = hip_attention(q, k, v, H, 0.125)
+    ref = _attention_ref(q, k, v, H, 0.125)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 5e-5
+    plain = torch.empty_like(out)
+    _lib.check(Lh.smk_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), plain.data_ptr(), B, L, H, 64, D, D, D, D, 0.125, 0,
+                                _lib.stream_ptr(q.device)))
+    # against the unsplit kernel: the probabilities are formed relative to different running maxima before their bf16 split, so the two
+    # agree to the arithmetic's accuracy (a few 1e-6), not bit for bit
+    assert rel_err(out.cpu().numpy(), plain.cpu().numpy()) < 1e-5
+    assert torch.equal(out, hip_attention(q, k, v, H, 0.125))                     # fixed merge order: deterministic
+
+
 def test_attention_reads_strided_qkv_and_rejects_other_head_dims():
     from smokephysai_amd.models.attention import hip_attention, hip_attention_supported
     g = torch.Generator(device="cuda").manual_seed(5)
