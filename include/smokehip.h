@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 13
+#define SMK_ABI_VERSION 14
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -330,6 +330,24 @@ int smk_conv3d_cl_zsum_forward(smk_linear *lin, const float *src, int32_t D, int
  * 448 = 7 kz x 8 ky slots x 8 kx slots, weight column (kz*8 + ky)*8 + kx (slot 7 of ky and of kx zero), out_features = 64.
  * H % 8 == 0, W % 16 == 0, H * W * 256 < 2^31. */
 int smk_conv3d_s7_march_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, float *a1, int32_t activation, void *stream);
+
+/* smk_chaos_addend for up to 8 layers in ONE launch (a model's layers draw their noise up front; six launches of one workgroup per batch
+ * element are six launch latencies at batch 1).  Each layer: its own noise [3][B], weights, output and strength; B, D and the Lorenz constants
+ * are shared. */
+typedef struct smk_chaos_layer {
+    const float *noise, *proj_w, *proj_b, *gate_w, *gate_b;
+    float *addend;
+    int64_t ld_addend;
+    double strength;
+} smk_chaos_layer;
+int smk_chaos_addend_batched(int32_t n_layers, const smk_chaos_layer *layers, int32_t B, int32_t D, double sigma, double rho, double beta,
+                             double dt, void *stream);
+
+/* SmokePhysNet's tail (smokephys_net.py:116-118): pooled [B][D] = features.mean(dim=1) of x [B][L][ldx] and out [B][H2] =
+ * Linear2(ReLU(Linear1(pooled))) with w1 [H1][D], w2 [H2][H1] (row-major, nn.Linear layout), in two launches instead of PyTorch-ROCm's
+ * seven (reduce, two GEMM calls with their bias copies, ReLU, fill).  workspace: B * 32 * D floats.  fp32, fixed summation order. */
+int smk_pooled_head(const float *x, int32_t B, int32_t L, int32_t D, int64_t ldx, const float *w1, const float *b1, int32_t H1,
+                    const float *w2, const float *b2, int32_t H2, float *pooled, float *out, float *workspace, void *stream);
 
 /* ChaosAttention.generate_chaos_field's five explicit-Euler Lorenz states (chaos_attention.py:39-59) for noise [3][B] (the three
  * randn(B,1) draws before the 0.1 scale): states [B][5][3].  The gradient-free part of the chaos term, for the training path. */

@@ -7,7 +7,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMOKEHIP_LIB") or os.path.join(_HERE, "libsmokehip.so")   # SMOKEHIP_LIB: diagnostic builds only
 
-ABI_VERSION = 13                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
+ABI_VERSION = 14                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
 SMK_ERR_TIMEOUT = -5
 SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
 SMK_ACT_NONE, SMK_ACT_GELU, SMK_ACT_RELU = 0, 1, 2
@@ -99,6 +99,9 @@ _SIGNATURES = {
                          C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p],
     "smk_attention": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                       C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_void_p],
+    "smk_chaos_addend_batched": [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p],
+    "smk_pooled_head": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_attention_ws": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                          C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p],
     "smk_attention_forward_lse": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -134,6 +137,12 @@ _SIGNATURES = {
 EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace", "smk_conv2_train_workspace", "smk_conv2_train_wgrad_workspace", "smk_conv1_train_wgrad_workspace", "smk_attention_workspace_bytes"] + list(_SIGNATURES)
 
 _lib = None
+
+
+class SmkChaosLayer(C.Structure):
+    """smk_chaos_layer (include/smokehip.h)."""
+    _fields_ = [("noise", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("gate_w", C.c_void_p), ("gate_b", C.c_void_p),
+                ("addend", C.c_void_p), ("ld_addend", C.c_int64), ("strength", C.c_double)]
 
 
 class SmokeHipError(RuntimeError):

@@ -1036,6 +1036,37 @@ int smk_chaos_addend(const float *noise, int32_t B, int32_t D, const float *proj
     return check_launch(launch_chaos_addend(a, (hipStream_t)stream), "chaos_addend");
 }
 
+int smk_chaos_addend_batched(int32_t n_layers, const smk_chaos_layer *layers, int32_t B, int32_t D, double sigma, double rho, double beta,
+                             double dt, void *stream) {
+    SMK_REQUIRE(layers && n_layers >= 1 && n_layers <= 8, "1 .. 8 layers");
+    SMK_REQUIRE(B >= 1 && D >= 1, "B >= 1, D >= 1");
+    ChaosAddendBatch a;
+    a.NL = n_layers;
+    for (int i = 0; i < n_layers; ++i) {
+        const smk_chaos_layer &l = layers[i];
+        SMK_REQUIRE(l.noise && l.proj_w && l.proj_b && l.gate_w && l.gate_b && l.addend, "null pointer in a layer");
+        SMK_REQUIRE(l.ld_addend >= D && l.ld_addend < (1LL << 30), "ld_addend >= D");
+        ChaosAddendArgs &x = a.layer[i];
+        x.noise = l.noise; x.proj_w = l.proj_w; x.proj_b = l.proj_b; x.gate_w = l.gate_w; x.gate_b = l.gate_b; x.addend = l.addend;
+        x.B = B; x.D = D; x.ld = (int)l.ld_addend;
+        x.strength = (float)l.strength; x.sigma = (float)sigma; x.rho = (float)rho; x.beta = (float)beta; x.dt = (float)dt;
+    }
+    for (int i = n_layers; i < 8; ++i) a.layer[i] = a.layer[0];
+    return check_launch(launch_chaos_addend_batch(a, (hipStream_t)stream), "chaos_addend_batch");
+}
+
+int smk_pooled_head(const float *x, int32_t B, int32_t L, int32_t D, int64_t ldx, const float *w1, const float *b1, int32_t H1,
+                    const float *w2, const float *b2, int32_t H2, float *pooled, float *out, float *workspace, void *stream) {
+    SMK_REQUIRE(x && w1 && b1 && w2 && b2 && pooled && out && workspace, "null pointer");
+    SMK_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D >= 1 && H1 >= 1 && H2 >= 1 && ldx >= D, "B in 1 .. 65535, L, D, H1, H2 >= 1, ldx >= D");
+    SMK_REQUIRE((int64_t)(D + H1) * 4 <= 64 * 1024 && D % 4 == 0, "D + H1 <= 16,384 (the pooled vector and the hidden layer sit in LDS), D % 4 == 0");
+    SMK_REQUIRE(((uintptr_t)w1 & 15) == 0, "16-byte aligned w1");
+    PooledHeadArgs a;
+    a.x = x; a.ldx = ldx; a.B = B; a.L = L; a.D = D; a.w1 = w1; a.b1 = b1; a.H1 = H1; a.w2 = w2; a.b2 = b2; a.H2 = H2;
+    a.pooled = pooled; a.out = out; a.ws = workspace;
+    return check_launch(launch_pooled_head(a, (hipStream_t)stream), "pooled_head");
+}
+
 int smk_lorenz_states(const float *noise, int32_t B, double sigma, double rho, double beta, double dt, float *states, void *stream) {
     SMK_REQUIRE(noise && states && B >= 1, "null noise / states or B < 1");
     return check_launch(launch_lorenz_states(noise, B, (float)sigma, (float)rho, (float)beta, (float)dt, states, (hipStream_t)stream), "lorenz_states");

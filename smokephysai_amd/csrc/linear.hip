@@ -139,7 +139,11 @@ struct LinearArgs {
 // KS > 1 (small problems only: fewer tiles than the chip has workgroup slots): KS wave groups of NW waves share one output tile, each
 // walking 1/KS of the K range with its own LDS chunk stream; the partial sums are merged through LDS in fixed group order
 // (deterministic, no atomics) and group 0 runs the epilogue.
-template <int MB, int NW, bool AS, int KS = 1>
+// RING: weight fragments in flight, in 16-k steps (default LN_RING = 4: three steps ahead -- enough when other waves cover an L2 round
+// trip).  The one-tile-per-workgroup problems of a single frame (M = 1,024, MB = 1: a k-step is 3 MFMAs = 96 cycles) are bound by exactly
+// that round trip -- 32 k-steps x ~0.3 us = the 10 us such a layer took -- so they run RING = 16 (fifteen steps = ~1 us ahead; the chunk loop
+// is unrolled RING / 4 times so that the slot indices stay compile-time; needs K % (16 RING) == 0).
+template <int MB, int NW, bool AS, int KS = 1, int RING = LN_RING>
 __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(const LinearArgs a) {
     constexpr int TN = NW * 32, RP = AS ? NW * 8 : NW * 4;   // tile columns; rows staged per pass (fp32: 16 float4 per row chunk; split: 8 x 32 B)
     constexpr bool sched = SMK_LINEAR_SCHED;
@@ -185,9 +189,9 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_b, ((LN_DBG(a, 2) ? 0 : kn + k_off) * 2 + part) * frag_bytes, 0);
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
-    uint4 bqh[LN_RING], bql[LN_RING];
+    uint4 bqh[RING], bql[RING];
 #pragma unroll
-    for (int k = 0; k < LN_RING - 1; ++k) {
+    for (int k = 0; k < RING - 1; ++k) {
         bqh[k] = load_b(k, 0);
         bql[k] = load_b(k, 1);
     }
@@ -290,9 +294,10 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
             for (int g = 0; g < 16; ++g) acc[mi][g] = 0.f;
 
 #pragma unroll 1
-        for (int c = 0; c < nchunks; ++c) {
+        for (int c0 = 0; c0 < nchunks; c0 += RING / 4) {
             auto kstep = [&](auto U) {
-                constexpr int u = decltype(U)::value;
+                constexpr int pu = decltype(U)::value, u = pu & 3;        // pu: k-step within the unrolled group of RING / 4 chunks
+                const int c = c0 + (pu >> 2);
 #ifdef SMK_LN_STAMPS
                 LN_STAMP(t_u);
                 if (u > 0) sum_u[u - 1] += t_u - t_prev;
@@ -300,11 +305,11 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                 t_prev = t_u;
 #endif
                 {   // refill the ring slot consumed one k-step ago (k index wraps: the next tile uses the same weights)
-                    int kn = c * 4 + u + LN_RING - 1;
+                    int kn = c * 4 + u + RING - 1;
                     kn = kn >= nks ? kn - nks : kn;
                     kn = __builtin_amdgcn_readfirstlane(kn);
-                    bqh[(u + LN_RING - 1) % LN_RING] = load_b(kn, 0);
-                    bql[(u + LN_RING - 1) % LN_RING] = load_b(kn, 1);
+                    bqh[(pu + RING - 1) % RING] = load_b(kn, 0);
+                    bql[(pu + RING - 1) % RING] = load_b(kn, 1);
                 }
                 // The staged registers hold the chunk after this one: k-steps 0..2 each split + write a share of its 2*MB
                 // pieces to the other buffer (last read before the previous chunk's barrier; complete before this chunk's) and
@@ -326,8 +331,8 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
 #endif
                 if (u & 1) load_a(u == 3 ? buf ^ 1 : buf, (u + 1) & 3, ahA, alA);
                 else load_a(buf, u + 1, ahB, alB);
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, bqh[u]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, bql[u]);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bqh[pu % RING]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, bql[pu % RING]);
                 // product-major emission: consecutive MFMAs go to different accumulators; each still sums lo*hi, hi*lo, hi*hi in order
 #pragma unroll
                 for (int mi = 0; mi < MB; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, (u & 1) ? alB[mi] : alA[mi], acc[mi], 0, 0, 0);
@@ -364,11 +369,20 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            kstep(std::integral_constant<int, 0>{});
-            kstep(std::integral_constant<int, 1>{});
-            kstep(std::integral_constant<int, 2>{});
-            kstep(std::integral_constant<int, 3>{});
-            buf ^= 1;
+            auto chunk = [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                kstep(std::integral_constant<int, 4 * j>{});
+                kstep(std::integral_constant<int, 4 * j + 1>{});
+                kstep(std::integral_constant<int, 4 * j + 2>{});
+                kstep(std::integral_constant<int, 4 * j + 3>{});
+                buf ^= 1;
+            };
+            chunk(std::integral_constant<int, 0>{});
+            if constexpr (RING >= 8) chunk(std::integral_constant<int, 1>{});
+            if constexpr (RING >= 16) {
+                chunk(std::integral_constant<int, 2>{});
+                chunk(std::integral_constant<int, 3>{});
+            }
         }
 
 #ifdef SMK_LN_STAMPS
@@ -508,11 +522,11 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
 #endif
 }
 
-template <int MB, int NW, bool AS, int KS = 1>
+template <int MB, int NW, bool AS, int KS = 1, int RING = LN_RING>
 static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     constexpr int lds = KS * ln_lds_bytes<MB, NW>() + (KS - 1) * NW * 64 * MB * 16 * 4;
-    once_per_device((const void *)k_linear_x3<MB, NW, AS, KS>, [&] {
-        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    once_per_device((const void *)k_linear_x3<MB, NW, AS, KS, RING>, [&] {
+        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS, KS, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const int nseg = a.c.nseg;
     const int nwg_max = (NW == 8 || KS > 1 ? 1 : 2) * a.num_cu / nseg;     // 8 waves per CU either way (split-K: one workgroup per CU)
@@ -530,7 +544,7 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     // one tile ~ (K/64) chunks x ~4.2 K cycles + ~9 K epilogue; s_sleep(127) ~ 8 K cycles
     b.stagger_unit = stg_env > 1 ? (int)(((a.l.K / 64) * 4200 + 9000) / 8128 / stg_env) : 0;
     if (b.stagger_unit < 1) b.stagger = 0;
-    hipLaunchKernelGGL((k_linear_x3<MB, NW, AS, KS>), dim3((unsigned)nwg), dim3(NW * 64 * KS), lds, st, b);
+    hipLaunchKernelGGL((k_linear_x3<MB, NW, AS, KS, RING>), dim3((unsigned)nwg), dim3(NW * 64 * KS), lds, st, b);
     return hipGetLastError();
 }
 
@@ -989,9 +1003,14 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
             // 512 tiles already on the chip a split only adds the merge (+15 %)
             if (tiles * c.nseg <= num_cu / 2 && nch % 4 == 0 && nch >= 16) ks = 4;
             if (force_ks == 1 || ((force_ks == 2 || force_ks == 4) && nch % force_ks == 0 && nch / force_ks >= 1)) ks = force_ks;
+            // one tile per workgroup (a single frame's layers): the deep weight ring (see k_linear_x3) when K allows it
+            static int deep = -1;
+            if (deep < 0) { const char *sv = getenv("SMK_LINEAR_DEEP"); deep = sv ? atoi(sv) : 1; }
+            const bool dr = deep && (nch / ks) % 4 == 0 && tiles * c.nseg <= 2 * num_cu;
+            // (not with four wave groups: 1,024 threads leave 128 registers per wave, and the 16-slot ring then spills)
             if (ks == 4) e = launch_mb<1, 4, false, 4>(a, st);
             else if (ks == 2) e = launch_mb<1, 4, false, 2>(a, st);
-            else e = launch_mb<1, 4, false>(a, st);
+            else e = dr ? launch_mb<1, 4, false, 1, 16>(a, st) : launch_mb<1, 4, false>(a, st);
         }
     }
 #ifdef SMK_LN_STAMPS

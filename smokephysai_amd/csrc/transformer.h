@@ -12,6 +12,23 @@ struct ChaosAddendArgs {
     float strength, sigma, rho, beta, dt;
 };
 hipError_t launch_chaos_addend(const ChaosAddendArgs &a, hipStream_t st);
+// the addends of up to 8 layers (each with its own noise, weights and output) as ONE launch: grid (B, layers)
+struct ChaosAddendBatch { int NL; ChaosAddendArgs layer[8]; };
+hipError_t launch_chaos_addend_batch(const ChaosAddendBatch &a, hipStream_t st);
+
+// SmokePhysNet's tail behind the transformer (smokephys_net.py:116-118): latent = features.mean(dim=1), physics = Linear(ReLU(Linear(latent))).
+// Two launches: per-chunk token sums ([B][32 chunks][D] workspace), then per batch element the chunk sums in order, the mean and the
+// two small matrix-vector products (a wave per output row, lanes along the input: coalesced weight reads, fixed summation order).
+struct PooledHeadArgs {
+    const float *x; long long ldx;       // features [B][L][ldx], D columns used
+    int B, L, D;
+    const float *w1, *b1; int H1;        // [H1][D], [H1]
+    const float *w2, *b2; int H2;        // [H2][H1], [H2]
+    float *pooled;                       // [B][D]
+    float *out;                          // [B][H2]
+    float *ws;                           // [B][32][D]
+};
+hipError_t launch_pooled_head(const PooledHeadArgs &a, hipStream_t st);
 // the five Lorenz states [B][5][3] of the same noise (no projection / gate)
 hipError_t launch_lorenz_states(const float *noise, int B, float sigma, float rho, float beta, float dt, float *states, hipStream_t st);
 

@@ -8,9 +8,9 @@ namespace smk {
 // state s_t gives C_t = chaos_proj(s_t) [D], g_t = sigmoid(chaos_gate(C_t)) and the addend strength * g_t * C_t that row
 // l = t (mod 5) of the sequence adds to its query.  In the reference this is ~90 one-element-per-batch elementwise
 // launches per layer; here one workgroup per batch element.  fp32 with the reference's operation order (no contraction).
-__global__ __launch_bounds__(256) void k_chaos_addend(const ChaosAddendArgs a) {
+__device__ __forceinline__ void chaos_addend_body(const ChaosAddendArgs &a, const int b) {
     __shared__ float red[5][4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float x = a.noise[b] * 0.1f, y = a.noise[a.B + b] * 0.1f, z = a.noise[2 * a.B + b] * 0.1f;
     float sx[5], sy[5], sz[5];
 #pragma unroll
@@ -51,6 +51,76 @@ __global__ __launch_bounds__(256) void k_chaos_addend(const ChaosAddendArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_chaos_addend(const ChaosAddendArgs a) { chaos_addend_body(a, blockIdx.x); }
+// every layer's addend in one launch (the layers' noise is drawn up front: smokephys_net.py, _body_hip): blockIdx.y = layer
+__global__ __launch_bounds__(256) void k_chaos_addend_batch(const ChaosAddendBatch args) { chaos_addend_body(args.layer[blockIdx.y], blockIdx.x); }
+
+// ---- the model's tail: token mean + physics head (see transformer.h)
+constexpr int PH_CHUNKS = 32;
+__global__ __launch_bounds__(256) void k_token_chunk_sums(const PooledHeadArgs a) {
+    const int b = blockIdx.x, ch = blockIdx.y;
+    const int per = (a.L + PH_CHUNKS - 1) / PH_CHUNKS, l0 = ch * per, l1 = l0 + per < a.L ? l0 + per : a.L;
+    for (int d = threadIdx.x; d < a.D; d += 256) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int l = l0; l < l1; ++l) s += a.x[((size_t)b * a.L + l) * a.ldx + d];
+        a.ws[((size_t)b * PH_CHUNKS + ch) * a.D + d] = s;
+    }
+}
+__global__ __launch_bounds__(256) void k_pooled_head(const PooledHeadArgs a) {
+    extern __shared__ float ph_smem[];                       // pooled [D] | hidden [H1]
+    float *pooled = ph_smem, *hid = ph_smem + a.D;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int d = tid; d < a.D; d += 256) {
+        float s = 0.f;
+        for (int ch = 0; ch < PH_CHUNKS; ++ch) s += a.ws[((size_t)b * PH_CHUNKS + ch) * a.D + d];
+        s = s / (float)a.L;
+        pooled[d] = s;
+        a.pooled[(size_t)b * a.D + d] = s;
+    }
+    __syncthreads();
+    // hidden layer: a wave per output row, lanes along the input (coalesced 16-byte weight reads), EIGHT rows in flight per wave -- one
+    // row at a time is a chain of load -> reduce round trips (64 of them per wave: 0.1 ms for a 512 KB matrix)
+    const int dq = a.D >> 2;                                 // float4 per row (D % 4 == 0: api.hip)
+    for (int j0 = wave * 8; j0 < a.H1; j0 += 32) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int q = lane; q < dq; q += 64) {
+            const float4 pv = *reinterpret_cast<const float4 *>(pooled + 4 * q);
+            float4 wv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int j = j0 + r < a.H1 ? j0 + r : a.H1 - 1;
+                wv[r] = *reinterpret_cast<const float4 *>(a.w1 + (size_t)j * a.D + 4 * q);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s[r] += ((wv[r].x * pv.x + wv[r].y * pv.y) + wv[r].z * pv.z) + wv[r].w * pv.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float v = s[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && j0 + r < a.H1) {
+                v += a.b1[j0 + r];
+                hid[j0 + r] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = wave; k < a.H2; k += 4) {
+        float s = 0.f;
+        for (int j = lane; j < a.H1; j += 64) s += a.w2[(size_t)k * a.H1 + j] * hid[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) a.out[(size_t)b * a.H2 + k] = s + a.b2[k];
+    }
+}
+hipError_t launch_pooled_head(const PooledHeadArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(k_token_chunk_sums, dim3(a.B, PH_CHUNKS), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pooled_head, dim3(a.B), dim3(256), (size_t)(a.D + a.H1) * sizeof(float), st, a);
+    return hipGetLastError();
+}
+
 // The five Lorenz states alone ([B][5][3]; chaos_attention.py:39-59): the part of the chaos term that carries no gradient, for the
 // training path (chaos_proj / chaos_gate then run under autograd on a [B, 5, 3] tensor instead of behind ~75 one-element launches).
 __global__ __launch_bounds__(64) void k_lorenz_states(const float *__restrict__ noise, int B, float sigma, float rho, float beta, float dt,
@@ -78,6 +148,10 @@ hipError_t launch_lorenz_states(const float *noise, int B, float sigma, float rh
 
 hipError_t launch_chaos_addend(const ChaosAddendArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_chaos_addend, dim3(a.B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_chaos_addend_batch(const ChaosAddendBatch &a, hipStream_t st) {
+    hipLaunchKernelGGL(k_chaos_addend_batch, dim3(a.layer[0].B, a.NL), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

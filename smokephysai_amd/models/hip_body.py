@@ -68,9 +68,42 @@ class HipBody:
         lins = [a.q_proj, a.k_proj, a.v_proj, a.out_proj, layer.ffn[0], layer.ffn[3]]
         return all(hip_linear_supported(m.in_features, m.out_features) for m in lins)
 
-    def layer(self, name: str, layer, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _addend_buffer(self, name: str, B: int, D: int, device) -> torch.Tensor:
+        add15 = self.addend_bufs.get((name, B))
+        if add15 is None or add15.device != device:         # the k|v columns stay zero, the q columns are rewritten per call
+            add15 = self.addend_bufs[(name, B)] = torch.zeros(B, 5, 3 * D, device=device)
+        return add15
+
+    def chaos_addends(self, names, layers, noise_all: torch.Tensor, B: int, device) -> bool:
+        """Every layer's chaos addend (chaos_attention.py:39-66, 85-100) in ONE launch (smk_chaos_addend_batched) into the layers' addend
+        buffers; noise_all [num_layers, 3, B, 1].  False (nothing done) when the layers do not share dim / Lorenz constants or are more than 8."""
+        from .. import _lib
+        atts = [l.chaos_attention for l in layers]
+        if not (1 <= len(atts) <= 8) or noise_all.shape[0] != len(atts):
+            return False
+        D = atts[0].dim
+        consts = [(float(a.lorenz_sigma), float(a.lorenz_rho), float(a.lorenz_beta)) if a._lorenz_host is None else a._lorenz_host for a in atts]
+        for a, c in zip(atts, consts):
+            a._lorenz_host = c
+        if any(a.dim != D for a in atts) or any(c != consts[0] for c in consts):
+            return False
+        n = noise_all.to(device, torch.float32).reshape(len(atts), 3, B).contiguous()
+        arr = (_lib.SmkChaosLayer * len(atts))()
+        for i, (name, a) in enumerate(zip(names, atts)):
+            w, g = a.chaos_proj.weight, a.chaos_gate.weight
+            if not (w.is_contiguous() and g.is_contiguous()):
+                return False
+            buf = self._addend_buffer(name, B, D, device)
+            arr[i] = _lib.SmkChaosLayer(n[i].data_ptr(), w.data_ptr(), a.chaos_proj.bias.data_ptr(), g.data_ptr(), a.chaos_gate.bias.data_ptr(),
+                                        buf.data_ptr(), buf.shape[2], float(a.chaos_strength))
+        import ctypes
+        sg, rh, bt = consts[0]
+        _lib.check(_lib.load().smk_chaos_addend_batched(len(atts), ctypes.cast(arr, ctypes.c_void_p), B, D, sg, rh, bt, 0.01, _lib.stream_ptr(device)))
+        return True
+
+    def layer(self, name: str, layer, x: torch.Tensor, noise: Optional[torch.Tensor] = None, addend_ready: bool = False) -> torch.Tensor:
         """One ChaosTransformerLayer, eval mode, IN PLACE on x [B,L,D] (the residual stream).  noise: the layer's three
-        randn(B,1) draws [3,B,1] or None to draw them like the reference does."""
+        randn(B,1) draws [3,B,1] or None to draw them like the reference does.  addend_ready: chaos_addends() has filled this layer's buffer."""
         B, L, D = x.shape
         att = layer.chaos_attention
         H, d = att.num_heads, att.head_dim
@@ -79,10 +112,9 @@ class HipBody:
         # Measured neutral on MI355X (the K loop is not bound by the split arithmetic: DESIGN.md 3.3), so it is off by default.
         sp = self.split_activations and D % 8 == 0 and layer.ffn[0].out_features % 8 == 0
         h = self.layernorm(x, layer.norm1, out_split=sp)
-        add15 = self.addend_bufs.get((name, B))
-        if add15 is None or add15.device != x.device:       # the k|v columns stay zero, the q columns are rewritten per call
-            add15 = self.addend_bufs[(name, B)] = torch.zeros(B, 5, 3 * D, device=x.device)
-        att.chaos_addend_hip(B, x.device, noise, out=add15)
+        add15 = self._addend_buffer(name, B, D, x.device)
+        if not addend_ready:
+            att.chaos_addend_hip(B, x.device, noise, out=add15)
         qkv = self.qkv(name + "chaos_attention.qkv", att)(h, periodic_add=add15, rows_per_group=L, x_split=sp)
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         scale = 1.0 / (math.sqrt(d) * att.temperature)

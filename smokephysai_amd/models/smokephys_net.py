@@ -267,11 +267,36 @@ class SmokePhysNet(nn.Module):
             chaos_noise = torch.randn(len(self.chaos_layers), 3, B, 1, device=tokens.device, dtype=torch.float32)
         x = body.linear("feature_proj", self.feature_proj)(tokens, periodic_add=self._pos_embed(pool_size),
                                                            rows_per_group=B * L)
+        names = [f"chaos_layers.{li}." for li in range(len(self.chaos_layers))]
+        ready = body.chaos_addends(names, list(self.chaos_layers), chaos_noise, B, tokens.device)        # all layers' chaos terms: one launch
         for li, layer in enumerate(self.chaos_layers):
-            body.layer(f"chaos_layers.{li}.", layer, x, None if chaos_noise is None else chaos_noise[li])
+            body.layer(names[li], layer, x, chaos_noise[li], addend_ready=ready)
         dec = body.linear("output_decoder.0", self.output_decoder[0])(x, activation="relu")
         dec = body.linear("output_decoder.2", self.output_decoder[2])(dec)
         return x, dec
+
+    def _hip_tail_ok(self, features: torch.Tensor) -> bool:
+        h = self.physics_head
+        return (self.linear_dtype == "bf16x3" and not self.training and not torch.is_grad_enabled() and features.is_cuda
+                and features.dtype == torch.float32 and features.dim() == 3 and features.stride(2) == 1
+                and features.stride(0) == features.shape[1] * features.stride(1) and features.shape[0] <= 65535
+                and len(h) == 3 and type(h[0]) is nn.Linear and type(h[1]) is nn.ReLU and type(h[2]) is nn.Linear
+                and h[0].bias is not None and h[2].bias is not None and h[0].in_features == features.shape[2]
+                and h[0].in_features + h[0].out_features <= 16384 and h[0].in_features % 4 == 0 and h[0].weight.data_ptr() % 16 == 0
+                and all(p.is_contiguous() and p.dtype == torch.float32 and p.device == features.device for p in h.parameters()))
+
+    def _tail_hip(self, features: torch.Tensor):
+        """smokephys_net.py:116-118 -- latent = features.mean(dim=1); physics = physics_head(latent) -- as smk_pooled_head (fp32)."""
+        from .. import _lib
+        B, L, D = features.shape
+        l1, l2 = self.physics_head[0], self.physics_head[2]
+        pooled = torch.empty(B, D, device=features.device, dtype=torch.float32)
+        out = torch.empty(B, l2.out_features, device=features.device, dtype=torch.float32)
+        ws = torch.empty(B * 32 * D, device=features.device, dtype=torch.float32)
+        _lib.check(_lib.load().smk_pooled_head(features.data_ptr(), B, L, D, features.stride(1), l1.weight.data_ptr(), l1.bias.data_ptr(),
+                                               l1.out_features, l2.weight.data_ptr(), l2.bias.data_ptr(), l2.out_features, pooled.data_ptr(),
+                                               out.data_ptr(), ws.data_ptr(), _lib.stream_ptr(features.device)))
+        return pooled, out
 
     def _hip_body_ok(self, tokens: torch.Tensor) -> bool:
         if self.linear_dtype != "bf16x3" or self.training or torch.is_grad_enabled():
@@ -314,8 +339,11 @@ class SmokePhysNet(nn.Module):
         else:
             output_reshaped = output_features.transpose(1, 2).reshape(B, -1, pool_size, pool_size)
             reconstructed = self.reconstruction_head(output_reshaped)
-        pooled_features = features.mean(dim=1)
-        physics_pred = self.physics_head(pooled_features)
+        if self._hip_tail_ok(features):
+            pooled_features, physics_pred = self._tail_hip(features)             # token mean + the physics MLP: two launches
+        else:
+            pooled_features = features.mean(dim=1)
+            physics_pred = self.physics_head(pooled_features)
         results = {"reconstructed": reconstructed, "physics_features": physics_pred, "latent_features": pooled_features}
         if return_features:
             results["intermediate_features"] = features

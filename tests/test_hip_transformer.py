@@ -456,3 +456,43 @@ def test_lorenz_states_kernel_matches_the_torch_chain():
     torch.manual_seed(11); a = att.chaos_states(5, "cuda")
     torch.manual_seed(11); b = att.chaos_states_hip(5, "cuda")
     assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
+
+
+def test_batched_chaos_addend_equals_the_per_layer_launches():
+    """smk_chaos_addend_batched (one launch for all layers of a model) writes bit for bit what six smk_chaos_addend launches write."""
+    from smokephysai_amd.models import SmokePhysNet
+    torch.manual_seed(5)
+    model = SmokePhysNet().cuda().eval()
+    B = 3
+    noise = torch.randn(len(model.chaos_layers), 3, B, 1, device="cuda")
+    body = model._hip_body
+    names = [f"chaos_layers.{i}." for i in range(len(model.chaos_layers))]
+    with torch.no_grad():
+        assert body.chaos_addends(names, list(model.chaos_layers), noise, B, noise.device)
+        for i, layer in enumerate(model.chaos_layers):
+            att = layer.chaos_attention
+            got = body.addend_bufs[(names[i], B)][:, :, :att.dim].clone()
+            ref = att.chaos_addend_hip(B, noise.device, noise[i])
+            assert torch.equal(got, ref), i
+            assert float(body.addend_bufs[(names[i], B)][:, :, att.dim:].abs().max()) == 0.0       # the k | v columns stay zero
+
+
+@pytest.mark.parametrize("B,L", [(1, 1024), (5, 1024), (2, 100)])
+def test_pooled_head_kernel_matches_torch(B, L):
+    """smk_pooled_head: features.mean(dim=1) and Linear(ReLU(Linear(.))) (smokephys_net.py:116-118) against the same modules in fp64."""
+    from smokephysai_amd import _lib
+    torch.manual_seed(B * 10 + L)
+    D, H1, H2 = 512, 256, 3
+    x = torch.randn(B, L, D, device="cuda")
+    l1, l2 = torch.nn.Linear(D, H1).cuda(), torch.nn.Linear(H1, H2).cuda()
+    pooled = torch.empty(B, D, device="cuda")
+    out = torch.empty(B, H2, device="cuda")
+    ws = torch.empty(B * 32 * D, device="cuda")
+    _lib.check(_lib.load().smk_pooled_head(x.data_ptr(), B, L, D, D, l1.weight.data_ptr(), l1.bias.data_ptr(), H1, l2.weight.data_ptr(),
+                                           l2.bias.data_ptr(), H2, pooled.data_ptr(), out.data_ptr(), ws.data_ptr(), _lib.stream_ptr(x.device)))
+    with torch.no_grad():
+        p64 = x.double().mean(dim=1)
+        o64 = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(p64, l1.weight.double(), l1.bias.double())), l2.weight.double(),
+                                         l2.bias.double())
+    assert rel_err(pooled.cpu().numpy(), p64.cpu().numpy()) < 1e-6
+    assert rel_err(out.cpu().numpy(), o64.cpu().numpy()) < 1e-5
