@@ -344,8 +344,8 @@ int smk_chaos_addend_batched(int32_t n_layers, const smk_chaos_layer *layers, in
                              double dt, void *stream);
 
 /* SmokePhysNet's tail (smokephys_net.py:116-118): pooled [B][D] = features.mean(dim=1) of x [B][L][ldx] and out [B][H2] =
- * Linear2(ReLU(Linear1(pooled))) with w1 [H1][D], w2 [H2][H1] (row-major, nn.Linear layout), in two launches instead of PyTorch-ROCm's
- * seven (reduce, two GEMM calls with their bias copies, ReLU, fill).  workspace: B * 32 * D floats.  fp32, fixed summation order. */
+ * Linear2(ReLU(Linear1(pooled))) with w1 [H1][D], w2 [H2][H1] (row-major, nn.Linear layout), in three small launches instead of PyTorch-ROCm's
+ * seven (reduce, two GEMM calls with their bias copies, ReLU, fill).  workspace: B * (32 * D + H1) floats.  fp32, fixed summation order. */
 int smk_pooled_head(const float *x, int32_t B, int32_t L, int32_t D, int64_t ldx, const float *w1, const float *b1, int32_t H1,
                     const float *w2, const float *b2, int32_t H2, float *pooled, float *out, float *workspace, void *stream);
 

@@ -1059,7 +1059,7 @@ int smk_pooled_head(const float *x, int32_t B, int32_t L, int32_t D, int64_t ldx
                     const float *w2, const float *b2, int32_t H2, float *pooled, float *out, float *workspace, void *stream) {
     SMK_REQUIRE(x && w1 && b1 && w2 && b2 && pooled && out && workspace, "null pointer");
     SMK_REQUIRE(B >= 1 && B <= 65535 && L >= 1 && D >= 1 && H1 >= 1 && H2 >= 1 && ldx >= D, "B in 1 .. 65535, L, D, H1, H2 >= 1, ldx >= D");
-    SMK_REQUIRE((int64_t)(D + H1) * 4 <= 64 * 1024 && D % 4 == 0, "D + H1 <= 16,384 (the pooled vector and the hidden layer sit in LDS), D % 4 == 0");
+    SMK_REQUIRE((int64_t)D * 4 <= 64 * 1024 && D % 4 == 0 && (H1 + 31) / 32 <= 65535, "D <= 16,384 (the pooled vector sits in LDS), D % 4 == 0");
     SMK_REQUIRE(((uintptr_t)w1 & 15) == 0, "16-byte aligned w1");
     PooledHeadArgs a;
     a.x = x; a.ldx = ldx; a.B = B; a.L = L; a.D = D; a.w1 = w1; a.b1 = b1; a.H1 = H1; a.w2 = w2; a.b2 = b2; a.H2 = H2;

@@ -17,8 +17,8 @@ struct ChaosAddendBatch { int NL; ChaosAddendArgs layer[8]; };
 hipError_t launch_chaos_addend_batch(const ChaosAddendBatch &a, hipStream_t st);
 
 // SmokePhysNet's tail behind the transformer (smokephys_net.py:116-118): latent = features.mean(dim=1), physics = Linear(ReLU(Linear(latent))).
-// Two launches: per-chunk token sums ([B][32 chunks][D] workspace), then per batch element the chunk sums in order, the mean and the
-// two small matrix-vector products (a wave per output row, lanes along the input: coalesced weight reads, fixed summation order).
+// Three small launches: per-chunk token sums ([B][32 chunks][D] workspace); the chunk sums in order -> mean, and the hidden layer, 32
+// units per workgroup (a wave per 8 rows, lanes along the input: coalesced weight reads, fixed summation order); the output layer.
 struct PooledHeadArgs {
     const float *x; long long ldx;       // features [B][L][ldx], D columns used
     int B, L, D;
@@ -26,7 +26,7 @@ struct PooledHeadArgs {
     const float *w2, *b2; int H2;        // [H2][H1], [H2]
     float *pooled;                       // [B][D]
     float *out;                          // [B][H2]
-    float *ws;                           // [B][32][D]
+    float *ws;                           // [B][32][D] chunk sums, then [B][H1] hidden
 };
 hipError_t launch_pooled_head(const PooledHeadArgs &a, hipStream_t st);
 // the five Lorenz states [B][5][3] of the same noise (no projection / gate)

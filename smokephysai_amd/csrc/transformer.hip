@@ -67,46 +67,53 @@ __global__ __launch_bounds__(256) void k_token_chunk_sums(const PooledHeadArgs a
         a.ws[((size_t)b * PH_CHUNKS + ch) * a.D + d] = s;
     }
 }
-__global__ __launch_bounds__(256) void k_pooled_head(const PooledHeadArgs a) {
-    extern __shared__ float ph_smem[];                       // pooled [D] | hidden [H1]
-    float *pooled = ph_smem, *hid = ph_smem + a.D;
+// hidden layer, 32 units per workgroup (grid (B, ceil(H1 / 32)): one workgroup for the whole 512 KB matrix is a chain of load -> reduce
+// round trips, 33 us at batch 1): every workgroup forms the pooled vector from the chunk sums (in chunk order), workgroup y = 0 stores it;
+// a wave takes 8 units at once, lanes along the input (coalesced 16-byte weight reads); hidden -> ws behind the chunk sums
+__global__ __launch_bounds__(256) void k_pooled_hidden(const PooledHeadArgs a) {
+    extern __shared__ float ph_smem[];                       // pooled [D]
+    float *pooled = ph_smem;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int d = tid; d < a.D; d += 256) {
         float s = 0.f;
+#pragma unroll 8
         for (int ch = 0; ch < PH_CHUNKS; ++ch) s += a.ws[((size_t)b * PH_CHUNKS + ch) * a.D + d];
         s = s / (float)a.L;
         pooled[d] = s;
-        a.pooled[(size_t)b * a.D + d] = s;
+        if (blockIdx.y == 0) a.pooled[(size_t)b * a.D + d] = s;
     }
     __syncthreads();
-    // hidden layer: a wave per output row, lanes along the input (coalesced 16-byte weight reads), EIGHT rows in flight per wave -- one
-    // row at a time is a chain of load -> reduce round trips (64 of them per wave: 0.1 ms for a 512 KB matrix)
+    float *hid = a.ws + (size_t)a.B * PH_CHUNKS * a.D + (size_t)b * a.H1;
     const int dq = a.D >> 2;                                 // float4 per row (D % 4 == 0: api.hip)
-    for (int j0 = wave * 8; j0 < a.H1; j0 += 32) {
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int q = lane; q < dq; q += 64) {
-            const float4 pv = *reinterpret_cast<const float4 *>(pooled + 4 * q);
-            float4 wv[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int j = j0 + r < a.H1 ? j0 + r : a.H1 - 1;
-                wv[r] = *reinterpret_cast<const float4 *>(a.w1 + (size_t)j * a.D + 4 * q);
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) s[r] += ((wv[r].x * pv.x + wv[r].y * pv.y) + wv[r].z * pv.z) + wv[r].w * pv.w;
-        }
+    const int j0 = blockIdx.y * 32 + wave * 8;
+    if (j0 >= a.H1) return;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = lane; q < dq; q += 64) {
+        const float4 pv = *reinterpret_cast<const float4 *>(pooled + 4 * q);
+        float4 wv[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            float v = s[r];
+            const int j = j0 + r < a.H1 ? j0 + r : a.H1 - 1;
+            wv[r] = *reinterpret_cast<const float4 *>(a.w1 + (size_t)j * a.D + 4 * q);
+        }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0 && j0 + r < a.H1) {
-                v += a.b1[j0 + r];
-                hid[j0 + r] = v > 0.f ? v : 0.f;
-            }
+        for (int r = 0; r < 8; ++r) s[r] += ((wv[r].x * pv.x + wv[r].y * pv.y) + wv[r].z * pv.z) + wv[r].w * pv.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float v = s[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && j0 + r < a.H1) {
+            v += a.b1[j0 + r];
+            hid[j0 + r] = v > 0.f ? v : 0.f;
         }
     }
-    __syncthreads();
+}
+// output layer: a wave per output unit over the hidden vector
+__global__ __launch_bounds__(256) void k_pooled_out(const PooledHeadArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *hid = a.ws + (size_t)a.B * PH_CHUNKS * a.D + (size_t)b * a.H1;
     for (int k = wave; k < a.H2; k += 4) {
         float s = 0.f;
         for (int j = lane; j < a.H1; j += 64) s += a.w2[(size_t)k * a.H1 + j] * hid[j];
@@ -117,7 +124,8 @@ __global__ __launch_bounds__(256) void k_pooled_head(const PooledHeadArgs a) {
 }
 hipError_t launch_pooled_head(const PooledHeadArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_token_chunk_sums, dim3(a.B, PH_CHUNKS), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_pooled_head, dim3(a.B), dim3(256), (size_t)(a.D + a.H1) * sizeof(float), st, a);
+    hipLaunchKernelGGL(k_pooled_hidden, dim3(a.B, (a.H1 + 31) / 32), dim3(256), (size_t)a.D * sizeof(float), st, a);
+    hipLaunchKernelGGL(k_pooled_out, dim3(a.B), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -292,7 +292,7 @@ class SmokePhysNet(nn.Module):
         l1, l2 = self.physics_head[0], self.physics_head[2]
         pooled = torch.empty(B, D, device=features.device, dtype=torch.float32)
         out = torch.empty(B, l2.out_features, device=features.device, dtype=torch.float32)
-        ws = torch.empty(B * 32 * D, device=features.device, dtype=torch.float32)
+        ws = torch.empty(B * (32 * D + l1.out_features), device=features.device, dtype=torch.float32)
         _lib.check(_lib.load().smk_pooled_head(features.data_ptr(), B, L, D, features.stride(1), l1.weight.data_ptr(), l1.bias.data_ptr(),
                                                l1.out_features, l2.weight.data_ptr(), l2.bias.data_ptr(), l2.out_features, pooled.data_ptr(),
                                                out.data_ptr(), ws.data_ptr(), _lib.stream_ptr(features.device)))
@@ -340,7 +340,7 @@ class SmokePhysNet(nn.Module):
             output_reshaped = output_features.transpose(1, 2).reshape(B, -1, pool_size, pool_size)
             reconstructed = self.reconstruction_head(output_reshaped)
         if self._hip_tail_ok(features):
-            pooled_features, physics_pred = self._tail_hip(features)             # token mean + the physics MLP: two launches
+            pooled_features, physics_pred = self._tail_hip(features)             # token mean + the physics MLP: three small launches
         else:
             pooled_features = features.mean(dim=1)
             physics_pred = self.physics_head(pooled_features)

@@ -487,7 +487,7 @@ def test_pooled_head_kernel_matches_torch(B, L):
     l1, l2 = torch.nn.Linear(D, H1).cuda(), torch.nn.Linear(H1, H2).cuda()
     pooled = torch.empty(B, D, device="cuda")
     out = torch.empty(B, H2, device="cuda")
-    ws = torch.empty(B * 32 * D, device="cuda")
+    ws = torch.empty(B * (32 * D + H1), device="cuda")
     _lib.check(_lib.load().smk_pooled_head(x.data_ptr(), B, L, D, D, l1.weight.data_ptr(), l1.bias.data_ptr(), H1, l2.weight.data_ptr(),
                                            l2.bias.data_ptr(), H2, pooled.data_ptr(), out.data_ptr(), ws.data_ptr(), _lib.stream_ptr(x.device)))
     with torch.no_grad():
