@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 14
+#define SMK_ABI_VERSION 15
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -305,6 +305,15 @@ int smk_linear_wgrad(const float *dy, int64_t ld_dy, const float *x, int64_t ldx
 int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx, void *y, int64_t ldy,
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream);
+
+/* LayerNorm fused in front of the layer, for one-tile-per-workgroup problems (a single frame: ceil(rows / 32) * ceil(out_features / 128) at
+ * most twice the CU count -- smk_linear_ln_max_rows): y = act(LN(x) W^T + b + periodic_add), LN over the in_features of a row with `eps`.
+ * `lin` must have been created from the FOLDED parameters W' = W diag(gamma), b' = b + W beta; wsum [out_features] = row sums of W'.  The
+ * kernel reads the raw x, gathers each row's mean / variance while staging it and applies rstd (x W'^T - mean wsum) + b' in its epilogue: the
+ * separate LayerNorm launch and its round trip are gone.  fp32 in / out; no residual. */
+int64_t smk_linear_ln_max_rows(smk_linear *lin);
+int smk_linear_forward_ln(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy, const float *wsum, double eps,
+                          const float *periodic_add, int32_t rows_per_group, int32_t period, int32_t activation, void *stream);
 
 /* Conv3d(64 -> N, kernel 3, padding 1) + bias + activation as an IMPLICIT GEMM on the split-bf16 MFMA layer kernel -- no patch matrix:
  * src [D][H][W][64] fp32 channels-last, `lin` a layer handle with in_features = 27 * 64 whose weight columns are tap * 64 + c

@@ -7,7 +7,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMOKEHIP_LIB") or os.path.join(_HERE, "libsmokehip.so")   # SMOKEHIP_LIB: diagnostic builds only
 
-ABI_VERSION = 14                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
+ABI_VERSION = 15                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
 SMK_ERR_TIMEOUT = -5
 SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
 SMK_ACT_NONE, SMK_ACT_GELU, SMK_ACT_RELU = 0, 1, 2
@@ -102,6 +102,8 @@ _SIGNATURES = {
     "smk_chaos_addend_batched": [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p],
     "smk_pooled_head": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "smk_linear_forward_ln": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p,
+                              C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "smk_attention_ws": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                          C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p],
     "smk_attention_forward_lse": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -134,7 +136,7 @@ _SIGNATURES = {
     "smk_linear_forward": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
-EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace", "smk_conv2_train_workspace", "smk_conv2_train_wgrad_workspace", "smk_conv1_train_wgrad_workspace", "smk_attention_workspace_bytes"] + list(_SIGNATURES)
+EXPORTS = ["smk_abi_version", "smk_last_error", "smk_linear_wgrad_workspace", "smk_bn_train_workspace", "smk_layernorm_bwd_workspace", "smk_conv2_train_workspace", "smk_conv2_train_wgrad_workspace", "smk_conv1_train_wgrad_workspace", "smk_attention_workspace_bytes", "smk_linear_ln_max_rows"] + list(_SIGNATURES)
 
 _lib = None
 
@@ -180,6 +182,8 @@ def load():
         L.smk_conv1_train_wgrad_workspace.restype = C.c_int64
         L.smk_attention_workspace_bytes.argtypes = [C.c_int32] * 4
         L.smk_attention_workspace_bytes.restype = C.c_int64
+        L.smk_linear_ln_max_rows.argtypes = [C.c_void_p]
+        L.smk_linear_ln_max_rows.restype = C.c_int64
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -969,6 +969,35 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
     return check_launch(launch_linear_x3(lin->l, c, (hipStream_t)stream), "linear_x3");
 }
 
+int64_t smk_linear_ln_max_rows(smk_linear *lin) {
+    if (!lin) return 0;
+    DeviceGuard guard(lin->device);
+    if (guard.rc) return 0;
+    const int64_t slots = 2LL * device_num_cu(), tn = (lin->l.N + 127) / 128;
+    return slots / tn * 32;
+}
+
+int smk_linear_forward_ln(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy, const float *wsum, double eps,
+                          const float *periodic_add, int32_t rows_per_group, int32_t period, int32_t activation, void *stream) {
+    SMK_REQUIRE(lin && x && y && wsum, "null lin/x/y/wsum");
+    SMK_REQUIRE(rows >= 1 && ldx >= lin->l.K && ldy >= lin->l.N && ldx % 4 == 0 && ldy % 4 == 0, "rows >= 1, row pitches >= features, multiples of 4");
+    SMK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wsum) & 15) == 0, "16-byte aligned x / y / wsum");
+    SMK_REQUIRE((rows + 256) * ldx < (1LL << 30), "(rows + 256) * ldx < 2^30 floats");
+    SMK_REQUIRE(activation == SMK_ACT_NONE || activation == SMK_ACT_GELU || activation == SMK_ACT_RELU, "activation");
+    SMK_REQUIRE(!periodic_add || (rows_per_group >= 32 && rows_per_group % 32 == 0 && period >= 1 && rows % rows_per_group == 0),
+                "periodic_add: rows_per_group a multiple of 32 that divides rows, period >= 1");
+    SMK_REQUIRE(eps > 0.0, "eps > 0");
+    DeviceGuard guard(lin->device);
+    if (guard.rc) return guard.rc;
+    SMK_REQUIRE(rows <= smk_linear_ln_max_rows(lin), "fused LayerNorm serves one tile per workgroup: rows <= smk_linear_ln_max_rows");
+    LinearCall c;
+    c.x = x; c.ldx = ldx; c.y = y; c.ldy = ldy; c.x_split = 0; c.y_split = 0; c.res = nullptr; c.ldr = 0;
+    c.padd = periodic_add; c.rows_per_group = periodic_add ? rows_per_group : 1; c.period = periodic_add ? period : 1;
+    c.M = (int)rows; c.act = activation;
+    c.ln_wsum = wsum; c.ln_eps = (float)eps;
+    return check_launch(launch_linear_x3(lin->l, c, (hipStream_t)stream), "linear_x3 (fused LayerNorm)");
+}
+
 int smk_conv3d_cl_forward(smk_linear *lin, const float *src, int32_t D, int32_t H, int32_t W, int32_t z0, int32_t nz, float *y, int64_t ldy,
                           int32_t activation, void *stream) {
     SMK_REQUIRE(lin && src && y, "null lin/src/y");

@@ -23,6 +23,11 @@ struct LinearCall {
     // problems y[s] = x[:, s*K:(s+1)*K] w[:, s*K:(s+1)*K]^T share one launch; l.K is the SEGMENT length, the weights hold nseg*K
     // k in one layout, y is nseg dense [M][N] slabs.  nseg = 1: the plain layer.
     int nseg = 1;
+    // LayerNorm fused in front of the layer (one-tile-per-workgroup problems: a single frame): x is the RAW row, the handle holds
+    // W' = W diag(gamma) and b' = b + W beta, ln_wsum[n] = sum_k W'[n][k]; the kernel gathers each row's sum and sum of squares while it
+    // stages the row and finishes y = rstd (x W'^T - mean ln_wsum) + b' in the epilogue.  Null: the plain layer.
+    const float *ln_wsum = nullptr;
+    float ln_eps = 0.f;
 };
 
 hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed = 0,

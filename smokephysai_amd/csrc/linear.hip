@@ -33,7 +33,7 @@ constexpr int LN_PITCH = 144;      // bytes per staged row per plane: 64 bf16 + 
 #endif
 constexpr int LN_RING = 4;         // B fragments in flight: 3 k-steps ahead; 4 k-steps per chunk keep the ring indices static
 template <int MB> constexpr int ln_plane_bytes() { return MB * 32 * LN_PITCH; }
-template <int MB, int NW> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 1024; }   // + bias tile; MB = 4: 74,240 B -> 2 workgroups per CU
+template <int MB, int NW> constexpr int ln_lds_bytes() { return 2 * 2 * ln_plane_bytes<MB>() + 2048; }   // + bias tile (+ fused-LayerNorm column sums, row statistics); MB = 4: 75,264 B -> 2 workgroups per CU
 
 // transposed: `w` is [K][N] row-major (the handle then computes x W for a layer whose weight is W [K][N]: its input-gradient GEMM).
 // ld: source row pitch in floats; k_valid: k >= k_valid reads as zero (the weight-gradient form pads the token rows to whole segments).
@@ -143,8 +143,11 @@ struct LinearArgs {
 // trip).  The one-tile-per-workgroup problems of a single frame (M = 1,024, MB = 1: a k-step is 3 MFMAs = 96 cycles) are bound by exactly
 // that round trip -- 32 k-steps x ~0.3 us = the 10 us such a layer took -- so they run RING = 16 (fifteen steps = ~1 us ahead; the chunk loop
 // is unrolled RING / 4 times so that the slot indices stay compile-time; needs K % (16 RING) == 0).
-template <int MB, int NW, bool AS, int KS = 1, int RING = LN_RING>
+// LNF: LayerNorm fused in front (LinearCall::ln_wsum; fp32 input, one wave group, ONE tile per workgroup: the row sums are gathered over
+// the workgroup's whole chunk stream).
+template <int MB, int NW, bool AS, int KS = 1, int RING = LN_RING, bool LNF = false>
 __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(const LinearArgs a) {
+    static_assert(!LNF || (!AS && KS == 1), "fused LayerNorm: fp32 activations, one wave group");
     constexpr int TN = NW * 32, RP = AS ? NW * 8 : NW * 4;   // tile columns; rows staged per pass (fp32: 16 float4 per row chunk; split: 8 x 32 B)
     constexpr bool sched = SMK_LINEAR_SCHED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -202,6 +205,9 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     constexpr int NPC_ALL = TM / RP;                         // pieces per chunk per thread
     float4 stage[AS ? 1 : NPC_ALL];
     u32x4 sth[AS ? NPC_ALL : 1], stl[AS ? NPC_ALL : 1];
+    float ln_s[LNF ? NPC_ALL : 1], ln_q[LNF ? NPC_ALL : 1];   // LNF: this thread's share of sum / sum of squares of rows sr + RP j
+#pragma unroll
+    for (int j = 0; j < (LNF ? NPC_ALL : 1); ++j) { ln_s[j] = 0.f; ln_q[j] = 0.f; }
     // x through a buffer resource: a row past M (ragged last tile, or the chunk stream running past this workgroup's last
     // tile) is out of range and reads as zero in hardware -- no clamp, no predicate (either would cost VALU issue slots or
     // split the k-step into basic blocks and undo the MFMA / staging interleave below).  One v_add per load: the offset
@@ -231,6 +237,10 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
         }
         unsigned char *ph = smem + buf * 2 * PLANE + (sr + RP * j) * LN_PITCH + sc * 8;
         const float v[4] = {stage[AS ? 0 : j].x, stage[AS ? 0 : j].y, stage[AS ? 0 : j].z, stage[AS ? 0 : j].w};
+        if constexpr (LNF) {
+            ln_s[j] += (v[0] + v[1]) + (v[2] + v[3]);
+            ln_q[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
         bf16x4 vh, vl;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -277,6 +287,8 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     const bool nw_ok = tn * TN + wave * 32 < N;
     float *bias_s = reinterpret_cast<float *>(smem + 4 * PLANE);       // this workgroup's 128 bias values
     if (tid < TN) bias_s[tid] = (a.l.bias && tn * TN + tid < N) ? a.l.bias[tn * TN + tid] : 0.f;   // visible after the first barrier below             // N % 32 == 0: a wave's 32 columns are all inside or all outside
+    float *wsum_s = bias_s + TN, *stat_s = wsum_s + TN;                  // LNF: column sums of W', then (mean, rstd) per tile row
+    if (LNF && tid < TN) wsum_s[tid] = tn * TN + tid < N ? a.c.ln_wsum[tn * TN + tid] : 0.f;
 
 #ifdef SMK_LN_STAMPS
     unsigned long long sum_k = 0, sum_e = 0, ntl = 0, sum_u[5] = {0, 0, 0, 0, 0}, t_prev = 0;
@@ -416,6 +428,22 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
             // (the next write to xch by groups 1.. lies behind at least one more workgroup barrier -- the next tile's first chunk --
             //  which group 0 reaches only after these reads)
         }
+        if constexpr (LNF) {   // row statistics: the 16 threads sc = 0 .. 15 of a staging row hold its 64 k of every chunk between them
+#pragma unroll
+            for (int j = 0; j < NPC_ALL; ++j) {
+                float s1 = ln_s[j], s2 = ln_q[j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                if (sc == 0) {
+                    const float mean = s1 / (float)K;
+                    float var = s2 / (float)K - mean * mean;
+                    var = var > 0.f ? var : 0.f;
+                    stat_s[2 * (sr + RP * j)] = mean;
+                    stat_s[2 * (sr + RP * j) + 1] = 1.0f / sqrtf(var + a.c.ln_eps);
+                }
+            }
+            __syncthreads();
+        }
         // ---- epilogue.  The weights are the MFMA's row operand, so acc[mi][4q + i] = output row mi*32 + r (this lane's token),
         //      column 8q + 4hi + i of the wave's 32: four consecutive columns per lane -> 16-byte loads and stores.
         if (grp == 0 && nw_ok && !LN_DBG(a, 4)) {
@@ -474,6 +502,15 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                     *reinterpret_cast<float4 *>(y_seg + (long long)row * a.c.ldy + ncol + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             };
+            // fused LayerNorm: v = rstd (x W'^T - mean wsum) + b' for row mi*32 + r, columns 8q + 4hi .. + 3 of the wave's 32
+            auto ln_finish = [&](float (&v)[4], int mi, int q, const float4 &bq) {
+                const float mean = stat_s[2 * (mi * 32 + r)], rstd = stat_s[2 * (mi * 32 + r) + 1];
+                const float4 wq4 = *reinterpret_cast<const float4 *>(wsum_s + wave * 32 + 4 * hi + 8 * q);
+                v[0] = rstd * (acc[mi][4 * q] - mean * wq4.x) + bq.x;
+                v[1] = rstd * (acc[mi][4 * q + 1] - mean * wq4.y) + bq.y;
+                v[2] = rstd * (acc[mi][4 * q + 2] - mean * wq4.z) + bq.z;
+                v[3] = rstd * (acc[mi][4 * q + 3] - mean * wq4.w) + bq.w;
+            };
             if (!any_ex) {
                 // plain path: no global loads at all, so nothing ever waits on vmcnt -- which on CDNA4 also counts the stores
                 // (a wait here would drain every store to memory before the next one is issued)
@@ -484,6 +521,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                     for (int q = 0; q < 4; ++q) {
                         const float4 bq = *reinterpret_cast<const float4 *>(bias_w + 8 * q);
                         float v[4] = {acc[mi][4 * q] + bq.x, acc[mi][4 * q + 1] + bq.y, acc[mi][4 * q + 2] + bq.z, acc[mi][4 * q + 3] + bq.w};
+                        if constexpr (LNF) ln_finish(v, mi, q, bq);
                         finish(v, row, q);
                         store4(v, row, q);
                     }
@@ -499,6 +537,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                         const float4 bq = *reinterpret_cast<const float4 *>(bias_w + 8 * q);
                         const float4 eq = ex[mi & 1][q];
                         float v[4] = {acc[mi][4 * q] + bq.x, acc[mi][4 * q + 1] + bq.y, acc[mi][4 * q + 2] + bq.z, acc[mi][4 * q + 3] + bq.w};
+                        if constexpr (LNF) ln_finish(v, mi, q, bq);
                         if (a.c.padd) { v[0] += eq.x; v[1] += eq.y; v[2] += eq.z; v[3] += eq.w; }
                         finish(v, row, q);
                         if (!a.c.padd) { v[0] = eq.x + v[0]; v[1] = eq.y + v[1]; v[2] = eq.z + v[2]; v[3] = eq.w + v[3]; }
@@ -522,11 +561,11 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
 #endif
 }
 
-template <int MB, int NW, bool AS, int KS = 1, int RING = LN_RING>
+template <int MB, int NW, bool AS, int KS = 1, int RING = LN_RING, bool LNF = false>
 static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     constexpr int lds = KS * ln_lds_bytes<MB, NW>() + (KS - 1) * NW * 64 * MB * 16 * 4;
-    once_per_device((const void *)k_linear_x3<MB, NW, AS, KS, RING>, [&] {
-        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS, KS, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    once_per_device((const void *)k_linear_x3<MB, NW, AS, KS, RING, LNF>, [&] {
+        (void)hipFuncSetAttribute((const void *)k_linear_x3<MB, NW, AS, KS, RING, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const int nseg = a.c.nseg;
     const int nwg_max = (NW == 8 || KS > 1 ? 1 : 2) * a.num_cu / nseg;     // 8 waves per CU either way (split-K: one workgroup per CU)
@@ -544,7 +583,8 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     // one tile ~ (K/64) chunks x ~4.2 K cycles + ~9 K epilogue; s_sleep(127) ~ 8 K cycles
     b.stagger_unit = stg_env > 1 ? (int)(((a.l.K / 64) * 4200 + 9000) / 8128 / stg_env) : 0;
     if (b.stagger_unit < 1) b.stagger = 0;
-    hipLaunchKernelGGL((k_linear_x3<MB, NW, AS, KS, RING>), dim3((unsigned)nwg), dim3(NW * 64 * KS), lds, st, b);
+    if (LNF && nwg < tiles * nseg) return hipErrorInvalidValue;          // fused LayerNorm: one tile per workgroup
+    hipLaunchKernelGGL((k_linear_x3<MB, NW, AS, KS, RING, LNF>), dim3((unsigned)nwg), dim3(NW * 64 * KS), lds, st, b);
     return hipGetLastError();
 }
 
@@ -955,6 +995,12 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     a.swz = 0;
     a.stagger = 0;
     a.stamps = nullptr;
+    if (c.ln_wsum) {   // LayerNorm fused in front: 32-row tiles, one per workgroup (launch_mb refuses more tiles than workgroup slots)
+        if (c.x_split || c.y_split || c.nseg != 1 || c.res || (c.padd && c.rows_per_group % 32 != 0)) return hipErrorInvalidValue;
+        a.tiles_n = cdiv(l.N, 128);
+        a.tiles_m = cdiv(c.M, 32);
+        return (l.K / 64) % 4 == 0 ? launch_mb<1, 4, false, 1, 16, true>(a, st) : launch_mb<1, 4, false, 1, LN_RING, true>(a, st);
+    }
     int nw = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) * c.nseg >= num_cu) ? 8 : 4;
     if (force_nw == 4 || force_nw == 8) nw = force_nw;
     a.tiles_n = cdiv(l.N, nw * 32);

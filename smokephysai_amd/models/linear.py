@@ -145,6 +145,48 @@ class HipLinear:
         return y
 
 
+class HipLinearLN(HipLinear):
+    """LayerNorm + Linear as ONE launch for single-frame problems (smk_linear_forward_ln): the handle holds the folded parameters
+    W' = W diag(gamma), b' = b + W beta; the kernel normalises inside (row statistics gathered while it stages the raw rows, the mean /
+    rstd correction in its epilogue).  `max_rows`: the largest row count the fused form serves (one tile per workgroup)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], ln_weight: torch.Tensor, ln_bias: torch.Tensor, eps: float,
+                 device=None):
+        w = weight.detach().double()
+        g, be = ln_weight.detach().double().to(w.device), ln_bias.detach().double().to(w.device)
+        wf = w * g[None, :]
+        bf = w @ be + (0.0 if bias is None else bias.detach().double())
+        super().__init__(wf.float(), bf.float(), device=device)
+        self.eps = float(eps)
+        self.wsum = wf.sum(dim=1).float().to(self._dev).contiguous()
+        self.max_rows = int(self._L.smk_linear_ln_max_rows(self._handle))
+
+    def forward_ln(self, x: torch.Tensor, activation: Optional[str] = None, periodic_add: Optional[torch.Tensor] = None,
+                   rows_per_group: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [..., in_features] RAW (not normalised) -> act(LayerNorm(x) W^T + b + periodic_add)."""
+        if x.device != self._dev or x.dtype != torch.float32 or x.shape[-1] != self.in_features:
+            raise ValueError(f"HipLinearLN: x must be float32 [..., {self.in_features}] on {self._dev}")
+        x2 = x.reshape(-1, self.in_features)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        if rows > self.max_rows:
+            raise ValueError(f"HipLinearLN: {rows} rows > max_rows {self.max_rows} (use the LayerNorm kernel + HipLinear)")
+        y = out if out is not None else torch.empty(*x.shape[:-1], self.out_features, device=self._dev, dtype=torch.float32)
+        y2 = y.view(-1, self.out_features)
+        pa_ptr, period, rpg = 0, 1, 1
+        if periodic_add is not None:
+            pa = periodic_add.to(torch.float32).contiguous()
+            rpg = rows_per_group or (x.shape[-2] if x.dim() >= 2 else rows)
+            if pa.dim() != 3 or pa.shape[2] != self.out_features or pa.shape[0] * rpg != rows:
+                raise ValueError("HipLinearLN: periodic_add must be [rows / rows_per_group, period, out_features]")
+            pa_ptr, period = pa.data_ptr(), pa.shape[1]
+        act = {None: _lib.SMK_ACT_NONE, "none": _lib.SMK_ACT_NONE, "gelu": _lib.SMK_ACT_GELU, "relu": _lib.SMK_ACT_RELU}[activation]
+        _lib.check(self._L.smk_linear_forward_ln(self._handle, x2.data_ptr(), rows, x2.stride(0), y2.data_ptr(), y2.stride(0),
+                                                 self.wsum.data_ptr(), self.eps, pa_ptr, rpg, period, act, _lib.stream_ptr(self._dev)))
+        return y
+
+
 def hip_linear_wgrad_supported(in_features: int, out_features: int) -> bool:
     return in_features % 32 == 0 and out_features % 4 == 0
 

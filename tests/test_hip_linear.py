@@ -190,3 +190,34 @@ def test_weight_gradient_row_chunking(monkeypatch):
     assert rel_err(parts.cpu().numpy(), ref.cpu().numpy()) < 2e-5 and rel_err(whole.cpu().numpy(), ref.cpu().numpy()) < 2e-5
     _, db = hl.hip_linear_wgrad(dy, x, want_db=True)                # chunked: per-chunk column sums added
     assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("rows,K,N,act,padd", [(1024, 512, 1536, None, True), (1024, 512, 2048, "gelu", False), (96, 128, 64, "relu", False),
+                                                (1000, 512, 512, None, False)])
+def test_layernorm_fused_into_the_linear_layer(rows, K, N, act, padd):
+    """smk_linear_forward_ln (HipLinearLN): act(LayerNorm(x) W^T + b + periodic_add) against the same chain in fp64 -- rows whose mean is
+    far from zero (the epilogue's mean * wsum correction carries weight), a ragged last tile, the periodic addend of the q | k | v layer."""
+    from smokephysai_amd.models.linear import HipLinearLN
+    g = torch.Generator(device="cuda").manual_seed(rows + K + N)
+    x = torch.randn(rows, K, device="cuda", generator=g) * 1.7 + torch.randn(rows, 1, device="cuda", generator=g) * 1.5      # per-row offsets
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    gamma = torch.rand(K, device="cuda", generator=g) + 0.5
+    beta = torch.randn(K, device="cuda", generator=g) * 0.3
+    lin = HipLinearLN(w, b, gamma, beta, 1e-5)
+    assert lin.max_rows >= rows
+    pa = torch.randn(rows // 32 if rows % 32 == 0 else 1, 5, N, device="cuda", generator=g) if padd else None
+    rpg = 32 if padd else 0
+    y = lin.forward_ln(x, activation=act, periodic_add=pa, rows_per_group=rpg)
+    h = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5)
+    ref = h @ w.double().t() + b.double()
+    if padd:
+        idx = torch.arange(rows, device="cuda")
+        ref = ref + pa.double()[idx // 32, (idx % 32) % 5]
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    elif act == "relu":
+        ref = torch.relu(ref)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+    with pytest.raises(ValueError):
+        lin.forward_ln(torch.zeros(lin.max_rows + 32, K, device="cuda"))
