@@ -79,15 +79,15 @@ def test_features_vs_oracle(shape, slab):
     assert rel_err(im(x).cpu().numpy(), got) < 1e-6
 
 
-@pytest.mark.parametrize("D", [1, 2, 5])
-def test_march_kernel_depth_edges_and_zsum(D):
+@pytest.mark.parametrize("D,H,W", [(1, 16, 48), (2, 16, 48), (5, 16, 48), (3, 8, 16), (4, 24, 16)])
+def test_march_kernel_depth_edges_and_zsum(D, H, W):
     """smk_conv3d_cl_zsum_forward alone, against the fp64 oracle's conv2 on the same (random, signed) channels-last input: depths 1 and 2
-    (planes z-1 / z+1 / z+2 of the ring outside the volume), walls in x and y on every tile, no activation and ReLU."""
+    (planes z-1 / z+1 / z+2 of the ring outside the volume), walls in x and y on every tile (down to a volume that IS one 8 x 16 tile), a
+    single tile column of three tiles, no activation and ReLU."""
     from oracle.encoder3d import conv3d
     from smokephysai_amd import _lib
     from smokephysai_amd.models.linear import HipLinear
-    rng = np.random.RandomState(D)
-    H, W = 16, 48
+    rng = np.random.RandomState(D + H)
     a1 = rng.randn(D, H, W, 64).astype(np.float32)
     w2 = (rng.randn(128, 64, 3, 3, 3) * 0.05).astype(np.float32)
     b2 = rng.randn(128).astype(np.float32)
@@ -104,14 +104,13 @@ def test_march_kernel_depth_edges_and_zsum(D):
         _lib.check(L.smk_conv3d_cl_zsum_forward(lin._handle, src.data_ptr(), D, 12, W, zsum.data_ptr(), 0, _lib.stream_ptr(src.device)))
 
 
-@pytest.mark.parametrize("D", [1, 4, 9])
-def test_conv1_march_kernel_depth_edges(D):
+@pytest.mark.parametrize("D,H,W", [(1, 16, 32), (4, 16, 32), (9, 16, 32), (3, 8, 16), (8, 24, 48)])
+def test_conv1_march_kernel_depth_edges(D, H, W):
     """smk_conv3d_s7_march_forward alone against the fp64 oracle's conv1 (7 x 7 x 7, padding 3) on a signed random volume: depths below, at and
     above the ring's seven planes, every tile touching a wall in x or y, both activations."""
     from oracle.encoder3d import conv3d
     from smokephysai_amd.models.linear import HipLinear
-    rng = np.random.RandomState(10 + D)
-    H, W = 16, 32
+    rng = np.random.RandomState(10 + D + W)
     vol = rng.randn(D, H, W).astype(np.float32)
     w1 = (rng.randn(64, 1, 7, 7, 7) * 0.05).astype(np.float32)
     b1 = rng.randn(64).astype(np.float32)
