@@ -547,7 +547,7 @@ int smk_sim3d_add_sources(smk_sim3d *sim, const smk_source3d *src, int32_t n, vo
 namespace {
 // one stage on the ping-pong pair: s = caller's tensors, t = scratch.  A step runs
 //   (u, v, w, d) --buoy+diffuse--> t --project (p in place via p2)--> t --advect u--> s.u --advect v--> s.v --advect w--> s.w --advect d--> s.d
-int run_stage3d(smk_sim3d *sim, int stage, float *frames, int64_t fsb, hipStream_t st) {
+int run_stage3d(smk_sim3d *sim, int stage, float *frames, int64_t fsb, hipStream_t st, bool keep_gradient = false) {
     const Geom3 &g = sim->g;
     State3 &s = sim->s, &t = sim->t;
     switch (stage) {
@@ -557,7 +557,7 @@ int run_stage3d(smk_sim3d *sim, int stage, float *frames, int64_t fsb, hipStream
             int rc = check_launch(launch3_divergence(g, t, sim->div, st), "divergence3d");
             if (rc) return rc;
             rc = check_launch(launch3_jacobi(g, s.p, t.p, sim->div, sim->jacobi_iters, st), "jacobi3d");
-            if (rc) return rc;
+            if (rc || keep_gradient) return rc;          // keep_gradient: the advection launch subtracts dt grad p while it stages its inputs
             return check_launch(launch3_grad_subtract(g, t, s.p, st), "grad_subtract3d");
         }
         case SMK_STAGE3D_ADVECT_U:
@@ -579,16 +579,22 @@ int smk_sim3d_step(smk_sim3d *sim, int32_t n_steps, float *frames, int64_t fsb, 
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(sim->device);
     if (guard.rc) return guard.rc;
-    static const bool staged = getenv("SMK_ADVECT3_STAGED") != nullptr;      // diagnostic: the four advections as four launches
+    // diagnostics (read once): SMK_ADVECT3_STAGED the four advections as four launches; SMK_ADVECT3_TILE the 8 x 8 x 32 tile launch of
+    // round 3; SMK_ADVECT3_GRAD=0 the z-marching launch behind a separate gradient-subtraction launch.  Default: the z-marching launch
+    // with the gradient subtraction applied while it stages its inputs.
+    static const bool staged = getenv("SMK_ADVECT3_STAGED") != nullptr;
+    static const bool tiled = getenv("SMK_ADVECT3_TILE") != nullptr;
+    static const bool fold_grad = !staged && !tiled && !(getenv("SMK_ADVECT3_GRAD") && atoi(getenv("SMK_ADVECT3_GRAD")) == 0);
     for (int t = 0; t < n_steps; ++t) {
         float *ft = frames ? frames + (size_t)t * fst : nullptr;
         const int last = staged ? SMK_STAGE3D_ADVECT_D : SMK_STAGE3D_PROJECT;
         for (int stage = SMK_STAGE3D_BUOY_DIFFUSE; stage <= last; ++stage) {
-            const int rc = run_stage3d(sim, stage, stage == SMK_STAGE3D_ADVECT_D ? ft : nullptr, fsb, st);
+            const int rc = run_stage3d(sim, stage, stage == SMK_STAGE3D_ADVECT_D ? ft : nullptr, fsb, st, fold_grad);
             if (rc) return rc;
         }
         if (!staged) {
-            const int rc = check_launch(launch3_advect_fused(sim->g, sim->t, sim->s, ft, fsb, st), "advect_fused3d");
+            const int rc = tiled ? check_launch(launch3_advect_fused(sim->g, sim->t, sim->s, ft, fsb, st), "advect_fused3d")
+                                 : check_launch(launch3_advect_march(sim->g, sim->t, fold_grad ? sim->s.p : nullptr, sim->s, ft, fsb, st), "advect_march3d");
             if (rc) return rc;
         }
     }

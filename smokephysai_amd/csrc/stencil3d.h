@@ -30,5 +30,26 @@ hipError_t launch3_advect(const Geom3 &g, int which, const float *field, float *
 
 // the four advections of one step as one launch: in = (u2, v2, w2, -, d2), out = (u, v, w, -, density); bit-identical to the four launches
 hipError_t launch3_advect_fused(const Geom3 &g, State3 in, State3 out, float *frames, int64_t frame_stride_b, hipStream_t st);
+// the same as a z-marching launch (inputs staged once into LDS rings).  p != nullptr: `in` holds the velocities BEFORE the projection's
+// gradient subtraction and the launch applies it on the fly (launch3_grad_subtract is then not run); bit-identical either way
+hipError_t launch3_advect_march(const Geom3 &g, State3 in, const float *p, State3 out, float *frames, int64_t frame_stride_b, hipStream_t st);
+
+
+// ---- device helpers shared by the 3-D kernel files
+__device__ __forceinline__ float clampf3(float x, float lo, float hi) {
+    float t = x < lo ? lo : x;   // torch.clamp = min(max(x, lo), hi)
+    return t > hi ? hi : t;
+}
+__device__ __forceinline__ int clampi3(int x, int lo, int hi) {
+    int t = x < lo ? lo : x;
+    return t > hi ? hi : t;
+}
+// Workgroups are dealt round-robin over the 8 XCDs (ids i and i + 8 share an XCD and its 4 MiB L2: MI355X_MICROARCH.md, speed only).  A tile
+// kernel whose tiles overlap (halos) or read each other's edge lines wants NEIGHBOURING tiles on one XCD: this maps the dispatch id to a
+// logical tile id such that XCD c works through one contiguous range of tiles, in order.  A bijection on [0, n) for every n.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned id, unsigned n) {
+    const unsigned c = id & 7u, q = n >> 3, r = n & 7u;
+    return c * q + (c < r ? c : r) + (id >> 3);
+}
 
 }  // namespace smk

@@ -12,20 +12,13 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace smk {
 
 #define TX3 64
 #define TY3 4
 
-__device__ __forceinline__ float clampf3(float x, float lo, float hi) {
-    float t = x < lo ? lo : x;   // torch.clamp = min(max(x, lo), hi)
-    return t > hi ? hi : t;
-}
-__device__ __forceinline__ int clampi3(int x, int lo, int hi) {
-    int t = x < lo ? lo : x;
-    return t > hi ? hi : t;
-}
 
 // ---------------------------------------------------------------- reset (navier_stokes.py:24-35)
 __global__ void k3_zero(Geom3 g, State3 s, const uint8_t *mask) {
@@ -131,8 +124,14 @@ __global__ void k3_buoy_diffuse(Geom3 g, State3 in, State3 out) {
 // w's extra plane z = D are ordinary iterations.  Per cell the expression trees of diffuse3_at -- bit-identical.
 template <int TXB, int TYB>
 __global__ __launch_bounds__(TXB * TYB) void k3_buoy_diffuse_march(Geom3 g, State3 in, State3 out) {
-    const int b = blockIdx.z, D = g.D, H = g.H, W = g.W;
-    const int x = blockIdx.x * TXB + threadIdx.x, y = blockIdx.y * TYB + threadIdx.y;
+    const int D = g.D, H = g.H, W = g.W;
+    // tiles in (x fastest, y, grid) order, a contiguous range per XCD: the x / y neighbours whose edge lines this tile reads share its L2
+    const unsigned ntx = (W + TXB - 1) / TXB, nty = (H + TYB) / TYB;
+    unsigned t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bx = t % ntx; t /= ntx;
+    const int by = t % nty;
+    const int b = t / nty;
+    const int x = bx * TXB + threadIdx.x, y = by * TYB + threadIdx.y;
     if (x >= W || y > H) return;
     const float *u = in.u + b * g.su, *v = in.v + b * g.sv, *w = in.w + b * g.sw, *d = in.d + b * g.sc;
     float *uo = out.u + b * g.su, *vo = out.v + b * g.sv, *wo = out.w + b * g.sw, *dd = out.d + b * g.sc;
@@ -204,7 +203,7 @@ hipError_t launch3_buoy_diffuse(const Geom3 &g, State3 in, State3 out, hipStream
     static const bool cellwise = getenv("SMK_DIFFUSE3_CELLWISE") != nullptr;      // diagnostic: the one-cell-per-thread form
     if (!cellwise && g.B <= 65535) {
         constexpr int TXB = 64, TYB = 4;
-        hipLaunchKernelGGL((k3_buoy_diffuse_march<TXB, TYB>), dim3(cdiv(g.W, TXB), cdiv(g.H + 1, TYB), g.B), dim3(TXB, TYB), 0, st, g, in, out);
+        hipLaunchKernelGGL((k3_buoy_diffuse_march<TXB, TYB>), dim3((unsigned)(cdiv(g.W, TXB) * cdiv(g.H + 1, TYB) * g.B)), dim3(TXB, TYB), 0, st, g, in, out);
         return hipGetLastError();
     }
     dim3 grid(cdiv(g.W + 1, TX3), cdiv(g.H + 1, TY3), g.B * (g.D + 1)), block(TX3, TY3);
@@ -297,8 +296,14 @@ template <int T, int TXB, int TYB, int CY>
 __global__ __launch_bounds__(TXB * TYB) void k3_jacobi_xt(Geom3 g, const float *__restrict__ p, float *__restrict__ pn, const float *__restrict__ div) {
     constexpr int ROWS = TYB * CY;
     __shared__ float L[T][2][ROWS][TXB];
-    const int tx = threadIdx.x, b = blockIdx.z;
-    const int x = blockIdx.x * (TXB - 2 * T) - T + tx;
+    const int tx = threadIdx.x;
+    // tiles in (x fastest, y, grid) order, a contiguous range per XCD: overlapping halos are fetched into ONE L2
+    const unsigned ntx = (g.W + (TXB - 2 * T) - 1) / (TXB - 2 * T), nty = (g.H + (ROWS - 2 * T) - 1) / (ROWS - 2 * T);
+    unsigned tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bx = tile % ntx; tile /= ntx;
+    const int by = tile % nty;
+    const int b = tile / nty;
+    const int x = bx * (TXB - 2 * T) - T + tx;
     const bool x_in = x >= 0 && x < g.W;
     const int txl = tx > 0 ? tx - 1 : 0, txr = tx < TXB - 1 ? tx + 1 : TXB - 1;
     const size_t ps = (size_t)g.H * g.pc;
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(TXB * TYB) void k3_jacobi_xt(Geom3 g, const float *
         ty[c] = threadIdx.y + c * TYB;
         tyu[c] = ty[c] > 0 ? ty[c] - 1 : 0;
         tyd[c] = ty[c] < ROWS - 1 ? ty[c] + 1 : ROWS - 1;
-        const int y = blockIdx.y * (ROWS - 2 * T) - T + ty[c];
+        const int y = by * (ROWS - 2 * T) - T + ty[c];
         inside[c] = x_in && y >= 0 && y < g.H;
         lshell[c] = x <= 0 || x >= g.W - 1 || y <= 0 || y >= g.H - 1;      // (also true outside the grid)
         outc[c] = inside[c] && tx >= T && tx < TXB - T && ty[c] >= T && ty[c] < ROWS - T;
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(TXB * TYB) void k3_jacobi_xt(Geom3 g, const float *
 
 template <int T, int TXB, int TYB, int CY>
 static void launch3_jacobi_xt(const Geom3 &g, const float *cur, float *nxt, const float *div, hipStream_t st) {
-    dim3 block(TXB, TYB), grid(cdiv(g.W, TXB - 2 * T), cdiv(g.H, TYB * CY - 2 * T), g.B);
+    dim3 block(TXB, TYB), grid((unsigned)(cdiv(g.W, TXB - 2 * T) * cdiv(g.H, TYB * CY - 2 * T) * g.B));
     hipLaunchKernelGGL((k3_jacobi_xt<T, TXB, TYB, CY>), grid, block, 0, st, g, cur, nxt, div);
 }
 
