@@ -452,6 +452,170 @@ __global__ __launch_bounds__(NW * 64, MINW) void k3_advect_march(Geom3 g, State3
     }
 }
 
+// ---------------------------------------------------------------- buoyancy + the four diffusions + the divergence, marching along z
+// SPEC_3D.md sections 3, 4 (navier_stokes.py:50-72,136,154-160).  Same organisation as k3_advect_march: a workgroup owns a TY x 64 column of
+// cells, the inputs live in LDS as rings of three planes of the (TY+3) x 67 window whose out-of-grid elements hold the CLAMPED in-grid
+// value -- which IS the replicate padding of diffusion_step -- with the step's buoyancy (v[..., :-1] += dt (0.1 density)) applied to v as
+// it is staged.  Every neighbour of a cell is an LDS read; every input element leaves HBM / L2 once per workgroup.  A wave owns R rows
+// (thread = column): it forms the diffused u on its rows + 1, v on its rows and on the tile's extra column (lane = row; lane 63 takes its
+// x + 1 neighbour from there, the others from the next lane by DPP), w, density, and -- one plane later, when w2(z+1) exists -- the
+// divergence ((((u2[y+1] - u2[y]) + v2[x+1]) - v2[x]) + w2[z+1]) - w2[z]) / dt from its registers: launch3_divergence's re-read of the
+// three diffused velocities (1.6 GB at configs[4]) and its launch disappear.  Per cell the expression trees of diffuse3_at / k3_divergence.
+template <int R, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k3_diffuse_div_march(Geom3 g, State3 in, State3 out, float *__restrict__ divf) {
+    constexpr int TY = R * NW, TX = 64, NT = NW * 64;
+    constexpr int WR = TY + 3, WC = TX + 3, WP = 68, WPL = WR * WP;
+    constexpr int NST = (WR * WC + NT - 1) / NT;
+    __shared__ float Us[3 * WPL], Vs[3 * WPL], Ws[3 * WPL], Ds[3 * WPL];
+    const int D = g.D, H = g.H, W = g.W, pc = g.pc, pv = g.pv;
+    const int ntx = (W + TX - 1) / TX, nty = (H + TY - 1) / TY;
+    unsigned tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tix = tile % ntx; tile /= ntx;
+    const int tiy = tile % nty;
+    const int b = tile / nty;
+    const int x0 = tix * TX, y0 = tiy * TY;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *u = in.u + b * g.su, *v = in.v + b * g.sv, *w = in.w + b * g.sw, *d = in.d + b * g.sc;
+    float *uo = out.u + b * g.su, *vo = out.v + b * g.sv, *wo = out.w + b * g.sw, *dn = out.d + b * g.sc, *dv = divf + b * g.sc;
+    const int pus = (H + 1) * pc, pvs = H * pv, pcs = H * pc;
+    const float dt = g.dt, cuv = g.coef_uv, cd = g.coef_d;
+
+    int so[NST], gc[NST], gu[NST], gv[NST];
+    unsigned cond = 0;                                                    // bit it: element exists; 8 + it: v's element takes buoyancy (column < W)
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int e0 = tid + it * NT, e = e0 < WR * WC ? e0 : WR * WC - 1;
+        const int r = e / WC, c = e - r * WC;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        const int yc = clampi3(gy, 0, H - 1), xc = clampi3(gx, 0, W - 1), yu = clampi3(gy, 0, H), xv = clampi3(gx, 0, W);
+        so[it] = r * WP + c;
+        gc[it] = 4 * (yc * pc + xc);
+        gu[it] = 4 * (yu * pc + xc);
+        gv[it] = 4 * (yc * pv + xv);
+        if (e0 < WR * WC) cond |= 1u << it;
+        if (xv < W) cond |= 1u << (8 + it);
+    }
+    float ru[NST], rv[NST], rw[NST], rd[NST];
+    auto plane_rsrc = [](const float *base) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    };
+    auto ldb = [](__amdgpu_buffer_rsrc_t rs, int voff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0)); };
+    auto request = [&](int j) {                                         // planes j of u, v, density (clamped to D-1) and of w (clamped to D)
+        const int zu = clampi3(j, 0, D - 1), zw = clampi3(j, 0, D);
+        const __amdgpu_buffer_rsrc_t bu = plane_rsrc(u + (size_t)zu * pus), bv = plane_rsrc(v + (size_t)zu * pvs);
+        const __amdgpu_buffer_rsrc_t bw = plane_rsrc(w + (size_t)zw * pcs), bd = plane_rsrc(d + (size_t)zu * pcs);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            ru[it] = ldb(bu, gu[it]);
+            rv[it] = ldb(bv, gv[it]);
+            rw[it] = ldb(bw, gc[it]);
+            rd[it] = ldb(bd, gc[it]);
+        }
+    };
+    auto commit = [&](int slot) {
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            float bq = rv[it];
+            if ((cond >> (8 + it)) & 1u) {                                  // navier_stokes.py:154-155: two fp32 roundings
+                const float bb = rd[it] * 0.1f;
+                bq = bq + dt * bb;
+            }
+            if ((cond >> it) & 1u) {
+                Us[slot + so[it]] = ru[it];
+                Vs[slot + so[it]] = bq;
+                Ws[slot + so[it]] = rw[it];
+                Ds[slot + so[it]] = rd[it];
+            }
+        }
+    };
+    auto slot3 = [](int j) { return ((j + 3) % 3) * WPL; };
+    request(-1); commit(slot3(-1));
+    request(0);  commit(slot3(0));
+    request(1);  commit(slot3(1));
+    __syncthreads();
+
+    const int rb = wv * R, yb = y0 + rb;
+    const int x = x0 + lane, x4 = 4 * x;
+    const int wbase = (rb + 1) * WP + lane + 1;
+    const int wex = (rb + 1 + (lane < R ? lane : R - 1)) * WP + TX + 1;    // extra-column unit: lane = row, column x0 + TX
+    auto stb = [&](float *rowbase, int voff, float val) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), __builtin_amdgcn_make_buffer_rsrc(rowbase, 0, 0x7fffffff, 0x00020000), voff, 0, 0);
+    };
+    // diffuse3_at on the rings: centre, up (row-1), down, left, right, front (plane-1), back
+    auto diffuse = [&](const float *ring, int sm, int sc, int sp, int w0, float coef) -> float {
+        const float c = ring[sc + w0];
+        float lap = ring[sc + w0 - WP] + ring[sc + w0 + WP];
+        lap = lap + ring[sc + w0 - 1];
+        lap = lap + ring[sc + w0 + 1];
+        lap = lap + ring[sm + w0];
+        lap = lap + ring[sp + w0];
+        lap = lap - 6.0f * c;
+        return c + coef * lap;
+    };
+    float a3[R], wprev[R];                                                 // ((u2[y+1] - u2[y]) + v2[x+1]) - v2[x] and w2 of the previous plane
+#pragma unroll
+    for (int r = 0; r < R; ++r) { a3[r] = 0.f; wprev[r] = 0.f; }
+    const bool xin = x < W;
+    int sm = slot3(-1), sc = slot3(0), sp = slot3(1);
+    for (int k = 0; k <= D; ++k) {
+        if (k < D) request(k + 2);
+        float u2[R + 1], v2[R], v2x[R], w2[R];
+        // ---- w2(k), k = 0 .. D; then the divergence of plane k-1
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int y = yb + r;
+            w2[r] = diffuse(Ws, sm, sc, sp, wbase + r * WP, cuv);
+            if (y < H && xin) {
+                stb(wo + (size_t)(k * H + y) * pc, x4, w2[r]);
+                if (k >= 1) {
+                    float a = a3[r] + w2[r];
+                    a = a - wprev[r];
+                    stb(dv + (size_t)((k - 1) * H + y) * pc, x4, __fdiv_rn(a, dt));
+                }
+            }
+        }
+        if (k < D) {
+            // ---- u2 on rows 0 .. R, v2 on rows 0 .. R-1 (+ the extra column), density
+#pragma unroll
+            for (int r = 0; r <= R; ++r) {
+                const int y = yb + r;
+                u2[r] = diffuse(Us, sm, sc, sp, wbase + r * WP, cuv);
+                if ((r < R || y == H) && y <= H && xin) stb(uo + (size_t)(k * (H + 1) + y) * pc, x4, u2[r]);
+            }
+            const float vex = diffuse(Vs, sm, sc, sp, wex, cuv);            // lane l: v2 at (row yb + l, column x0 + TX)
+            if (x0 + TX == W && lane < R && yb + lane < H) stb(vo + (size_t)(k * H + yb + lane) * pv, 4 * W, vex);      // the field's own last column
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = yb + r;
+                v2[r] = diffuse(Vs, sm, sc, sp, wbase + r * WP, cuv);
+                v2x[r] = shl1_with(v2[r], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vex), r)));
+                const float d2 = diffuse(Ds, sm, sc, sp, wbase + r * WP, cd);
+                if (y < H) {
+                    if (x <= W) stb(vo + (size_t)(k * H + y) * pv, x4, v2[r]);      // (x = W: the last column of a tile narrower than 64)
+                    if (xin) stb(dn + (size_t)(k * H + y) * pc, x4, d2);
+                }
+                float a = u2[r + 1] - u2[r];
+                a = a + v2x[r];
+                a3[r] = a - v2[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) wprev[r] = w2[r];
+        __syncthreads();
+        if (k < D) commit(sm);
+        __syncthreads();
+        { const int t = sm; sm = sc; sc = sp; sp = t; }
+    }
+}
+
+hipError_t launch3_diffuse_div_march(const Geom3 &g, State3 in, State3 out, float *div, hipStream_t st) {
+    constexpr int R = 4, NW = 4;
+    const long long nb = (long long)cdiv(g.W, 64) * cdiv(g.H, R * NW) * g.B;
+    if (nb > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k3_diffuse_div_march<R, NW>), dim3((unsigned)nb), dim3(NW * 64), 0, st, g, in, out, div);
+    return hipGetLastError();
+}
+
 template <int R, int NW, int MINW, int BU, bool GRAD>
 static hipError_t launch3_advect_march_t(const Geom3 &g, State3 in, const float *p, State3 out, float *frames, int64_t fsb, hipStream_t st) {
     const long long nb = (long long)cdiv(g.W, 64) * cdiv(g.H, R * NW) * g.B;

@@ -585,16 +585,35 @@ int smk_sim3d_step(smk_sim3d *sim, int32_t n_steps, float *frames, int64_t fsb, 
     static const bool staged = getenv("SMK_ADVECT3_STAGED") != nullptr;
     static const bool tiled = getenv("SMK_ADVECT3_TILE") != nullptr;
     static const bool fold_grad = !staged && !tiled && !(getenv("SMK_ADVECT3_GRAD") && atoi(getenv("SMK_ADVECT3_GRAD")) == 0);
+    // SMK_DIFFUSE3_FUSED=0: buoyancy + diffusion and the divergence as two launches (the per-stage forms) instead of the z-marching one
+    static const bool fused_dd = !(getenv("SMK_DIFFUSE3_FUSED") && atoi(getenv("SMK_DIFFUSE3_FUSED")) == 0);
+    const Geom3 &g = sim->g;
     for (int t = 0; t < n_steps; ++t) {
         float *ft = frames ? frames + (size_t)t * fst : nullptr;
-        const int last = staged ? SMK_STAGE3D_ADVECT_D : SMK_STAGE3D_PROJECT;
-        for (int stage = SMK_STAGE3D_BUOY_DIFFUSE; stage <= last; ++stage) {
-            const int rc = run_stage3d(sim, stage, stage == SMK_STAGE3D_ADVECT_D ? ft : nullptr, fsb, st, fold_grad);
+        int rc;
+        if (fused_dd) {
+            rc = check_launch(launch3_diffuse_div_march(g, sim->s, sim->t, sim->div, st), "diffuse_div_march3d");
             if (rc) return rc;
+            rc = check_launch(launch3_jacobi(g, sim->s.p, sim->t.p, sim->div, sim->jacobi_iters, st), "jacobi3d");
+            if (rc) return rc;
+            if (!fold_grad) {
+                rc = check_launch(launch3_grad_subtract(g, sim->t, sim->s.p, st), "grad_subtract3d");
+                if (rc) return rc;
+            }
+        } else {
+            for (int stage = SMK_STAGE3D_BUOY_DIFFUSE; stage <= SMK_STAGE3D_PROJECT; ++stage) {
+                rc = run_stage3d(sim, stage, nullptr, fsb, st, fold_grad);
+                if (rc) return rc;
+            }
         }
-        if (!staged) {
-            const int rc = tiled ? check_launch(launch3_advect_fused(sim->g, sim->t, sim->s, ft, fsb, st), "advect_fused3d")
-                                 : check_launch(launch3_advect_march(sim->g, sim->t, fold_grad ? sim->s.p : nullptr, sim->s, ft, fsb, st), "advect_march3d");
+        if (staged) {
+            for (int stage = SMK_STAGE3D_ADVECT_U; stage <= SMK_STAGE3D_ADVECT_D; ++stage) {
+                rc = run_stage3d(sim, stage, stage == SMK_STAGE3D_ADVECT_D ? ft : nullptr, fsb, st);
+                if (rc) return rc;
+            }
+        } else {
+            rc = tiled ? check_launch(launch3_advect_fused(g, sim->t, sim->s, ft, fsb, st), "advect_fused3d")
+                       : check_launch(launch3_advect_march(g, sim->t, fold_grad ? sim->s.p : nullptr, sim->s, ft, fsb, st), "advect_march3d");
             if (rc) return rc;
         }
     }

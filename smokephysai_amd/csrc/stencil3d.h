@@ -21,6 +21,8 @@ hipError_t launch3_zero(const Geom3 &g, State3 s, const uint8_t *dev_mask, hipSt
 hipError_t launch3_add_sources(const Geom3 &g, float *density, const Src3Dev *src, const int *first, hipStream_t st);
 hipError_t launch3_buoy_diffuse(const Geom3 &g, State3 in, State3 out, hipStream_t st);
 hipError_t launch3_divergence(const Geom3 &g, State3 s, float *div, hipStream_t st);
+// buoyancy + the four diffusions + the divergence of the diffused velocities as ONE z-marching launch (bit-identical to the two launches)
+hipError_t launch3_diffuse_div_march(const Geom3 &g, State3 in, State3 out, float *div, hipStream_t st);
 // `iters` sweeps on `div`; result in p (p2 scratch of the same layout)
 hipError_t launch3_jacobi(const Geom3 &g, float *p, float *p2, const float *div, int iters, hipStream_t st);
 hipError_t launch3_grad_subtract(const Geom3 &g, State3 s, const float *p, hipStream_t st);
