@@ -160,8 +160,11 @@ def dataset_leg(dev, N=128, samples=512, cpu_budget_s=8.0):
 
 
 def config4_measure(dev, steps=6, rank=0, world=1):
-    """This rank's share of configs[4] (8 / world volumes of 512 x 512 x 64, Jacobi-20, SPEC_3D.md): ms per stepper step (HIP events on the
-    launch stream) and ms per encoded volume (all of the step's volumes through HipEncoder3D).  No collective in here."""
+    """This rank's share of configs[4] (8 / world volumes of 512 x 512 x 64, Jacobi-20, SPEC_3D.md) as the PIPELINE it is: every timed step is
+    one `step_into` of the stepper followed by HipEncoder3D on all the volumes that step emitted, HIP events on the launch stream around
+    both parts.  Returns ms per step of: the stepper, the encoder (per volume), the whole step (event to event) -- and the encoder's time
+    per volume on DENSE input (U(0, 1.8), the fixtures' dense-frame distribution: matrix-core power depends on the data).  No collective."""
+    from smokephysai_amd.models import HipEncoder3D
     from smokephysai_amd.physics import NavierStokesSimulator3D
     B_total, D, H, W, J = 8, 64, 512, 512, 20
     B = B_total // world
@@ -169,19 +172,6 @@ def config4_measure(dev, steps=6, rank=0, world=1):
     rng = np.random.RandomState(4 + rank)
     sim.add_smoke_sources([(b, int(rng.randint(40, W - 40)), int(rng.randint(40, H - 40)), int(rng.randint(10, D - 10)), 8,
                             float(rng.uniform(0.5, 2.0))) for b in range(B) for _ in range(3)])
-    frame = torch.empty(B, D, H, W, device=dev)
-    for _ in range(2):
-        sim.step_into(frame, 1)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    ev[0].record()
-    for k in range(steps):
-        sim.step_into(frame, 1)
-        ev[k + 1].record()
-    torch.cuda.synchronize(dev)
-    assert torch.isfinite(frame).all() and float(frame.abs().sum()) > 0
-    ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]))
-    # the encoder (SPEC_3D.md section 8) on the step's emitted volumes (one volume first, untimed: buffers, first-use setup)
-    from smokephysai_amd.models import HipEncoder3D
     g = torch.Generator().manual_seed(0)
     w = {"conv1_w": torch.randn(64, 1, 7, 7, 7, generator=g) * 0.05, "conv1_b": torch.randn(64, generator=g) * 0.1,
          "bn1_w": torch.rand(64, generator=g) + 0.5, "bn1_b": torch.randn(64, generator=g) * 0.1, "bn1_mean": torch.randn(64, generator=g) * 0.2,
@@ -189,42 +179,95 @@ def config4_measure(dev, steps=6, rank=0, world=1):
          "conv2_b": torch.randn(128, generator=g) * 0.1, "bn2_w": torch.rand(128, generator=g) + 0.5, "bn2_b": torch.randn(128, generator=g) * 0.1,
          "bn2_mean": torch.randn(128, generator=g) * 0.2, "bn2_var": torch.rand(128, generator=g) + 0.3}
     enc = HipEncoder3D(w, device=dev)
-    enc(frame[:1])
+    frame = torch.empty(B, D, H, W, device=dev)
+    for _ in range(2):                                       # untimed: buffers, first-use setup, clocks
+        sim.step_into(frame, 1)
+        feats = enc(frame)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    feats = enc(frame)
+    for k in range(steps):
+        ev[k][0].record()
+        sim.step_into(frame, 1)
+        ev[k][1].record()
+        feats = enc(frame)
+        ev[k][2].record()
     torch.cuda.synchronize(dev)
-    ms_enc = (time.perf_counter() - t0) * 1e3 / B
+    assert torch.isfinite(frame).all() and float(frame.abs().sum()) > 0
     assert feats.shape == (B, 128, 32, 32) and torch.isfinite(feats).all()
-    return ms, ms_enc
+    ms_sim = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_enc = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) / B
+    ms_step = ev[0][0].elapsed_time(ev[-1][2]) / steps      # first record to last record: launch gaps between the parts included
+    dense = torch.rand(1, D, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 1.8
+    enc(dense)
+    d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    d0.record()
+    for _ in range(3):
+        enc(dense)
+    d1.record()
+    torch.cuda.synchronize(dev)
+    return ms_sim, ms_enc, ms_step, d0.elapsed_time(d1) / 3
 
 
-def config4_block(ms, ms_enc, steps=6, world=1):
-    """The `config4` block of the bench line from the (max-over-ranks) component times."""
+def sim3d_counters():
+    """HBM bytes per configs[4] stepper step from the committed rocprofv3 --pmc passes (tools/pmc_sim3d.sh -> profiles/r04/sim3d_pmc.json):
+    replayed, not measured live, with the stamp of the sources they were taken on."""
+    f = os.path.join(ROOT, "profiles", "r04", "sim3d_pmc.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    st = d.get("stamp", {})
+    return {"bytes_per_step": d["per_step"]["hbm_bytes"], "fetch": d["per_step"]["hbm_fetch_bytes"], "write": d["per_step"]["hbm_write_bytes"],
+            "kernel_us_per_step_under_profiler": d["per_step"]["kernel_us"],
+            "by_kernel": {k: {"launches_per_step": e.get("launches_per_step"), "us": e.get("us_per_launch_trace"),
+                              "bytes": round(e.get("hbm_fetch_bytes_per_launch", 0) + e.get("hbm_write_bytes_per_launch", 0))}
+                          for k, e in d["kernels"].items()},
+            "source": {"file": "profiles/r04/sim3d_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2 as "
+                               "MI355X_MICROARCH.md prescribes for gfx950: it counts the L2's fabric-side requests, Infinity-Cache hits included)",
+                       "stamp": st, "stale": st.get("csrc_sha256") != source_stamp()["csrc_sha256"]}}
+
+
+def config4_block(ms, ms_enc, ms_step, ms_enc_dense, steps=6, world=1):
+    """The `config4` block of the bench line from the (max-over-ranks) times of the pipelined steps."""
     B_total, D, H, W, J = 8, 64, 512, 512, 20
     B = B_total // world
     cells = B * D * H * W
     alg = cells * 4.0 * (37 + 3 * J)
     gbs = alg / (ms * 1e-3) / 1e9
     enc_flop = 2.0 * D * H * W * (343 * 64 + 27 * 64 * 128)
-    ms_total = ms + B * ms_enc
+    roof_st = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+               "note": "per GPU.  achieved / frac = PASS-MODEL bytes 4*(37+3J) per cell (SPEC_3D.md section 7) over the measured time: work done "
+                       "per second in the survey's unit, NOT utilisation of the pins -- the launches move fewer bytes (diffusion + divergence "
+                       "fused, four Jacobi sweeps per launch, gradient subtraction + four advections fused).  traffic / measured_GBs / "
+                       "frac_measured = HBM-side bytes from the rocprofv3 counters over the live time"}
+    c = sim3d_counters()
+    if c is not None and world == 1:
+        roof_st.update({"traffic": c["bytes_per_step"], "traffic_split": {"fetch": c["fetch"], "write": c["write"]}, "traffic_by_kernel": c["by_kernel"],
+                        "traffic_source": c["source"], "measured_GBs": c["bytes_per_step"] / (ms * 1e-3) / 1e9,
+                        "frac_measured": c["bytes_per_step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "compulsory_bytes_per_step": cells * 4.0 * (9 + 3 * 6 + 10),
+                        "compulsory_note": "4 in + 5 out (diffuse + divergence), 6 Jacobi launches x (p, div in; p out), 5 in + 5 out (advection with the gradient subtraction and the frame)"})
+    tf = enc_flop / (ms_enc * 1e-3) / 1e12
+    tfd = enc_flop / (ms_enc_dense * 1e-3) / 1e12
     return {"workload": f"configs[4]: {W}x{H}x{D} grid, batch {B_total} ({B} per GPU), Jacobi-{J} (SPEC_3D.md), conv3d encoder -> [B,128,32,32]",
-            "value": B_total / (ms_total * 1e-3), "unit": "volumes/s (simulated + encoded, whole job)", "ms_per_step": ms_total, "n_gpus": world,
+            "value": B_total / (ms_step * 1e-3), "unit": "volumes/s (simulated + encoded, whole job)", "ms_per_step": ms_step, "n_gpus": world,
+            "timing": "pipelined: every timed step = the stepper's step then the encoder on the volumes it emitted, one stream, HIP events; "
+                      "ms_per_step = first event to last event / steps",
             "volumes_per_gpu": B, "parallelism": f"independent volumes sharded over {world} GPU(s), no data-path collective; times = max over ranks",
-            "ms_sim_per_step": ms, "sim_only_volumes_per_s": B_total / (ms * 1e-3), "ms_encode_per_volume": ms_enc, "steps": steps, "dtype": "f32 stencil + bf16x3 GEMM",
+            "ms_sim_per_step": ms, "sim_only_volumes_per_s": B_total / (ms * 1e-3), "ms_encode_per_volume": ms_enc,
+            "ms_encode_per_volume_dense": ms_enc_dense, "steps": steps, "dtype": "f32 stencil + bf16x3 GEMM",
             "cells_per_step": cells, "algorithmic_bytes_per_step": alg,
-            "launches_per_step": "4 + ceil(J / 4): buoyancy+diffusion (z-marching), divergence, Jacobi in 4-sweep temporally blocked launches, "
-                                 "gradient subtraction, the four advections as one launch",
-            "roofline_stencil": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "note": "per GPU: pass-model bytes 4*(37+3J) per cell (SPEC_3D.md section 7) over the measured time; the kernels move fewer "
-                                         "(four Jacobi sweeps per launch, one advection launch), so like the 2-D figure this is work done per "
-                                         "second in the survey's unit, not a bound on the pins"},
+            "launches_per_step": "2 + ceil(J / 4) + 1: buoyancy + diffusion + divergence (one z-marching launch), Jacobi in 4-sweep temporally blocked "
+                                 "launches, gradient subtraction + the four advections (one z-marching launch)",
+            "roofline_stencil": roof_st,
             "roofline_encoder": {"bound": "mfma", "kernel": "conv1: k_conv3d_s7_march (weights in registers, fragment tables in LDS), conv2 + depth pooling: k_conv3d_march "
                                                             "(three input planes in LDS, 27 taps per plane from there); k_pool3d_accum on the depth sums",
-                                 "achieved": enc_flop / (ms_enc * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s",
-                                 "frac": enc_flop / (ms_enc * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16x3"],
-                                 "note": "per GPU; features 4e-6 from the fp64 oracle (tolerance 1e-4); the x3 split executes 3 MFMA products per counted multiply (frac 0.33 = the matrix "
-                                         "pipe full); every volume of the step timed; conv1's output (4.3 GB per volume) is the one activation still written to HBM"}}
+                                 "achieved": tf, "peak": MFMA_PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS["bf16x3"],
+                                 "achieved_dense": tfd, "frac_dense": tfd / MFMA_PEAK_TFLOPS["bf16x3"],
+                                 "note": "per GPU; achieved = the stepper's own volumes (mostly background), achieved_dense = U(0, 1.8) volumes -- the "
+                                         "figure the kernel profile under profiles/ (tools/pmc_enc3d.sh, random data) corresponds to; the matrix pipe "
+                                         "clocks lower on dense operands.  Features 4e-6 from the fp64 oracle (tolerance 1e-4); the x3 split executes 3 "
+                                         "MFMA products per counted multiply (frac 0.33 = the matrix pipe full); conv1's output (4.3 GB per volume) is "
+                                         "the one activation still written to HBM"}}
 
 
 def config4_leg(dev, steps=6, rank=0, world=1, dist=None, backend="nccl"):
@@ -233,20 +276,20 @@ def config4_leg(dev, steps=6, rank=0, world=1, dist=None, backend="nccl"):
     data-path collective (8 / N per GPU; every rank runs this leg); each component is the MAX over ranks.  A rank whose share fails still
     takes part in the one collective of the leg (a failure flag travels with the times), so the others never wait for it."""
     err = None
-    ms = ms_enc = 0.0
+    vals = [0.0, 0.0, 0.0, 0.0]
     try:
-        ms, ms_enc = config4_measure(dev, steps, rank, world)
+        vals = list(config4_measure(dev, steps, rank, world))
     except Exception as e:        # noqa: BLE001 -- reported in the block; the headline line must still be printed
         if dist is None:
             raise
         err = f"rank {rank}: {type(e).__name__}: {e}"
     if dist is not None:
-        t = torch.tensor([ms, ms_enc, 0.0 if err is None else 1.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor(vals + [0.0 if err is None else 1.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if float(t[2].item()) > 0:
+        if float(t[4].item()) > 0:
             return {"error": err or "another rank failed in its share of the leg", "n_gpus": world}
-        ms, ms_enc = float(t[0].item()), float(t[1].item())
-    return config4_block(ms, ms_enc, steps, world)
+        vals = [float(x) for x in t[:4].tolist()]
+    return config4_block(*vals, steps=steps, world=world)
 
 
 def hbm_copy_gbs(dev):
@@ -681,6 +724,21 @@ def main(argv=None):
         leg_order.append("alt")
     elapsed, ms_sim, ms_enc = timed(args.encoder_dtype)
     leg_order.append("headline")
+    ms_enc_dense = None
+    if not args.no_encode and rank == 0:
+        # the same encoder launch on DENSE frames (U(0, 1.8), the fixtures' dense-frame distribution): the simulated frames above are
+        # > 99 % background and matrix-core power (hence clock) depends on the operand data
+        dense = torch.rand(B, N, N, device=dev, generator=torch.Generator(device=dev).manual_seed(7)) * 1.8
+        run = (lambda: enc(dense, input_dim=128, dtype="f32")) if args.encoder_dtype == "f32" else (lambda: enc.tokens(dense, input_dim=128, dtype=args.encoder_dtype))
+        for _ in range(max(W, 2)):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(K):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_enc_dense = e0.elapsed_time(e1) / K
     config4_sharded = None
     if world > 1 and 8 % world == 0 and not args.no_config4 and not args.no_encode:
         config4_sharded = config4_leg(dev, rank=rank, world=world, dist=dist, backend=backend)      # every rank: 8 / N volumes each
@@ -726,6 +784,13 @@ def main(argv=None):
                                 "counted multiply (split operands), so matrix-pipe work is 3x the counted figure"}
             if args.encoder_dtype in ("bf16x3", "i8x3"):
                 roof_enc["mfma_work_frac"] = 3.0 * tf / peak if args.encoder_dtype == "bf16x3" else None
+            if ms_enc_dense is not None:
+                tfd = enc_flops / (ms_enc_dense * 1e-3) / 1e12
+                out["encode_only_dense"] = {"input": f"{B} frames of U(0, 1.8) at {N}x{N} (every pixel non-zero), same launch as the headline's encoder",
+                                            "ms_per_launch": ms_enc_dense, "frames_per_s": B / (ms_enc_dense * 1e-3), "counted_TFLOPs": tfd,
+                                            "frac": tfd / peak, "vs_simulated_frames": ms_enc_dense / ms_enc}
+                roof_enc["achieved_dense"] = tfd
+                roof_enc["frac_dense"] = tfd / peak
             out.update({"encode_only_frames_per_s": B / (ms_enc * 1e-3), "ms_encode_per_step": ms_enc,
                         "roofline": roof_enc if ms_enc >= ms_sim else roof_stencil,
                         "roofline_stencil": roof_stencil, "roofline_encoder": roof_enc})

@@ -76,7 +76,10 @@ def test_self_launched_two_ranks_gloo_rehearsal():
     # configs[4] (quoted on 8 GPUs) shards its 8 volumes over the ranks: 4 each here, no collective on the data path
     c4 = d["config4"]
     assert c4["n_gpus"] == 2 and c4["volumes_per_gpu"] == 4 and c4["value"] > 0
-    assert abs(c4["ms_per_step"] - (c4["ms_sim_per_step"] + 4 * c4["ms_encode_per_volume"])) < 1e-6
+    # measured as a pipeline (step -> encode -> step ...): the whole step is the two parts plus the launch gaps between them
+    parts = c4["ms_sim_per_step"] + 4 * c4["ms_encode_per_volume"]
+    assert 0.98 * parts <= c4["ms_per_step"] <= 1.25 * parts, (c4["ms_per_step"], parts)
+    assert c4["ms_encode_per_volume_dense"] > 0 and "pipelined" in c4["timing"]
     ts = d["train_step"]
     assert "error" not in ts, ts
     assert ts["ranks"] == 2 and ts["global_batch"] == 8 and ts["ms_per_step"] > 0

@@ -145,6 +145,12 @@ def main():
     args = parser.parse_args()
     config = load_config(args.config)
     hw = config.get("mi355x", {}) or {}
+    if hw.get("deterministic", False):
+        # run-to-run reproducible steps: MIOpen's default backward-weights solvers for the reconstruction head's three convolutions
+        # accumulate with atomics (the only non-reproducible op of the step: tools/rccl_diag.py); this restricts MIOpen to its
+        # deterministic solvers.  Every libsmokehip kernel is deterministic either way.
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
     rank, world, local_rank = init_distributed()
     exp_dir, writer, device = setup_experiment(config, rank, local_rank)
 
