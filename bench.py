@@ -485,14 +485,15 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None, force_dis
         # SURVEY 8f-3's alternative on the same bytes: all-to-all of the shards + ordered local sum + all-gather (every xGMI link busy
         # for two hops instead of a ring's 2 (N-1) dependent hops) -- first as flat collectives, then as the DDP hook inside the step
         res["stage"] = "flat direct exchange"
-        shard = (nparam + world - 1) // world
-        send, recv = torch.zeros(world * shard, device=flat.device), torch.empty(world * shard, device=flat.device)
-        out = torch.empty(world * shard, device=flat.device)
+        from smokephysai_amd.utils.distributed import DirectExchangeState, direct_exchange_hook
 
-        def direct_once():
-            dist.all_to_all_single(recv, send)
-            mine = recv.view(world, shard).sum(0) / world
-            dist.all_gather_into_tensor(out, mine)
+        class _Bucket:                                       # what DDP hands the hook: the flat gradient bucket
+            def __init__(self, t): self.t = t
+            def buffer(self): return self.t
+        dstate = DirectExchangeState(None, None)
+
+        def direct_once():                                   # the hook itself on the whole gradient as ONE bucket (111 MB)
+            direct_exchange_hook(dstate, _Bucket(flat)).wait()
         for _ in range(2):
             direct_once()
         torch.cuda.synchronize(); dist.barrier()
@@ -502,8 +503,10 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None, force_dis
         torch.cuda.synchronize()
         dr = (time.perf_counter() - t0) / 5
         res["direct_exchange_flat"] = {"bytes": nparam * 4, "ms": dr * 1e3, "algbw_GBs": nparam * 4 / dr / 1e9,
-                                       "what": "all_to_all_single + local sum in rank order + all_gather_into_tensor"}
-        del ddp, send, recv, out, flat
+                                       "what": "utils.distributed.direct_exchange_hook on the flat gradient: all_to_all_single straight from the bucket, "
+                                               "smk_reduce_shards (one launch: rank-order fp32 sum / N into the owner's slice), in-place "
+                                               "all_gather_into_tensor; one rank: nothing to move"}
+        del ddp, flat
         import gc
         gc.collect()                                         # (the first wrapper's reducer hooks go with it)
         res["stage"] = "direct-exchange steps"

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 15
+#define SMK_ABI_VERSION 16
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -372,6 +372,16 @@ int smk_lorenz_states(const float *noise, int32_t B, double sigma, double rho, d
  * passes the forward's seed and p and no mask tensor exists (p is applied in units of 2^-16; p = 0 keeps every element). */
 enum smk_elt_op { SMK_ELT_GELU_DROPOUT_FWD = 0, SMK_ELT_GELU_DROPOUT_BWD = 1, SMK_ELT_DROPOUT_ADD_FWD = 2, SMK_ELT_DROPOUT_BWD = 3 };
 int smk_ffn_elementwise(int32_t op, const float *a, const float *b, float *out, int64_t n, double p, uint64_t seed, void *stream);
+
+/* The owner's pass of the direct gradient exchange (hooks in where the reference steps the optimiser,
+ * /root/reference/train.py:88-93 -- the reference itself is single-process and has no exchange): rank r holds `world` shards of n
+ * gradients each (its own and the ones the all-to-all brought in, `stride` elements apart) and forms their MEAN: the sum in rank
+ * order in fp32 (the same order on every rank, element and run: deterministic), a true divide by `world`, written as fp32 or bf16.
+ * dtype: SMK_WIRE_F32 / SMK_WIRE_BF16 for input and output independently (world = 1 makes it the converter of the bf16 wire mode).
+ * In place (out == shards) is allowed when the dtypes agree.  fp32 operands 16-byte aligned, bf16 operands 8-byte aligned, stride a
+ * multiple of 4.  Enqueued on `stream`. */
+enum smk_wire_dtype { SMK_WIRE_F32 = 0, SMK_WIRE_BF16 = 1 };
+int smk_reduce_shards(const void *shards, int32_t in_dtype, int32_t world, int64_t n, int64_t stride, void *out, int32_t out_dtype, void *stream);
 
 /* Training-mode BatchNorm2d (batch statistics) + ReLU + pool x pool mean pooling of an NCHW fp32 convolution output -- the
  * norm / activation / pool blocks of SmokePhysNet.input_encoder under autograd (smokephys_net.py:24-32 Conv -> BatchNorm2d -> ReLU,

@@ -7,7 +7,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMOKEHIP_LIB") or os.path.join(_HERE, "libsmokehip.so")   # SMOKEHIP_LIB: diagnostic builds only
 
-ABI_VERSION = 15                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
+ABI_VERSION = 16                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
 SMK_ERR_TIMEOUT = -5
 SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
 SMK_ACT_NONE, SMK_ACT_GELU, SMK_ACT_RELU = 0, 1, 2
@@ -112,6 +112,7 @@ _SIGNATURES = {
     "smk_attention_backward": [C.c_void_p] * 9 + [C.c_int32] * 4 + [C.c_int64] * 7 + [C.c_double, C.c_void_p],
     "smk_lorenz_states": [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     "smk_ffn_elementwise": [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p],
+    "smk_reduce_shards": [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p],
     "smk_conv1_train_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
     "smk_conv1_train_wgrad": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_conv2_train_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],

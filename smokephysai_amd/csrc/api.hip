@@ -1148,6 +1148,16 @@ int smk_ffn_elementwise(int32_t op, const float *a, const float *b, float *out, 
     }
 }
 
+int smk_reduce_shards(const void *shards, int32_t in_dtype, int32_t world, int64_t n, int64_t stride, void *out, int32_t out_dtype, void *stream) {
+    SMK_REQUIRE(shards && out && n >= 0 && world >= 1, "null shards / out, negative n or world < 1");
+    SMK_REQUIRE((in_dtype == SMK_WIRE_F32 || in_dtype == SMK_WIRE_BF16) && (out_dtype == SMK_WIRE_F32 || out_dtype == SMK_WIRE_BF16), "dtype: smk_wire_dtype");
+    SMK_REQUIRE(world == 1 || (stride >= n && stride % 4 == 0), "stride >= n and a multiple of 4");
+    SMK_REQUIRE(((uintptr_t)shards & (in_dtype == SMK_WIRE_F32 ? 15 : 7)) == 0 && ((uintptr_t)out & (out_dtype == SMK_WIRE_F32 ? 15 : 7)) == 0,
+                "fp32 operands 16-byte aligned, bf16 operands 8-byte aligned");
+    SMK_REQUIRE(shards != out || in_dtype == out_dtype, "in place needs equal dtypes");
+    return check_launch(launch_reduce_shards(shards, in_dtype == SMK_WIRE_BF16, world, n, stride, out, out_dtype == SMK_WIRE_BF16, (hipStream_t)stream), "reduce_shards");
+}
+
 // ------------------------------------------------------------------ softmax attention (chaos term folded into Q)
 int smk_attention(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
                   int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,

@@ -20,4 +20,8 @@ hipError_t launch_gelu_dropout_bwd(const EltArgs &e, hipStream_t st);      // a 
 hipError_t launch_dropout_add_fwd(const EltArgs &e, hipStream_t st);       // a = y, b = res   -> out = res + dropout(y)
 hipError_t launch_dropout_bwd(const EltArgs &e, hipStream_t st);           // a = dout         -> out = dy
 
+// out[i] = (sum over `world` shards, rank order, fp32) / world; shards `stride` elements apart; in / out fp32 or bf16 (the wire dtype of
+// the direct gradient exchange, utils/distributed.py); 16-byte (fp32) / 8-byte (bf16) aligned operands, stride a multiple of 4
+hipError_t launch_reduce_shards(const void *in, int in_bf16, int world, long long n, long long stride, void *out, int out_bf16, hipStream_t st);
+
 }  // namespace smk

@@ -85,4 +85,72 @@ hipError_t launch_gelu_dropout_bwd(const EltArgs &e, hipStream_t st) { return la
 hipError_t launch_dropout_add_fwd(const EltArgs &e, hipStream_t st) { return launch_elt<2>(e, st); }
 hipError_t launch_dropout_bwd(const EltArgs &e, hipStream_t st) { return launch_elt<3>(e, st); }
 
+
+// ---------------------------------------------------------------- the owner's pass of the direct gradient exchange
+// out[i] = (((s_0[i] + s_1[i]) + ...) + s_{W-1}[i]) / W over W shards (one per source rank, `stride` elements apart), the sum in rank
+// order in fp32 -- the same order on every rank and run -- and a true divide, written in the wire dtype (fp32 or bf16).  One read of
+// every shard and one write: replaces zeros + copy_ + W casts + W adds + divide + cast of the eager form.  W = 1 is the dtype converter.
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void k_reduce_shards(const TI *__restrict__ in, int world, long long n, long long stride, TO *__restrict__ out) {
+    const float fw = (float)world;
+    const long long step = (long long)gridDim.x * 256 * 4;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += step) {
+        float acc[4];
+        if (i + 4 <= n) {
+            auto load4 = [&](const TI *p) {
+                if constexpr (sizeof(TI) == 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(p);
+                    acc[0] = v.x; acc[1] = v.y; acc[2] = v.z; acc[3] = v.w;
+                } else {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+                    acc[0] = __uint_as_float(v.x << 16); acc[1] = __uint_as_float(v.x & 0xffff0000u);
+                    acc[2] = __uint_as_float(v.y << 16); acc[3] = __uint_as_float(v.y & 0xffff0000u);
+                }
+            };
+            float sum[4];
+            load4(in + i);
+            for (int k = 0; k < 4; ++k) sum[k] = acc[k];
+            for (int r = 1; r < world; ++r) {
+                load4(in + r * stride + i);
+                for (int k = 0; k < 4; ++k) sum[k] = sum[k] + acc[k];
+            }
+            if (world > 1)
+                for (int k = 0; k < 4; ++k) sum[k] = __fdiv_rn(sum[k], fw);
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4 *>(out + i) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+            } else {
+                __bf16 h[4];
+                for (int k = 0; k < 4; ++k) h[k] = (__bf16)sum[k];          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+                *reinterpret_cast<uint2 *>(out + i) = *reinterpret_cast<const uint2 *>(h);
+            }
+        } else {
+            for (long long j = i; j < n; ++j) {                              // ragged tail (n % 4)
+                auto ld = [&](const TI *p) -> float {
+                    if constexpr (sizeof(TI) == 4) return *reinterpret_cast<const float *>(p);
+                    else return __uint_as_float((unsigned)*reinterpret_cast<const unsigned short *>(p) << 16);
+                };
+                float sm = ld(in + j);
+                for (int r = 1; r < world; ++r) sm = sm + ld(in + r * stride + j);
+                if (world > 1) sm = __fdiv_rn(sm, fw);
+                if constexpr (sizeof(TO) == 4) out[j] = sm;
+                else { const __bf16 h = (__bf16)sm; out[j] = *reinterpret_cast<const unsigned short *>(&h); }
+            }
+        }
+    }
+}
+
+hipError_t launch_reduce_shards(const void *in, int in_bf16, int world, long long n, long long stride, void *out, int out_bf16, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n / 4 + 255) / 256;
+    const long long cap = (long long)device_num_cu() * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (!in_bf16 && !out_bf16) hipLaunchKernelGGL((k_reduce_shards<float, float>), grid, block, 0, st, (const float *)in, world, n, stride, (float *)out);
+    else if (!in_bf16) hipLaunchKernelGGL((k_reduce_shards<float, unsigned short>), grid, block, 0, st, (const float *)in, world, n, stride, (unsigned short *)out);
+    else if (!out_bf16) hipLaunchKernelGGL((k_reduce_shards<unsigned short, float>), grid, block, 0, st, (const unsigned short *)in, world, n, stride, (float *)out);
+    else hipLaunchKernelGGL((k_reduce_shards<unsigned short, unsigned short>), grid, block, 0, st, (const unsigned short *)in, world, n, stride, (unsigned short *)out);
+    return hipGetLastError();
+}
+
 }  // namespace smk

@@ -56,6 +56,25 @@ class DirectExchangeState:
         self.bytes_sent = 0
 
 
+def reduce_shards(shards: torch.Tensor, world: int, q: int, out: torch.Tensor) -> None:
+    """The owner's pass of the direct exchange: out[i] = (shards[0][i] + shards[1][i] + ... in rank order, fp32) / world, written in
+    out's dtype (fp32 or bf16).  `shards` is the flat [world * q] receive buffer.  Device tensors: ONE libsmokehip launch
+    (smk_reduce_shards: every shard read once, the mean written once).  Host tensors (the gloo rehearsal): the same arithmetic in torch."""
+    if shards.is_cuda:
+        from .. import _lib
+        code = {torch.float32: 0, torch.bfloat16: 1}
+        _lib.check(_lib.load().smk_reduce_shards(shards.data_ptr(), code[shards.dtype], world, q, q, out.data_ptr(), code[out.dtype],
+                                                 torch.cuda.current_stream(shards.device).cuda_stream))
+        return
+    parts = shards.view(world, q)
+    acc = parts[0].to(torch.float32)
+    for r in range(1, world):                               # rank order, one add per source: the same sum on every rank and run
+        acc = acc + parts[r].to(torch.float32)
+    if world > 1:
+        acc = acc / world
+    out.copy_(acc)
+
+
 def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) -> torch.futures.Future[torch.Tensor]:
     """DDP communication hook: the gradient mean as a DIRECT reduce-scatter + all-gather instead of a ring all-reduce.
 
@@ -64,36 +83,62 @@ def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) ->
     rank's bucket, one hop, all links busy; (2) the owner adds its N copies in rank order (the same order on every run and for every
     element: deterministic, unlike a ring whose summation order depends on the element's position) and divides by N; (3) all-gather of the
     reduced shards, one hop.  Each rank sends and receives (N-1)/N of the bucket twice -- the ring's byte count, in 2 hops instead of 2 (N-1).
-    `state.wire_dtype = torch.bfloat16` halves the bytes on both hops (the sum itself stays fp32); off by default because the averaged
-    gradient is then rounded to 8 bits.  Collectives are the backend's all_to_all_single / all_gather_into_tensor (RCCL on ROCm; gloo on
-    CPU for the tests); the all-gather of one bucket overlaps the rest of backward."""
+
+    No staging copies: with the gradients' own fp32 on the wire the all-to-all reads the bucket where it lies (the first N * (n // N)
+    elements; the < N left over go through one tiny all-reduce), the owner's pass is ONE kernel (`reduce_shards`) that writes the mean
+    straight into the owner's slice of the bucket, and the all-gather is in place on the bucket.  `state.wire_dtype = torch.bfloat16`
+    halves the bytes on both hops (the sum itself stays fp32) at the price of one conversion pass each way; off by default because the
+    averaged gradient is then rounded to 8 bits.  One rank: the mean over one copy is the copy -- nothing is moved, nothing is launched
+    but the (empty) in-place all-gather.  Collectives are the backend's all_to_all_single / all_gather_into_tensor (RCCL on ROCm; gloo
+    on CPU for the tests); the all-gather of one bucket overlaps the rest of backward."""
     group = state.process_group if state.process_group is not None else dist.group.WORLD
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     buf = bucket.buffer()
     n = buf.numel()
-    shard = (n + world - 1) // world
+    q = (n // world) // 4 * 4                               # shard length: a multiple of 4 elements (16-byte pieces for the owner's kernel)
+    main, tail = buf[:world * q], buf[world * q:]
     wire = state.wire_dtype or buf.dtype
     # (gloo moves host tensors only: a 1-GPU rehearsal of the multi-rank path stages the bucket through the host)
-    comm_dev = torch.device("cpu") if (buf.is_cuda and dist.get_backend(group) == "gloo") else buf.device
-    send = torch.zeros(world * shard, dtype=wire, device=comm_dev)
-    send[:n].copy_(buf)
-    recv = torch.empty_like(send)
+    via_host = buf.is_cuda and dist.get_backend(group) == "gloo"
     state.calls += 1
-    state.bytes_sent += 2 * (world - 1) * shard * send.element_size()
+    state.bytes_sent += 2 * (world - 1) * q * torch.empty(0, dtype=wire).element_size()
+    if tail.numel():                                        # < 4 N elements that do not fill a shard: one tiny all-reduce
+        t = tail.cpu() if via_host else tail
+        dist.all_reduce(t, group=group)
+        tail.copy_(t / world)
+    if q == 0:
+        fut = torch.futures.Future()
+        fut.set_result(buf)
+        return fut
+    if via_host:
+        src = main.cpu().to(wire)
+    elif wire != buf.dtype:
+        src = torch.empty(world * q, dtype=wire, device=buf.device)
+        reduce_shards(main, 1, world * q, src)               # fp32 -> bf16, one pass
+    else:
+        src = main
     # hop 1 is enqueued in call order (RCCL: stream-ordered, the host does not block; the bucket's own backward kernels have finished by
     # the time DDP calls the hook); only hop 2 is returned as the future -- no callback ever waits on another collective, so backends that
     # run callbacks on their worker threads (gloo) cannot deadlock with several buckets in flight
-    dist.all_to_all_single(recv, send, group=group)
-    parts = recv.view(world, shard)
-    mine = parts[0].to(torch.float32)
-    for r in range(1, world):                               # rank order, one add per source: the same sum on every rank and run
-        mine = mine + parts[r].to(torch.float32)
-    mine = (mine / world).to(wire)
-    out = torch.empty(world * shard, dtype=wire, device=comm_dev)
+    if world > 1:
+        recv = torch.empty_like(src)
+        dist.all_to_all_single(recv, src, group=group)
+    else:
+        recv = src                                          # one rank: its own shard is all there is
+    in_place = src is main                                  # fp32 on the wire, device tensors: reduce into and gather on the bucket itself
+    out = main if in_place else torch.empty(world * q, dtype=wire, device=src.device)
+    mine = out[rank * q:(rank + 1) * q]
+    if world > 1 or not in_place:
+        reduce_shards(recv, world, q, mine)
     fut = dist.all_gather_into_tensor(out, mine, group=group, async_op=True).get_future()
 
     def finish(_f):
-        buf.copy_(out[:n])
+        if not in_place:
+            if out.is_cuda:
+                reduce_shards(out, 1, world * q, main)       # bf16 -> fp32, one pass
+            else:
+                main.copy_(out)
         return buf
 
     return fut.then(finish)

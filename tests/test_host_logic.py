@@ -225,12 +225,12 @@ def _multibucket_worker(rank, world, port, out_path):
     torch.set_num_threads(2)
     init_distributed("gloo")
     grads = {}
-    for mode in ("allreduce", "direct"):
+    for mode in ("allreduce", "direct", "direct_bf16"):
         torch.manual_seed(0)
         m = torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(12)])
         d = torch.nn.parallel.DistributedDataParallel(m, bucket_cap_mb=0.02)       # ~10 buckets per backward
-        st = DirectExchangeState()
-        if mode == "direct":
+        st = DirectExchangeState(None, torch.bfloat16 if mode == "direct_bf16" else None)
+        if mode != "allreduce":
             d.register_comm_hook(st, direct_exchange_hook)
         g = torch.Generator().manual_seed(100 + rank)
         for _ in range(3):
@@ -253,6 +253,15 @@ def test_direct_exchange_with_several_buckets_in_flight(tmp_path):
     res = torch.load(out)
     assert res["direct_calls"] >= 10
     assert float((res["direct"] - res["allreduce"]).abs().max()) <= 1e-6 * float(res["allreduce"].abs().max())
+    # the bf16 wire mode (config key grad_exchange: direct_bf16): both hops carry bf16, the owner's sum stays fp32.  Every element that went
+    # through a shard is a bf16 value (the < 4 N elements per bucket left to the tail all-reduce stay fp32), and it is the bf16 rounding of
+    # the mean of bf16-rounded contributions: within 2^-8 of the fp32 mean's magnitude scale
+    b, ref = res["direct_bf16"], res["allreduce"]
+    assert res["direct_bf16_calls"] >= 10
+    is_bf16 = b == b.to(torch.bfloat16).to(torch.float32)
+    assert float(is_bf16.float().mean()) > 0.9
+    assert float((b - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    assert float((b - ref).abs().max()) > 0                                       # it is not the fp32 path under another name
 
 
 # ---------------------------------------------------------------- N>1: SyncBatchNorm == single-process whole-batch BatchNorm
