@@ -306,11 +306,13 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
                        const float *residual, int64_t ldr, const float *periodic_add, int32_t rows_per_group,
                        int32_t period, int32_t activation, int32_t x_format, int32_t y_format, void *stream);
 
-/* LayerNorm fused in front of the layer, for one-tile-per-workgroup problems (a single frame: ceil(rows / 32) * ceil(out_features / 128) at
- * most twice the CU count -- smk_linear_ln_max_rows): y = act(LN(x) W^T + b + periodic_add), LN over the in_features of a row with `eps`.
- * `lin` must have been created from the FOLDED parameters W' = W diag(gamma), b' = b + W beta; wsum [out_features] = row sums of W'.  The
- * kernel reads the raw x, gathers each row's mean / variance while staging it and applies rstd (x W'^T - mean wsum) + b' in its epilogue: the
- * separate LayerNorm launch and its round trip are gone.  fp32 in / out; no residual. */
+/* LayerNorm fused in front of the layer (nn.LayerNorm -> nn.Linear of the pre-LN block, /root/reference/src/models/smokephys_net.py:149-150,
+ * 161,165): y = act(LN(x) W^T + b + periodic_add), LN over the in_features of a row with `eps`.  `lin` must have been created from the
+ * FOLDED parameters W' = W diag(gamma), b' = b + W beta; wsum [out_features] = row sums of W'.  The kernel reads the raw x, gathers each
+ * row's mean / variance while staging it (shifted sums about a per-thread pivot merged pairwise: no cancellation for rows whose mean
+ * dwarfs their spread) and applies rstd (x W'^T - mean wsum) + b' in its epilogue: the separate LayerNorm launch and its round trip are
+ * gone.  Any row count (round 3 served one tile per workgroup only; smk_linear_ln_max_rows now only reflects the 32-bit offset range).
+ * fp32 in / out; no residual. */
 int64_t smk_linear_ln_max_rows(smk_linear *lin);
 int smk_linear_forward_ln(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy, const float *wsum, double eps,
                           const float *periodic_add, int32_t rows_per_group, int32_t period, int32_t activation, void *stream);

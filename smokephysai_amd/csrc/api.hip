@@ -998,8 +998,9 @@ int64_t smk_linear_ln_max_rows(smk_linear *lin) {
     if (!lin) return 0;
     DeviceGuard guard(lin->device);
     if (guard.rc) return 0;
-    const int64_t slots = 2LL * device_num_cu(), tn = (lin->l.N + 127) / 128;
-    return slots / tn * 32;
+    // (round 3: one tile per workgroup, i.e. 2 CUs / column tiles x 32 rows.)  The statistics now follow the chunk stream across the tiles a
+    // workgroup walks, so the only bound is the 32-bit offset range of the activation buffer
+    return ((1LL << 30) / lin->l.K) - 256;
 }
 
 int smk_linear_forward_ln(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy, const float *wsum, double eps,
@@ -1014,7 +1015,6 @@ int smk_linear_forward_ln(smk_linear *lin, const float *x, int64_t rows, int64_t
     SMK_REQUIRE(eps > 0.0, "eps > 0");
     DeviceGuard guard(lin->device);
     if (guard.rc) return guard.rc;
-    SMK_REQUIRE(rows <= smk_linear_ln_max_rows(lin), "fused LayerNorm serves one tile per workgroup: rows <= smk_linear_ln_max_rows");
     LinearCall c;
     c.x = x; c.ldx = ldx; c.y = y; c.ldy = ldy; c.x_split = 0; c.y_split = 0; c.res = nullptr; c.ldr = 0;
     c.padd = periodic_add; c.rows_per_group = periodic_add ? rows_per_group : 1; c.period = periodic_add ? period : 1;

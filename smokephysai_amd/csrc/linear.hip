@@ -205,9 +205,14 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     constexpr int NPC_ALL = TM / RP;                         // pieces per chunk per thread
     float4 stage[AS ? 1 : NPC_ALL];
     u32x4 sth[AS ? NPC_ALL : 1], stl[AS ? NPC_ALL : 1];
-    float ln_s[LNF ? NPC_ALL : 1], ln_q[LNF ? NPC_ALL : 1];   // LNF: this thread's share of sum / sum of squares of rows sr + RP j
+    // LNF: this thread's share (4 of every 64 k: K / 16 elements) of the statistics of rows sr + RP j, as SHIFTED sums about a pivot -- the
+    // first element the thread sees of that row -- so that rows whose mean dwarfs their spread lose nothing to cancellation:
+    // ln_s = sum (x - pivot), ln_q = sum (x - pivot)^2.  The chunk stream runs one chunk ahead of the K loop, so the first chunk of the
+    // NEXT tile is staged while this tile still computes: its sums start in the ln_n* set and become the current set after the epilogue.
+    float ln_p[LNF ? NPC_ALL : 1], ln_s[LNF ? NPC_ALL : 1], ln_q[LNF ? NPC_ALL : 1];
+    float ln_np[LNF ? NPC_ALL : 1], ln_ns[LNF ? NPC_ALL : 1], ln_nq[LNF ? NPC_ALL : 1];
 #pragma unroll
-    for (int j = 0; j < (LNF ? NPC_ALL : 1); ++j) { ln_s[j] = 0.f; ln_q[j] = 0.f; }
+    for (int j = 0; j < (LNF ? NPC_ALL : 1); ++j) { ln_p[j] = ln_s[j] = ln_q[j] = 0.f; ln_np[j] = ln_ns[j] = ln_nq[j] = 0.f; }
     // x through a buffer resource: a row past M (ragged last tile, or the chunk stream running past this workgroup's last
     // tile) is out of range and reads as zero in hardware -- no clamp, no predicate (either would cost VALU issue slots or
     // split the k-step into basic blocks and undo the MFMA / staging interleave below).  One v_add per load: the offset
@@ -228,7 +233,8 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
             stage[AS ? 0 : j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
-    auto stage_store = [&](int buf, int j) {
+    // first_of_next (wave-uniform, LNF only): the piece being stored is chunk 0 of the tile AFTER the one in the K loop
+    auto stage_store = [&](int buf, int j, bool first_of_next = false) {
         if (AS) {
             unsigned char *ph = smem + buf * 2 * PLANE + (sr + RP * j) * LN_PITCH + sc * 16;
             *reinterpret_cast<u32x4 *>(ph) = sth[AS ? j : 0];
@@ -238,8 +244,14 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
         unsigned char *ph = smem + buf * 2 * PLANE + (sr + RP * j) * LN_PITCH + sc * 8;
         const float v[4] = {stage[AS ? 0 : j].x, stage[AS ? 0 : j].y, stage[AS ? 0 : j].z, stage[AS ? 0 : j].w};
         if constexpr (LNF) {
-            ln_s[j] += (v[0] + v[1]) + (v[2] + v[3]);
-            ln_q[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            const float pv = first_of_next ? v[0] : ln_p[j];                 // selects, not branches: the k-step stays one basic block
+            const float d0 = v[0] - pv, d1 = v[1] - pv, d2 = v[2] - pv, d3 = v[3] - pv;
+            const float s1 = (d0 + d1) + (d2 + d3), s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            ln_s[j] += first_of_next ? 0.f : s1;
+            ln_q[j] += first_of_next ? 0.f : s2;
+            ln_np[j] = first_of_next ? pv : ln_np[j];
+            ln_ns[j] = first_of_next ? s1 : ln_ns[j];
+            ln_nq[j] = first_of_next ? s2 : ln_nq[j];
         }
         bf16x4 vh, vl;
 #pragma unroll
@@ -266,8 +278,12 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     advance();
 #pragma unroll
     for (int j = 0; j < TM / RP; ++j) {
-        stage_store(0, j);
+        stage_store(0, j, true);
         stage_load(ld_tm, ld_c, j);
+    }
+    if constexpr (LNF) {                                             // chunk 0 of the FIRST tile: its sums are the current set
+#pragma unroll
+        for (int j = 0; j < NPC_ALL; ++j) { ln_p[j] = ln_np[j]; ln_s[j] = ln_ns[j]; ln_q[j] = ln_nq[j]; }
     }
     advance();
     __syncthreads();
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                 constexpr int pbeg = u == 0 ? 0 : u == 1 ? P0 : u == 2 ? P1 : NP, pend = u == 0 ? P0 : u == 1 ? P1 : NP;
 #pragma unroll
                 for (int j = pbeg; j < pend; ++j) {
-                    stage_store(buf ^ 1, j);
+                    stage_store(buf ^ 1, j, LNF && c == nchunks - 1);
                     stage_load(ld_tm, ld_c, j);
                 }
                 if (u == 2) advance();
@@ -429,18 +445,26 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
             //  which group 0 reaches only after these reads)
         }
         if constexpr (LNF) {   // row statistics: the 16 threads sc = 0 .. 15 of a staging row hold its 64 k of every chunk between them
+            const float cnt = (float)(K >> 4);                            // elements per thread and row
 #pragma unroll
             for (int j = 0; j < NPC_ALL; ++j) {
-                float s1 = ln_s[j], s2 = ln_q[j];
+                // this thread's mean and sum of squared deviations about it, then the pairwise merge of equal-sized sets (Chan et al.):
+                // mean = (ma + mb) / 2, M2 = M2a + M2b + (mb - ma)^2 n / 2
+                float mean = ln_p[j] + ln_s[j] / cnt, m2 = ln_q[j] - ln_s[j] * ln_s[j] / cnt, nn = cnt;
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                for (int o = 1; o < 16; o <<= 1) {
+                    const float mo = __shfl_xor(mean, o), qo = __shfl_xor(m2, o), dlt = mo - mean;
+                    m2 = (m2 + qo) + dlt * dlt * (0.5f * nn);
+                    mean = 0.5f * (mean + mo);
+                    nn = nn + nn;
+                }
                 if (sc == 0) {
-                    const float mean = s1 / (float)K;
-                    float var = s2 / (float)K - mean * mean;
+                    float var = m2 / (float)K;
                     var = var > 0.f ? var : 0.f;
                     stat_s[2 * (sr + RP * j)] = mean;
                     stat_s[2 * (sr + RP * j) + 1] = 1.0f / sqrtf(var + a.c.ln_eps);
                 }
+                ln_p[j] = ln_np[j]; ln_s[j] = ln_ns[j]; ln_q[j] = ln_nq[j];       // the next tile's first chunk is already in
             }
             __syncthreads();
         }
@@ -583,7 +607,6 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
     // one tile ~ (K/64) chunks x ~4.2 K cycles + ~9 K epilogue; s_sleep(127) ~ 8 K cycles
     b.stagger_unit = stg_env > 1 ? (int)(((a.l.K / 64) * 4200 + 9000) / 8128 / stg_env) : 0;
     if (b.stagger_unit < 1) b.stagger = 0;
-    if (LNF && nwg < tiles * nseg) return hipErrorInvalidValue;          // fused LayerNorm: one tile per workgroup
     hipLaunchKernelGGL((k_linear_x3<MB, NW, AS, KS, RING, LNF>), dim3((unsigned)nwg), dim3(NW * 64 * KS), lds, st, b);
     return hipGetLastError();
 }
@@ -995,11 +1018,23 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     a.swz = 0;
     a.stagger = 0;
     a.stamps = nullptr;
-    if (c.ln_wsum) {   // LayerNorm fused in front: 32-row tiles, one per workgroup (launch_mb refuses more tiles than workgroup slots)
+    if (c.ln_wsum) {   // LayerNorm fused in front (k_linear_x3<.., LNF>): the tile shapes of the plain layer
         if (c.x_split || c.y_split || c.nseg != 1 || c.res || (c.padd && c.rows_per_group % 32 != 0)) return hipErrorInvalidValue;
-        a.tiles_n = cdiv(l.N, 128);
-        a.tiles_m = cdiv(c.M, 32);
-        return (l.K / 64) % 4 == 0 ? launch_mb<1, 4, false, 1, 16, true>(a, st) : launch_mb<1, 4, false, 1, LN_RING, true>(a, st);
+        int nwl = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) >= num_cu) ? 8 : 4;
+        if (force_nw == 4 || force_nw == 8) nwl = force_nw;
+        int mbl = 4;
+        while (mbl > 1 && (long long)cdiv(c.M, 32 * mbl) * cdiv(l.N, nwl * 32) < (nwl == 8 ? 1LL : 2LL) * num_cu) mbl >>= 1;
+        if (force_mb == 1 || force_mb == 2 || force_mb == 4) mbl = force_mb;
+        if (nwl == 8 && (mbl != 4 || (c.padd && c.rows_per_group % 128 != 0))) { nwl = 4; }
+        while (c.padd && mbl > 1 && c.rows_per_group % (32 * mbl) != 0) mbl >>= 1;
+        a.tiles_n = cdiv(l.N, nwl * 32);
+        a.tiles_m = cdiv(c.M, 32 * mbl);
+        if (nwl == 8) return launch_mb<4, 8, false, 1, LN_RING, true>(a, st);
+        if (mbl == 4) return launch_mb<4, 4, false, 1, LN_RING, true>(a, st);
+        if (mbl == 2) return launch_mb<2, 4, false, 1, LN_RING, true>(a, st);
+        // one 32-row tile per workgroup (a single frame): the deep weight ring when K allows it
+        const bool one = (long long)a.tiles_m * a.tiles_n <= 2LL * num_cu;
+        return (one && (l.K / 64) % 4 == 0) ? launch_mb<1, 4, false, 1, 16, true>(a, st) : launch_mb<1, 4, false, 1, LN_RING, true>(a, st);
     }
     int nw = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) * c.nseg >= num_cu) ? 8 : 4;
     if (force_nw == 4 || force_nw == 8) nw = force_nw;

@@ -24,7 +24,7 @@ class HipBody:
         self.sources: Dict[str, tuple] = {}                        # name -> the nn.Linear modules the handle mirrors
         self.addend_bufs: Dict[tuple, torch.Tensor] = {}           # (name, batch) -> [B,5,3D] addend of the fused q|k|v layer
         self.split_activations = os.environ.get("SMK_BODY_SPLIT", "0") == "1"
-        self.fuse_layernorm = os.environ.get("SMK_BODY_FUSE_LN", "1") == "1"     # single-frame batches only (HipLinearLN.max_rows)
+        self.fuse_layernorm = os.environ.get("SMK_BODY_FUSE_LN", "1") == "1"     # each LayerNorm inside the layer behind it (HipLinearLN)
 
     # ---- weight mirrors ----------------------------------------------------------------------------------------
     def linear(self, name: str, lin: nn.Linear) -> HipLinear:
@@ -49,12 +49,6 @@ class HipBody:
             hit = self.linears[name] = (HipLinear(torch.cat([m.weight for m in mods]), torch.cat([m.bias for m in mods])), fp)
             self.sources[name] = mods
         return hit[0]
-
-    @staticmethod
-    def _ln_rows_ok(rows: int, out_features: int, device) -> bool:
-        """smk_linear_ln_max_rows without a handle: one 32 x 128 tile per workgroup, two workgroup slots per CU."""
-        cus = torch.cuda.get_device_properties(device).multi_processor_count
-        return rows <= (2 * cus // ((out_features + 127) // 128)) * 32
 
     def linear_ln(self, name: str, lins, ln: nn.LayerNorm) -> HipLinearLN:
         """LayerNorm `ln` folded into the layer(s) `lins` (one nn.Linear, or several stacked along the outputs like q | k | v): the fused
@@ -134,14 +128,14 @@ class HipBody:
         # per element like fp32) written by the producers' epilogues, so no linear layer splits its input inside its K loop.
         # Measured neutral on MI355X (the K loop is not bound by the split arithmetic: DESIGN.md 3.3), so it is off by default.
         sp = self.split_activations and D % 8 == 0 and layer.ffn[0].out_features % 8 == 0
-        # a single frame (one 32-row tile per workgroup): each LayerNorm runs inside the layer that follows it (HipLinearLN) -- 12 launches
-        # and their round trips less per forward
+        # each LayerNorm runs inside the layer that follows it (HipLinearLN: statistics gathered while the kernel stages the raw rows) -- 12
+        # launches and their round trips less per forward, at every batch size.  The gate is the HANDLE's own limit (max_rows)
         fuse_ln = (self.fuse_layernorm and not sp and all(ln.elementwise_affine and ln.bias is not None for ln in (layer.norm1, layer.norm2)))
         add15 = self._addend_buffer(name, B, D, x.device)
         if not addend_ready:
             att.chaos_addend_hip(B, x.device, noise, out=add15)
-        if fuse_ln and self._ln_rows_ok(B * L, 3 * D, x.device):
-            qkv_ln = self.linear_ln(name + "chaos_attention.qkv", (att.q_proj, att.k_proj, att.v_proj), layer.norm1)
+        qkv_ln = self.linear_ln(name + "chaos_attention.qkv", (att.q_proj, att.k_proj, att.v_proj), layer.norm1) if fuse_ln else None
+        if qkv_ln is not None and B * L <= qkv_ln.max_rows:
             qkv = qkv_ln.forward_ln(x, periodic_add=add15, rows_per_group=L)
         else:
             h = self.layernorm(x, layer.norm1, out_split=sp)
@@ -156,8 +150,9 @@ class HipBody:
             o = o.transpose(1, 2).reshape(B, L, D)
             o = to_split(o) if sp else o
         self.linear(name + "chaos_attention.out_proj", att.out_proj)(o, residual=x, out=x, x_split=sp)     # x += attn
-        if fuse_ln and self._ln_rows_ok(B * L, layer.ffn[0].out_features, x.device):
-            f = self.linear_ln(name + "ffn.0", (layer.ffn[0],), layer.norm2).forward_ln(x, activation="gelu")
+        ffn_ln = self.linear_ln(name + "ffn.0", (layer.ffn[0],), layer.norm2) if fuse_ln else None
+        if ffn_ln is not None and B * L <= ffn_ln.max_rows:
+            f = ffn_ln.forward_ln(x, activation="gelu")
         else:
             h = self.layernorm(x, layer.norm2, out_split=sp)
             f = self.linear(name + "ffn.0", layer.ffn[0])(h, activation="gelu", x_split=sp, out_split=sp)

@@ -146,9 +146,9 @@ class HipLinear:
 
 
 class HipLinearLN(HipLinear):
-    """LayerNorm + Linear as ONE launch for single-frame problems (smk_linear_forward_ln): the handle holds the folded parameters
-    W' = W diag(gamma), b' = b + W beta; the kernel normalises inside (row statistics gathered while it stages the raw rows, the mean /
-    rstd correction in its epilogue).  `max_rows`: the largest row count the fused form serves (one tile per workgroup)."""
+    """LayerNorm + Linear as ONE launch (smk_linear_forward_ln): the handle holds the folded parameters W' = W diag(gamma),
+    b' = b + W beta; the kernel normalises inside (row statistics gathered while it stages the raw rows, the mean / rstd correction in
+    its epilogue).  `max_rows`: the largest row count the handle serves (the library's own answer, smk_linear_ln_max_rows)."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], ln_weight: torch.Tensor, ln_bias: torch.Tensor, eps: float,
                  device=None):

@@ -8,13 +8,17 @@ pytestmark = pytest.mark.gpu
 
 
 def _torch_form(shards, world, q, out_dtype):
+    """The host form (what utils.distributed.reduce_shards runs on gloo's CPU tensors): on the CPU torch's `/ world` is a true divide,
+    as in the kernel (PyTorch-ROCm's device kernel multiplies by the reciprocal instead: one ulp apart for world = 3)."""
+    dev = shards.device
+    shards = shards.cpu()
     parts = shards.view(world, q)
     acc = parts[0].to(torch.float32)
     for r in range(1, world):
         acc = acc + parts[r].to(torch.float32)
     if world > 1:
         acc = acc / world
-    return acc.to(out_dtype)
+    return acc.to(out_dtype).to(dev)
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])

@@ -193,7 +193,11 @@ def test_weight_gradient_row_chunking(monkeypatch):
 
 
 @pytest.mark.parametrize("rows,K,N,act,padd", [(1024, 512, 1536, None, True), (1024, 512, 2048, "gelu", False), (96, 128, 64, "relu", False),
-                                                (1000, 512, 512, None, False)])
+                                                (1000, 512, 512, None, False),
+                                                # several tiles per workgroup (the statistics follow the chunk stream across tiles): batch 4 and
+                                                # batch 64 of the body's two fused layers, a one-chunk K, a ragged row count on the 128-row tiles
+                                                (4096, 512, 1536, None, True), (4096, 512, 2048, "gelu", False), (65536, 512, 1536, None, True),
+                                                (65536, 512, 2048, "gelu", False), (40000, 64, 256, None, False), (33001, 512, 512, "relu", False)])
 def test_layernorm_fused_into_the_linear_layer(rows, K, N, act, padd):
     """smk_linear_forward_ln (HipLinearLN): act(LayerNorm(x) W^T + b + periodic_add) against the same chain in fp64 -- rows whose mean is
     far from zero (the epilogue's mean * wsum correction carries weight), a ragged last tile, the periodic addend of the q | k | v layer."""
@@ -206,18 +210,39 @@ def test_layernorm_fused_into_the_linear_layer(rows, K, N, act, padd):
     beta = torch.randn(K, device="cuda", generator=g) * 0.3
     lin = HipLinearLN(w, b, gamma, beta, 1e-5)
     assert lin.max_rows >= rows
-    pa = torch.randn(rows // 32 if rows % 32 == 0 else 1, 5, N, device="cuda", generator=g) if padd else None
-    rpg = 32 if padd else 0
+    rpg = (1024 if rows % 1024 == 0 and rows > 1024 else 32) if padd else 0      # (1,024: the body's tokens per frame -> 128-row tiles)
+    pa = torch.randn(rows // rpg, 5, N, device="cuda", generator=g) if padd else None
     y = lin.forward_ln(x, activation=act, periodic_add=pa, rows_per_group=rpg)
     h = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5)
     ref = h @ w.double().t() + b.double()
     if padd:
         idx = torch.arange(rows, device="cuda")
-        ref = ref + pa.double()[idx // 32, (idx % 32) % 5]
+        ref = ref + pa.double()[idx // rpg, (idx % rpg) % 5]
     if act == "gelu":
         ref = torch.nn.functional.gelu(ref)
     elif act == "relu":
         ref = torch.relu(ref)
     assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+    lin.max_rows = 64                                                   # (the library's own limit is the 32-bit offset range: not allocatable here)
     with pytest.raises(ValueError):
-        lin.forward_ln(torch.zeros(lin.max_rows + 32, K, device="cuda"))
+        lin.forward_ln(torch.zeros(96, K, device="cuda"))
+
+
+@pytest.mark.parametrize("rows", [1024, 4096])
+def test_fused_layernorm_rows_whose_mean_dwarfs_their_spread(rows):
+    """Rows like 50 + 0.1 randn (|mean| = 500 sigma): a one-pass E[x^2] - mean^2 loses its digits there.  The kernel gathers shifted sums
+    about a per-thread pivot and merges them pairwise, and its epilogue's rstd (x W'^T - mean wsum) subtracts two large terms -- the result
+    must still sit within 1e-4 of LayerNorm + Linear in fp64."""
+    from smokephysai_amd.models.linear import HipLinearLN
+    K, N = 512, 512
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = 50.0 + 0.1 * torch.randn(rows, K, device="cuda", generator=g)
+    x[::7] = -300.0 + 0.01 * torch.randn(x[::7].shape, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    gamma = torch.rand(K, device="cuda", generator=g) + 0.5
+    beta = torch.randn(K, device="cuda", generator=g) * 0.3
+    y = HipLinearLN(w, b, gamma, beta, 1e-5).forward_ln(x)
+    ref = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
+    # the statistics themselves: recover rstd from the output scale -- and the end result
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-4

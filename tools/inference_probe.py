@@ -9,7 +9,7 @@ torch.manual_seed(0)
 model = SmokePhysNet().to(dev).eval()
 g = GraphedSmokePhysNet(model)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for bs in (1, 4, 64):
+for bs in tuple(int(b) for b in os.environ.get('SMK_PROBE_BATCHES', '1,4,64').split(',')):
     x = torch.rand(bs, 1, N, N, device=dev)
     noise = torch.randn(len(model.chaos_layers), 3, bs, 1, device=dev)
     with torch.no_grad():
