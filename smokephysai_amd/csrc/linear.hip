@@ -205,14 +205,16 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     constexpr int NPC_ALL = TM / RP;                         // pieces per chunk per thread
     float4 stage[AS ? 1 : NPC_ALL];
     u32x4 sth[AS ? NPC_ALL : 1], stl[AS ? NPC_ALL : 1];
-    // LNF: this thread's share (4 of every 64 k: K / 16 elements) of the statistics of rows sr + RP j, as SHIFTED sums about a pivot -- the
-    // first element the thread sees of that row -- so that rows whose mean dwarfs their spread lose nothing to cancellation:
-    // ln_s = sum (x - pivot), ln_q = sum (x - pivot)^2.  The chunk stream runs one chunk ahead of the K loop, so the first chunk of the
-    // NEXT tile is staged while this tile still computes: its sums start in the ln_n* set and become the current set after the epilogue.
-    float ln_p[LNF ? NPC_ALL : 1], ln_s[LNF ? NPC_ALL : 1], ln_q[LNF ? NPC_ALL : 1];
-    float ln_np[LNF ? NPC_ALL : 1], ln_ns[LNF ? NPC_ALL : 1], ln_nq[LNF ? NPC_ALL : 1];
+    // LNF: every staged row piece is taken relative to a PIVOT -- the row's own first element x[row][0], loaded beside the piece -- before
+    // it is split into bf16: the GEMM then sees operands of the size of the row's SPREAD, not of its mean, and
+    //   LN(x) W'^T = rstd ((x - p) W'^T - (mean - p) wsum),   mean - p = S1 / K,   var = S2 / K - (S1 / K)^2
+    // with S1 = sum (x - p), S2 = sum (x - p)^2 loses nothing to cancellation for rows whose mean dwarfs their spread (neither in the
+    // variance nor in the epilogue's subtraction).  ln_s / ln_q: this thread's share (4 of every 64 k) of S1 / S2 of rows sr + RP j.
+    // The chunk stream runs one chunk ahead of the K loop, so the first chunk of the NEXT tile is staged while this tile still
+    // computes: its sums start in the ln_n* set and become the current set after the epilogue.
+    float ln_piv[LNF ? NPC_ALL : 1], ln_s[LNF ? NPC_ALL : 1], ln_q[LNF ? NPC_ALL : 1], ln_ns[LNF ? NPC_ALL : 1], ln_nq[LNF ? NPC_ALL : 1];
 #pragma unroll
-    for (int j = 0; j < (LNF ? NPC_ALL : 1); ++j) { ln_p[j] = ln_s[j] = ln_q[j] = 0.f; ln_np[j] = ln_ns[j] = ln_nq[j] = 0.f; }
+    for (int j = 0; j < (LNF ? NPC_ALL : 1); ++j) { ln_piv[j] = ln_s[j] = ln_q[j] = ln_ns[j] = ln_nq[j] = 0.f; }
     // x through a buffer resource: a row past M (ragged last tile, or the chunk stream running past this workgroup's last
     // tile) is out of range and reads as zero in hardware -- no clamp, no predicate (either would cost VALU issue slots or
     // split the k-step into basic blocks and undo the MFMA / staging interleave below).  One v_add per load: the offset
@@ -231,6 +233,8 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
             // (not __builtin_bit_cast(float, v[i]): hipcc 7.2 then emits a 1-dword load and leaves v[1..3] undefined)
             stage[AS ? 0 : j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            if constexpr (LNF)       // the row's pivot x[row][0] (the 16 threads of a staging row read one address; a row past M reads 0)
+                ln_piv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(row_u * (unsigned)ldxb + (unsigned)(sr * ldxb)), 0, 0));
         }
     };
     // first_of_next (wave-uniform, LNF only): the piece being stored is chunk 0 of the tile AFTER the one in the K loop
@@ -242,14 +246,14 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
             return;
         }
         unsigned char *ph = smem + buf * 2 * PLANE + (sr + RP * j) * LN_PITCH + sc * 8;
-        const float v[4] = {stage[AS ? 0 : j].x, stage[AS ? 0 : j].y, stage[AS ? 0 : j].z, stage[AS ? 0 : j].w};
+        float v[4] = {stage[AS ? 0 : j].x, stage[AS ? 0 : j].y, stage[AS ? 0 : j].z, stage[AS ? 0 : j].w};
         if constexpr (LNF) {
-            const float pv = first_of_next ? v[0] : ln_p[j];                 // selects, not branches: the k-step stays one basic block
-            const float d0 = v[0] - pv, d1 = v[1] - pv, d2 = v[2] - pv, d3 = v[3] - pv;
-            const float s1 = (d0 + d1) + (d2 + d3), s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            ln_s[j] += first_of_next ? 0.f : s1;
+            const float pv = ln_piv[j];                                      // loaded with this very piece
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] - pv;
+            const float s1 = (v[0] + v[1]) + (v[2] + v[3]), s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            ln_s[j] += first_of_next ? 0.f : s1;                             // selects, not branches: the k-step stays one basic block
             ln_q[j] += first_of_next ? 0.f : s2;
-            ln_np[j] = first_of_next ? pv : ln_np[j];
             ln_ns[j] = first_of_next ? s1 : ln_ns[j];
             ln_nq[j] = first_of_next ? s2 : ln_nq[j];
         }
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
     }
     if constexpr (LNF) {                                             // chunk 0 of the FIRST tile: its sums are the current set
 #pragma unroll
-        for (int j = 0; j < NPC_ALL; ++j) { ln_p[j] = ln_np[j]; ln_s[j] = ln_ns[j]; ln_q[j] = ln_nq[j]; }
+        for (int j = 0; j < NPC_ALL; ++j) { ln_s[j] = ln_ns[j]; ln_q[j] = ln_nq[j]; }
     }
     advance();
     __syncthreads();
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                     // per SIMD an MFMA gap hides about five other vector-issue slots (MI355X_MICROARCH.md, constants table), shared
                     // by the two resident waves: the split arithmetic is spread at ~12 VALU per piece over the k-step's gaps
                     constexpr int NMF = 3 * MB, NDS = 2 * MB, NPC = pend - pbeg;
-                    constexpr int VPER = NPC ? ((AS ? 3 : 14) * NPC + NMF - 1) / NMF : 0;
+                    constexpr int VPER = NPC ? ((AS ? 3 : (LNF ? 26 : 14)) * NPC + NMF - 1) / NMF : 0;
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                         if (VPER) __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);             // split arithmetic
                         if (i >= NMF - NPC) {
                             __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                      // a finished piece: 2 DS writes
-                            __builtin_amdgcn_sched_group_barrier(0x020, AS ? 2 : 1, 0);             //   + its re-issued load(s)
+                            __builtin_amdgcn_sched_group_barrier(0x020, (AS || LNF) ? 2 : 1, 0);    //   + its re-issued load(s) (LNF: + the pivot)
                         }
 #if !SMK_LN_RINGFIRST
                         if (i >= NMF - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // ring refill
@@ -445,26 +449,19 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
             //  which group 0 reaches only after these reads)
         }
         if constexpr (LNF) {   // row statistics: the 16 threads sc = 0 .. 15 of a staging row hold its 64 k of every chunk between them
-            const float cnt = (float)(K >> 4);                            // elements per thread and row
 #pragma unroll
             for (int j = 0; j < NPC_ALL; ++j) {
-                // this thread's mean and sum of squared deviations about it, then the pairwise merge of equal-sized sets (Chan et al.):
-                // mean = (ma + mb) / 2, M2 = M2a + M2b + (mb - ma)^2 n / 2
-                float mean = ln_p[j] + ln_s[j] / cnt, m2 = ln_q[j] - ln_s[j] * ln_s[j] / cnt, nn = cnt;
+                float s1 = ln_s[j], s2 = ln_q[j];
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const float mo = __shfl_xor(mean, o), qo = __shfl_xor(m2, o), dlt = mo - mean;
-                    m2 = (m2 + qo) + dlt * dlt * (0.5f * nn);
-                    mean = 0.5f * (mean + mo);
-                    nn = nn + nn;
-                }
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
                 if (sc == 0) {
-                    float var = m2 / (float)K;
+                    const float dm = s1 / (float)K;                       // mean - pivot
+                    float var = s2 / (float)K - dm * dm;
                     var = var > 0.f ? var : 0.f;
-                    stat_s[2 * (sr + RP * j)] = mean;
+                    stat_s[2 * (sr + RP * j)] = dm;
                     stat_s[2 * (sr + RP * j) + 1] = 1.0f / sqrtf(var + a.c.ln_eps);
                 }
-                ln_p[j] = ln_np[j]; ln_s[j] = ln_ns[j]; ln_q[j] = ln_nq[j];       // the next tile's first chunk is already in
+                ln_s[j] = ln_ns[j]; ln_q[j] = ln_nq[j];                   // the next tile's first chunk is already in
             }
             __syncthreads();
         }
@@ -526,9 +523,9 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                     *reinterpret_cast<float4 *>(y_seg + (long long)row * a.c.ldy + ncol + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             };
-            // fused LayerNorm: v = rstd (x W'^T - mean wsum) + b' for row mi*32 + r, columns 8q + 4hi .. + 3 of the wave's 32
+            // fused LayerNorm: v = rstd ((x - p) W'^T - (mean - p) wsum) + b' for row mi*32 + r, columns 8q + 4hi .. + 3 of the wave's 32
             auto ln_finish = [&](float (&v)[4], int mi, int q, const float4 &bq) {
-                const float mean = stat_s[2 * (mi * 32 + r)], rstd = stat_s[2 * (mi * 32 + r) + 1];
+                const float mean = stat_s[2 * (mi * 32 + r)], rstd = stat_s[2 * (mi * 32 + r) + 1];      // ("mean" = mean - pivot)
                 const float4 wq4 = *reinterpret_cast<const float4 *>(wsum_s + wave * 32 + 4 * hi + 8 * q);
                 v[0] = rstd * (acc[mi][4 * q] - mean * wq4.x) + bq.x;
                 v[1] = rstd * (acc[mi][4 * q + 1] - mean * wq4.y) + bq.y;
@@ -639,8 +636,11 @@ static hipError_t launch_mb(const LinearArgs &a, hipStream_t st) {
 //   R: depth of the weight ring in 32-k steps.  R = 2 requests step s+1 at the start of step s (768 matrix-pipe cycles ahead for the two
 //   waves of a SIMD: about an L2 round trip under load); R = 4 requests step s+3 (the chunk loop is unrolled twice so that the slots stay
 //   compile-time indices; needs an even number of 64-k chunks).
-template <int NW, int CONV = 0, int R = 2>
+// LNF: LayerNorm fused in front, as in k_linear_x3 (pivot-shifted rows, statistics gathered while the rows are staged and carried across the
+// tiles of the chunk stream, rstd ((x - p) W'^T - (mean - p) wsum) + b' in the epilogue); plain layers only (CONV = 0).
+template <int NW, int CONV = 0, int R = 2, bool LNF = false>
 __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
+    static_assert(!LNF || CONV == 0, "fused LayerNorm: plain layers");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int TM = 128, TN = NW * 32, RP = NW * 4, NP = TM / RP, PLANE = TM * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -674,6 +674,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     // ---- token staging (as k_linear_x3, fp32 source): thread = float4 column sc of rows sr, sr + RP, ...
     const int sc = tid & 15, sr = tid >> 4;
     float4 stage[NP];
+    // (see k_linear_x3; here the current tile's sums are closed at the START of its last chunk -- every piece of the tile has been stored by
+    // then -- and the same registers then gather the next tile's first chunk: three registers per staged row instead of five)
+    float ln_piv[LNF ? NP : 1], ln_s[LNF ? NP : 1], ln_q[LNF ? NP : 1];
+#pragma unroll
+    for (int j = 0; j < (LNF ? NP : 1); ++j) { ln_piv[j] = ln_s[j] = ln_q[j] = 0.f; }
     const unsigned xbytes = CONV == 1 ? (unsigned)((long long)a.cDl * a.cH * a.cW * 256)
                           : CONV == 2 ? (unsigned)((long long)a.cDl * a.cH * a.cW * 4)
                                       : (unsigned)(((long long)(M - 1) * a.c.ldx + K) * 4);
@@ -725,13 +730,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
             const unsigned off = ((unsigned)tmx * TM + RP * j) * (unsigned)ldxb + (unsigned)cx * 256u;    // rows past M read as zero in hardware
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(off + (unsigned)lane_x), 0, 0);
             stage[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            if constexpr (LNF)       // the row's pivot x[row][0], beside the piece (one address per staging row)
+                ln_piv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(((unsigned)tmx * TM + RP * j + (unsigned)sr) * (unsigned)ldxb), 0, 0));
         }
     };
     // row sr + RP j: RP is a multiple of 8, so (row & 7) = sr & 7 for every piece
     const int st_off = sr * 128 + ((((sc >> 1) ^ (sr & 7))) << 4) + (sc & 1) * 8;
     auto stage_store = [&](int buf, int j) {
         unsigned char *ph = smem + buf * 2 * PLANE + st_off + RP * j * 128;
-        const float v[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
+        float v[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
+        if constexpr (LNF) {
+            const float pv = ln_piv[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] - pv;
+            ln_s[j] += (v[0] + v[1]) + (v[2] + v[3]);
+            ln_q[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
         bf16x4 vh, vl;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -762,6 +776,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     advance();
     float *bias_s = reinterpret_cast<float *>(smem + 4 * PLANE);
     if (tid < TN) bias_s[tid] = (a.l.bias && tn * TN + tid < N) ? a.l.bias[tn * TN + tid] : 0.f;
+    float *wsum_s = bias_s + 256, *stat_s = wsum_s + 256;    // LNF: column sums of W', then (mean - pivot, rstd) per tile row
+    if (LNF && tid < TN) wsum_s[tid] = tn * TN + tid < N ? a.c.ln_wsum[tn * TN + tid] : 0.f;
     __syncthreads();
 
     // token fragments of unit u (32-k step u >> 1, token blocks 4 (u & 1) .. + 3): lane = (token l16 of the block, k-group g)
@@ -783,6 +799,29 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
     LN_STAMP(t_begin);
     LN_RSTAMP(r_begin);
 #endif
+    // LNF: at the start of a tile's LAST chunk every piece of the tile has gone through stage_store: close its statistics (the 16 threads
+    // sc = 0 .. 15 of a staging row hold its 64 k of every chunk between them) and hand the registers to the next tile, whose first
+    // chunk is staged during this last chunk.  stat_s is read by this tile's epilogue; the previous tile's epilogue lies behind at
+    // least one chunk barrier.
+    auto ln_close = [&](int cc) {
+        if constexpr (LNF) {
+            if (cc != nchunks - 1) return;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                float s1 = ln_s[j], s2 = ln_q[j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                if (sc == 0) {
+                    const float dm = s1 / (float)K;                       // mean - pivot
+                    float var = s2 / (float)K - dm * dm;
+                    var = var > 0.f ? var : 0.f;
+                    stat_s[2 * (sr + RP * j)] = dm;
+                    stat_s[2 * (sr + RP * j) + 1] = 1.0f / sqrtf(var + a.c.ln_eps);
+                }
+                ln_s[j] = 0.f; ln_q[j] = 0.f;
+            }
+        }
+    };
     for (; tm < a.tiles_m; tm += tm_step) {
 #ifdef SMK_LN_STAMPS
         LN_STAMP(t_k0);
@@ -840,7 +879,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                 {
                     // one fragment read per third MFMA, the weight loads right behind the first MFMAs (k_encoder_b16's placement), the
                     // split arithmetic spread over the gaps (an MFMA of this shape leaves 8 of its 16 cycles to other vector issue)
-                    constexpr int NMF = 24, NPC = pend - pbeg, VPER = NPC ? (14 * NPC + NMF - 1) / NMF : 0;
+                    constexpr int NMF = 24, NPC = pend - pbeg, VPER = NPC ? ((LNF ? 26 : 14) * NPC + NMF - 1) / NMF : 0;
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
@@ -849,18 +888,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                         if (VPER) __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);             // split arithmetic
                         if (i >= NMF - NPC) {
                             __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                      // a finished piece: 2 DS writes
-                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      //   + its re-issued load
+                            __builtin_amdgcn_sched_group_barrier(0x020, LNF ? 2 : 1, 0);            //   + its re-issued load (LNF: + the pivot)
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
+            if constexpr (LNF) ln_close(c);
             unit(std::integral_constant<int, 0>{}, c);
             unit(std::integral_constant<int, 1>{}, c);
             unit(std::integral_constant<int, 2>{}, c);
             unit(std::integral_constant<int, 3>{}, c);
             buf ^= 1;
             if constexpr (R == 4) {
+                if constexpr (LNF) ln_close(c + 1);
                 unit(std::integral_constant<int, 4>{}, c + 1);
                 unit(std::integral_constant<int, 5>{}, c + 1);
                 unit(std::integral_constant<int, 6>{}, c + 1);
@@ -916,6 +957,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                 for (int nb = 0; nb < 2; ++nb) {
                     const float4 bb = nb ? b1 : b0;
                     float v[4] = {acc[nb][t][0] + bb.x, acc[nb][t][1] + bb.y, acc[nb][t][2] + bb.z, acc[nb][t][3] + bb.w};
+                    if constexpr (LNF) {   // rstd ((x - p) W'^T - (mean - p) wsum) + b' for row t*16 + l16, columns nb*16 + 4g .. + 3 of the wave's 32
+                        const float dm = stat_s[2 * (t * 16 + l16)], rstd = stat_s[2 * (t * 16 + l16) + 1];
+                        const float4 wq4 = *reinterpret_cast<const float4 *>(wsum_s + wave * 32 + 4 * g + 16 * nb);
+                        v[0] = rstd * (acc[nb][t][0] - dm * wq4.x) + bb.x;
+                        v[1] = rstd * (acc[nb][t][1] - dm * wq4.y) + bb.y;
+                        v[2] = rstd * (acc[nb][t][2] - dm * wq4.z) + bb.z;
+                        v[3] = rstd * (acc[nb][t][3] - dm * wq4.w) + bb.w;
+                    }
                     if (any_ex) {
                         const float4 eq = ex[t & 1][nb];
                         if (a.c.padd) { v[0] += eq.x; v[1] += eq.y; v[2] += eq.z; v[3] += eq.w; }
@@ -943,11 +992,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
 #endif
 }
 
-template <int NW, int CONV = 0, int R = 2>
+template <int NW, int CONV = 0, int R = 2, bool LNF = false>
 static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
-    constexpr int lds = 4 * 128 * 128 + 1024;
-    once_per_device((const void *)k_linear_b16<NW, CONV, R>, [&] {
-        (void)hipFuncSetAttribute((const void *)k_linear_b16<NW, CONV, R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    constexpr int lds = 4 * 128 * 128 + 1024 + (LNF ? 2048 : 0);          // + bias tile (+ LNF: wsum tile, row statistics)
+    once_per_device((const void *)k_linear_b16<NW, CONV, R, LNF>, [&] {
+        (void)hipFuncSetAttribute((const void *)k_linear_b16<NW, CONV, R, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     const int nwg_max = (NW == 8 ? 1 : 2) * a.num_cu;        // 8 waves per CU either way
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
@@ -958,7 +1007,7 @@ static hipError_t launch_b16(const LinearArgs &a, hipStream_t st) {
     static int swz_env = -1;
     if (swz_env < 0) { const char *s = getenv("SMK_LINEAR_SWZ"); swz_env = s ? atoi(s) : 1; }
     b.swz = swz_env && nwg % (8 * a.tiles_n) == 0;
-    hipLaunchKernelGGL((k_linear_b16<NW, CONV, R>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
+    hipLaunchKernelGGL((k_linear_b16<NW, CONV, R, LNF>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, b);
     return hipGetLastError();
 }
 
@@ -1029,6 +1078,11 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
         while (c.padd && mbl > 1 && c.rows_per_group % (32 * mbl) != 0) mbl >>= 1;
         a.tiles_n = cdiv(l.N, nwl * 32);
         a.tiles_m = cdiv(c.M, 32 * mbl);
+        // full 128-row tiles: the 16x16x32-shape kernel, as for the plain layer (SMK_LINEAR_SHAPE=32 keeps the 32x32x16 one)
+        static int shape_ln = -1;
+        if (shape_ln < 0) { const char *sv = getenv("SMK_LINEAR_SHAPE"); shape_ln = sv ? atoi(sv) : 16; }
+        if (shape_ln != 32 && mbl == 4 && (!c.padd || c.rows_per_group % 128 == 0) && (l.K / 64) % 2 == 0 && l.K >= 128)
+            return nwl == 8 ? launch_b16<8, 0, 2, true>(a, st) : launch_b16<4, 0, 2, true>(a, st);
         if (nwl == 8) return launch_mb<4, 8, false, 1, LN_RING, true>(a, st);
         if (mbl == 4) return launch_mb<4, 4, false, 1, LN_RING, true>(a, st);
         if (mbl == 2) return launch_mb<2, 4, false, 1, LN_RING, true>(a, st);
@@ -1040,7 +1094,11 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     if (force_nw == 4 || force_nw == 8) nw = force_nw;
     a.tiles_n = cdiv(l.N, nw * 32);
     // row-block count per tile: the largest that still gives every CU its share of workgroups (small M: finer tiles)
-    const long long want = (nw == 8 ? 1LL : 2LL) * num_cu;
+    static int want_env = -1;
+    // workgroups per CU the tile choice aims at: 1 (measured round 4: batch 4 0.284 -> 0.276 ms per frame, batch 2 0.382 -> 0.375, larger
+    // batches unchanged -- 64-row tiles at one workgroup per CU beat 32-row tiles at two); SMK_LINEAR_WANT=2 restores round 3's rule
+    if (want_env < 0) { const char *sv = getenv("SMK_LINEAR_WANT"); want_env = sv ? atoi(sv) : 1; }
+    const long long want = (nw == 8 ? 1LL : (long long)want_env) * num_cu;
     int mb = 4;
     while (mb > 1 && (long long)cdiv(c.M, 32 * mb) * a.tiles_n * c.nseg < want) mb >>= 1;
     if (force_mb == 1 || force_mb == 2 || force_mb == 4) mb = force_mb;
@@ -1070,8 +1128,15 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
         else if (mb == 2) e = launch_mb<2, 4, true>(a, st);
         else e = launch_mb<1, 4, true>(a, st);
     } else {
+        static int ks2_env = -1;
+        if (ks2_env < 0) { const char *sv = getenv("SMK_LINEAR_KS2"); ks2_env = sv ? atoi(sv) : 1; }
         if (nw == 8) e = launch_mb<4, 8, false>(a, st);
         else if (mb == 4) e = launch_mb<4, 4, false>(a, st);
+        // 64-row tiles that leave every CU's second workgroup slot empty (batch 4: 256 tiles): two wave groups per workgroup split the K
+        // range instead (8 waves per CU either way; the serial K loop, which is what such a launch waits for, is half as long)
+        // (measured at M = 4,096: 2048 -> 512 33.3 -> 30.8 us; 512 -> 512 12.6 -> 13.5 us, where the merge outweighs four chunks less: K >= 2,048 only)
+        else if (mb == 2 && ks2_env && (long long)a.tiles_m * a.tiles_n * c.nseg <= num_cu && (l.K / 64) % 2 == 0 && l.K >= 2048)
+            e = launch_mb<2, 4, false, 2>(a, st);
         else if (mb == 2) e = launch_mb<2, 4, false>(a, st);
         else {
             // few 32 x 128 tiles (batch 1: 128 for the 2048 -> 512 layer): split K over 2 or 4 wave groups per workgroup

@@ -5,7 +5,7 @@ from torch.profiler import profile, ProfilerActivity
 from smokephysai_amd.models import SmokePhysNet
 torch.manual_seed(0)
 m = SmokePhysNet().cuda().eval()
-x = torch.rand(1, 1, 256, 256, device="cuda")
+x = torch.rand(int(os.environ.get("SMK_PROBE_BATCH", "1")), 1, 256, 256, device="cuda")
 with torch.no_grad():
     for _ in range(3): m(x)
     torch.cuda.synchronize()
