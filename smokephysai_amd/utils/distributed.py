@@ -88,9 +88,11 @@ def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) ->
     elements; the < N left over go through one tiny all-reduce), the owner's pass is ONE kernel (`reduce_shards`) that writes the mean
     straight into the owner's slice of the bucket, and the all-gather is in place on the bucket.  `state.wire_dtype = torch.bfloat16`
     halves the bytes on both hops (the sum itself stays fp32) at the price of one conversion pass each way; off by default because the
-    averaged gradient is then rounded to 8 bits.  One rank: the mean over one copy is the copy -- nothing is moved, nothing is launched
-    but the (empty) in-place all-gather.  Collectives are the backend's all_to_all_single / all_gather_into_tensor (RCCL on ROCm; gloo
-    on CPU for the tests); the all-gather of one bucket overlaps the rest of backward."""
+    averaged gradient is then rounded to 8 bits.  One rank: the mean over one copy is the copy -- with fp32 on the wire nothing is moved
+    and nothing is launched (RCCL's own one-rank all-reduce is a no-op too, 0.014 ms; its one-rank all-gather is NOT: it copies the 111 MB
+    onto themselves in 0.34 ms, so it is not called); the bf16 wire mode still rounds through bf16, which is its observable effect.
+    Collectives are the backend's all_to_all_single / all_gather_into_tensor (RCCL on ROCm; gloo on CPU for the tests); the all-gather of
+    one bucket overlaps the rest of backward."""
     group = state.process_group if state.process_group is not None else dist.group.WORLD
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -107,8 +109,8 @@ def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) ->
         t = tail.cpu() if via_host else tail
         dist.all_reduce(t, group=group)
         tail.copy_(t / world)
-    if q == 0:
-        fut = torch.futures.Future()
+    if q == 0 or (world == 1 and wire == buf.dtype and not via_host):
+        fut = torch.futures.Future()                        # nothing to exchange: the bucket is its own mean
         fut.set_result(buf)
         return fut
     if via_host:
@@ -131,7 +133,11 @@ def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) ->
     mine = out[rank * q:(rank + 1) * q]
     if world > 1 or not in_place:
         reduce_shards(recv, world, q, mine)
-    fut = dist.all_gather_into_tensor(out, mine, group=group, async_op=True).get_future()
+    if world == 1:                                          # (bf16 wire on one rank: the round trip through bf16 only)
+        fut = torch.futures.Future()
+        fut.set_result(out)
+    else:
+        fut = dist.all_gather_into_tensor(out, mine, group=group, async_op=True).get_future()
 
     def finish(_f):
         if not in_place:

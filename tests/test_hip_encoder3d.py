@@ -49,6 +49,25 @@ def test_patch_matrices_are_exact():
             np.testing.assert_array_equal(cols.cpu().numpy().reshape(nz, H, W, kpad), ref)
 
 
+def test_deep_volume_walks_the_plane_rings_many_times():
+    """D = 24: the z-marching kernels' plane rings (seven input planes for conv1, three a1 planes for conv2) wrap several times and the
+    depth pooling sums 24 planes -- against the fp64 oracle like the shallow shapes (the rings had been oracle-checked at
+    D <= 9 only).  One volume: the oracle needs ~20 s for it."""
+    shape = (24, 32, 32)
+    w = _weights(24)
+    rng = np.random.RandomState(11)
+    vol = (rng.rand(*shape) * 1.5).astype(np.float32)
+    vol[5:9] = 0.0                                                  # a band of empty planes inside the march
+    enc = HipEncoder3D({k: torch.from_numpy(v) for k, v in w.items()})
+    assert enc.conv2_mode == "march"
+    x = torch.from_numpy(vol).cuda()
+    got = enc(x[None, None]).cpu().numpy()[0]
+    a1 = enc.conv1_activations(x).cpu().numpy()
+    ref, ref_a1 = encoder3d_features(vol, w)
+    assert rel_err(got, ref) < 1e-4
+    assert rel_err(np.moveaxis(a1, -1, 0), ref_a1) < 1e-4
+
+
 @pytest.mark.parametrize("shape,slab", [((8, 32, 32), 1 << 22), ((6, 64, 64), 1 << 24), ((3, 128, 32), 2 << 30)])
 def test_features_vs_oracle(shape, slab):
     """Two volumes -> [2, 128, 32, 32]: conv1 activations and the pooled features within 1e-4 of the fp64 oracle (measured ~1e-6: split-bf16
