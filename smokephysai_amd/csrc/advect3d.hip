@@ -628,7 +628,7 @@ hipError_t launch3_advect_march(const Geom3 &g, State3 in, const float *p, State
     static const int shape = [] { const char *e = getenv("SMK_ADVECT3_ROWS"); return e ? atoi(e) : 4; }();      // rows per wave (diagnostic: 2, 3; default 4)
     if (shape == 4) return p ? launch3_advect_march_t<4, 4, 2, 3, true>(g, in, p, out, frames, fsb, st) : launch3_advect_march_t<4, 4, 2, 3, false>(g, in, nullptr, out, frames, fsb, st);
     if (shape == 2) return p ? launch3_advect_march_t<2, 4, 4, 2, true>(g, in, p, out, frames, fsb, st) : launch3_advect_march_t<2, 4, 4, 2, false>(g, in, nullptr, out, frames, fsb, st);
-    return p ? launch3_advect_march_t<3, 4, 3, 3, true>(g, in, p, out, frames, fsb, st) : launch3_advect_march_t<3, 4, 3, 3, false>(g, in, nullptr, out, frames, fsb, st);
+    return p ? launch3_advect_march_t<3, 4, 3, 2, true>(g, in, p, out, frames, fsb, st) : launch3_advect_march_t<3, 4, 3, 2, false>(g, in, nullptr, out, frames, fsb, st);
 }
 
 }  // namespace smk

@@ -370,6 +370,117 @@ __global__ __launch_bounds__(TXB * TYB) void k3_jacobi_xt(Geom3 g, const float *
     }
 }
 
+// The same temporal blocking with FOUR consecutive x per thread (W % 4 == 0): a 512-thread workgroup owns a 64 x 32 tile (16 lanes x 4 cells
+// per row; halo 4 = one lane / four rows on every side, whatever T <= 4), levels as float4 registers.  A cell's x-neighbours are the
+// thread's own registers except at the quad's two ends, its y-neighbours two 16-byte LDS reads per quad: per quad and sweep 1 ds_write_b128
+// + 2 ds_read_b128 + 2 ds_read_b32 instead of 4 x (1 write + 4 reads), a third of the vector instructions per cell (the scalar form spends
+// more on addresses and selects than on the seven flops), 16-byte global loads and stores.  Expression per cell = k3_jacobi's.
+// PD: planes of p and div requested ahead of their use (2: a third plane in flight costs more in registers than it hides).
+// hipcc notes: a 16-byte load or LDS read under a condition (`ok ? *q : zero`, `shell ? 0 : cell(...)`) is scalarised into per-component
+// loads under exec-mask branches (64 dword loads, 92 branches, 4-way bank conflicts on the dword LDS reads) -- every load here is
+// unconditional on a clamped address and the selects follow.
+template <int T, int PD = 3>
+__global__ __launch_bounds__(512, 2) void k3_jacobi_v4(Geom3 g, const float *__restrict__ p, float *__restrict__ pn, const float *__restrict__ div) {
+    constexpr int LX = 16, ROWS = 32, HALO = 4, UX = 4 * LX - 2 * HALO, UY = ROWS - 2 * HALO;      // useful 56 x 24 of the 64 x 32 tile
+    static_assert(T >= 1 && T <= HALO, "the halo covers T sweeps");
+    // (unpadded 256-byte rows: conflict-free for the lane groups of ds_read_b128 / ds_write_b128 -- a one-quad pad made them 2-way conflicts)
+    __shared__ float4 L[T][2][ROWS][LX];                                                          // T = 4: 64 KB
+    const int lx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const unsigned ntx = (g.W + UX - 1) / UX, nty = (g.H + UY - 1) / UY;
+    unsigned tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bx = tile % ntx; tile /= ntx;
+    const int by = tile % nty;
+    const int b = tile / nty;
+    const int x0 = bx * UX - HALO + 4 * lx, y = by * UY - HALO + ty;                              // this thread's cells: (y, x0 .. x0 + 3)
+    const bool inside = y >= 0 && y < g.H && x0 >= 0 && x0 + 3 < g.W;                             // (W % 4 == 0: a quad is inside or outside as a whole)
+    const bool rowshell = y <= 0 || y >= g.H - 1;
+    const bool sh0 = rowshell || x0 <= 0 || !inside, sh3 = rowshell || x0 + 3 >= g.W - 1 || !inside, sh12 = rowshell || !inside;
+    const bool outc = inside && lx >= 1 && lx < LX - 1 && ty >= HALO && ty < ROWS - HALO;
+    const int tyu = ty > 0 ? ty - 1 : 0, tyd = ty < ROWS - 1 ? ty + 1 : ROWS - 1;
+    const size_t ps = (size_t)g.H * g.pc;
+    const size_t o = b * g.sc + (size_t)(inside ? y : 0) * g.pc + (inside ? x0 : 0);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // every load is unconditional (the address of a quad outside the grid is the tile's first in-grid quad, a plane past the end is the
+    // last plane) and the select follows it: a load under a condition is scalarised into per-component branches by hipcc
+    auto ld4 = [&](const float *base, int plane, bool ok) {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)(plane < g.D ? plane : g.D - 1) * ps);
+        return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    };
+    float4 lm[T], lc[T], dv[T];                          // level l at planes z-l-1 and z-l; div at planes z .. z-T+1
+#pragma unroll
+    for (int l = 0; l < T; ++l) { lm[l] = zero4; lc[l] = zero4; dv[l] = zero4; }
+    lc[0] = ld4(p + o, 0, inside);
+    dv[0] = ld4(div + o, 0, inside);
+    float4 aq[PD], dq[PD];                               // requested: p and div at planes z+1 .. z+PD
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+        aq[i] = ld4(p + o, 1 + i, inside && 1 + i < g.D);
+        dq[i] = ld4(div + o, 1 + i, inside && 1 + i < g.D);
+    }
+    const float sixth = g.sixth;
+    for (int z = 0; z < g.D + T - 1; ++z) {
+        const float4 a_new = ld4(p + o, z + 1 + PD, inside && z + 1 + PD < g.D);
+        const float4 d_new = ld4(div + o, z + 1 + PD, inside && z + 1 + PD < g.D);
+        const float4 a_p = aq[0];                        // input at plane z+1
+#pragma unroll
+        for (int l = 0; l < T; ++l) L[l][z & 1][ty][lx] = lc[l];
+        __syncthreads();
+        float4 up = a_p;                                 // level s-1 at plane z-s+2, starting with the input at z+1
+#pragma unroll
+        for (int s = 1; s <= T; ++s) {
+            const int zp = z - s + 1;                    // the plane sweep s forms now
+            float4 r = zero4;
+            {
+                const bool zin = zp >= 1 && zp < g.D - 1;        // (wave-uniform; as a select below: the LDS reads stay unconditional 16-byte reads)
+                const float4 (*Lp)[LX] = L[s - 1][z & 1];
+                const float4 u4 = Lp[tyu][lx], d4 = Lp[tyd][lx], c4 = lc[s - 1];
+                // the quads to the left / right are the neighbouring lanes of this row of 16: DPP row shifts of the registers (the 4-byte LDS
+                // reads at a 16-byte stride they replace were 4-way bank conflicts: 2/3 of the kernel's LDS cycles).  Lanes 0 / 15 of a row
+                // receive 0: tile-halo cells, whose values nobody uses.
+                const float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c4.w), 0x111, 0xf, 0xf, true));
+                const float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c4.x), 0x101, 0xf, 0xf, true));
+                auto cell = [&](float u_, float d_, float l_, float r_, float f_, float b_, float dv_) {
+                    float sm = u_ + d_;
+                    sm = sm + l_;
+                    sm = sm + r_;
+                    sm = sm + f_;
+                    sm = sm + b_;
+                    sm = sm - dv_;
+                    return sixth * sm;
+                };
+                const float c0 = cell(u4.x, d4.x, lf, c4.y, lm[s - 1].x, up.x, dv[s - 1].x);
+                const float c1 = cell(u4.y, d4.y, c4.x, c4.z, lm[s - 1].y, up.y, dv[s - 1].y);
+                const float c2 = cell(u4.z, d4.z, c4.y, c4.w, lm[s - 1].z, up.z, dv[s - 1].z);
+                const float c3 = cell(u4.w, d4.w, c4.z, rt, lm[s - 1].w, up.w, dv[s - 1].w);
+                r.x = (sh0 || !zin) ? 0.f : c0;
+                r.y = (sh12 || !zin) ? 0.f : c1;
+                r.z = (sh12 || !zin) ? 0.f : c2;
+                r.w = (sh3 || !zin) ? 0.f : c3;
+            }
+            lm[s - 1] = lc[s - 1];
+            lc[s - 1] = up;
+            up = r;
+        }
+        if (z >= T - 1 && outc) *reinterpret_cast<float4 *>(pn + o + (size_t)(z - T + 1) * ps) = up;
+#pragma unroll
+        for (int l = T - 1; l > 0; --l) dv[l] = dv[l - 1];
+        dv[0] = dq[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PD; ++i) { aq[i] = aq[i + 1]; dq[i] = dq[i + 1]; }
+        aq[PD - 1] = a_new;
+        dq[PD - 1] = d_new;
+    }
+}
+
+template <int T>
+static void launch3_jacobi_v4(const Geom3 &g, const float *cur, float *nxt, const float *div, hipStream_t st) {
+    const unsigned nb = (unsigned)(cdiv(g.W, 56) * cdiv(g.H, 24) * g.B);
+    static const int pd = [] { const char *e = getenv("SMK_JACOBI3_PD"); return e ? atoi(e) : 2; }();     // planes requested ahead (measured per configs[4] step: 1 -> 6.00 ms, 2 -> 5.98, 3 -> 6.70; the one-cell-per-thread kernel 6.50)
+    if (pd == 1) hipLaunchKernelGGL((k3_jacobi_v4<T, 1>), dim3(nb), dim3(512), 0, st, g, cur, nxt, div);
+    else if (pd == 2) hipLaunchKernelGGL((k3_jacobi_v4<T, 2>), dim3(nb), dim3(512), 0, st, g, cur, nxt, div);
+    else hipLaunchKernelGGL((k3_jacobi_v4<T, 3>), dim3(nb), dim3(512), 0, st, g, cur, nxt, div);
+}
+
 template <int T, int TXB, int TYB, int CY>
 static void launch3_jacobi_xt(const Geom3 &g, const float *cur, float *nxt, const float *div, hipStream_t st) {
     dim3 block(TXB, TYB), grid((unsigned)(cdiv(g.W, TXB - 2 * T) * cdiv(g.H, TYB * CY - 2 * T) * g.B));
@@ -383,19 +494,25 @@ hipError_t launch3_jacobi(const Geom3 &g, float *p, float *p2, const float *div,
     int it = 0;
     // temporally blocked launches first (SMK_JACOBI3_T = 1, 2, 4 caps the sweeps per launch; default 4), single sweeps for the rest
     static const int tmax = [] { const char *e = getenv("SMK_JACOBI3_T"); return e ? atoi(e) : 4; }();
+    // four cells per thread (k3_jacobi_v4) where rows are whole quads; SMK_JACOBI3_QUAD=0 keeps the one-cell-per-thread blocked kernel
+    static const int quad_env = [] { const char *e = getenv("SMK_JACOBI3_QUAD"); return e ? atoi(e) : 1; }();      // 0 never, 1 always, 2 for the 2-sweep launches only
+    const bool quad_ok = vec && (((uintptr_t)p | (uintptr_t)p2 | (uintptr_t)div) & 15) == 0 && g.sc % 4 == 0;
+    const bool quad = quad_ok && quad_env == 1, quad2 = quad_ok && quad_env >= 1;
     if (g.B <= 65535) {
         if (tmax >= 4) {
             // an even number of launches ends in p without a copy: with iters % 4 == 0 and an odd count, trade one 4-sweep launch for two 2-sweep ones
             int n4 = iters / 4;
             if (iters % 4 == 0 && (n4 & 1) && n4 >= 1) --n4;
             for (int k = 0; k < n4; ++k, it += 4) {
-                launch3_jacobi_xt<4, 64, 16, 2>(g, cur, nxt, div, st);
+                if (quad) launch3_jacobi_v4<4>(g, cur, nxt, div, st);
+                else launch3_jacobi_xt<4, 64, 16, 2>(g, cur, nxt, div, st);
                 float *t = cur; cur = nxt; nxt = t;
             }
         }
         if (tmax >= 2)
             for (; it + 2 <= iters; it += 2) {
-                launch3_jacobi_xt<2, 64, 16, 1>(g, cur, nxt, div, st);
+                if (quad2) launch3_jacobi_v4<2>(g, cur, nxt, div, st);
+                else launch3_jacobi_xt<2, 64, 16, 1>(g, cur, nxt, div, st);
                 float *t = cur; cur = nxt; nxt = t;
             }
     }
