@@ -94,6 +94,7 @@ struct smk_sim3d {
     State3 s;             // caller-owned
     State3 t;             // library scratch (u2, v2, w2, p2, d2)
     float *div = nullptr;
+    float *p3 = nullptr;   // third pressure buffer: only when the Jacobi plan has an odd number (>= 3) of launches (launch3_jacobi)
     uint8_t *dev_mask = nullptr;
     Src3Dev *dev_src = nullptr;
     int *dev_first = nullptr;
@@ -473,6 +474,10 @@ int smk_sim3d_create(const smk_sim3d_desc *d, smk_sim3d **out) {
     auto alloc = [&](float **p, size_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, n * sizeof(float)); };
     alloc(&sim->t.u, B * g.su); alloc(&sim->t.v, B * g.sv); alloc(&sim->t.w, B * g.sw); alloc(&sim->t.p, B * g.sc); alloc(&sim->t.d, B * g.sc);
     alloc(&sim->div, B * g.sc);
+    {   // J = 4 n with n odd and >= 3 (the default J = 20): five 4-sweep launches through a third buffer instead of four + two 2-sweep ones
+        const int J = sim->jacobi_iters;
+        if (J % 4 == 0 && ((J / 4) & 1) && J / 4 >= 3) alloc(&sim->p3, B * g.sc);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&sim->dev_mask, B);
     if (e == hipSuccess) e = hipMalloc((void **)&sim->dev_first, (B + 1) * sizeof(int));
     if (e != hipSuccess) {
@@ -487,7 +492,7 @@ int smk_sim3d_create(const smk_sim3d_desc *d, smk_sim3d **out) {
 int smk_sim3d_destroy(smk_sim3d *sim) {
     if (!sim) return SMK_OK;
     DeviceGuard guard(sim->device);
-    float *ptrs[] = {sim->t.u, sim->t.v, sim->t.w, sim->t.p, sim->t.d, sim->div};
+    float *ptrs[] = {sim->t.u, sim->t.v, sim->t.w, sim->t.p, sim->t.d, sim->div, sim->p3};
     for (float *p : ptrs) if (p) (void)hipFree(p);
     if (sim->dev_mask) (void)hipFree(sim->dev_mask);
     if (sim->dev_first) (void)hipFree(sim->dev_first);
@@ -556,7 +561,7 @@ int run_stage3d(smk_sim3d *sim, int stage, float *frames, int64_t fsb, hipStream
         case SMK_STAGE3D_PROJECT: {
             int rc = check_launch(launch3_divergence(g, t, sim->div, st), "divergence3d");
             if (rc) return rc;
-            rc = check_launch(launch3_jacobi(g, s.p, t.p, sim->div, sim->jacobi_iters, st), "jacobi3d");
+            rc = check_launch(launch3_jacobi(g, s.p, t.p, sim->p3, sim->div, sim->jacobi_iters, st), "jacobi3d");
             if (rc || keep_gradient) return rc;          // keep_gradient: the advection launch subtracts dt grad p while it stages its inputs
             return check_launch(launch3_grad_subtract(g, t, s.p, st), "grad_subtract3d");
         }
@@ -594,7 +599,7 @@ int smk_sim3d_step(smk_sim3d *sim, int32_t n_steps, float *frames, int64_t fsb, 
         if (fused_dd) {
             rc = check_launch(launch3_diffuse_div_march(g, sim->s, sim->t, sim->div, st), "diffuse_div_march3d");
             if (rc) return rc;
-            rc = check_launch(launch3_jacobi(g, sim->s.p, sim->t.p, sim->div, sim->jacobi_iters, st), "jacobi3d");
+            rc = check_launch(launch3_jacobi(g, sim->s.p, sim->t.p, sim->p3, sim->div, sim->jacobi_iters, st), "jacobi3d");
             if (rc) return rc;
             if (!fold_grad) {
                 rc = check_launch(launch3_grad_subtract(g, sim->t, sim->s.p, st), "grad_subtract3d");

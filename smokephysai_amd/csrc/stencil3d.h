@@ -23,8 +23,9 @@ hipError_t launch3_buoy_diffuse(const Geom3 &g, State3 in, State3 out, hipStream
 hipError_t launch3_divergence(const Geom3 &g, State3 s, float *div, hipStream_t st);
 // buoyancy + the four diffusions + the divergence of the diffused velocities as ONE z-marching launch (bit-identical to the two launches)
 hipError_t launch3_diffuse_div_march(const Geom3 &g, State3 in, State3 out, float *div, hipStream_t st);
-// `iters` sweeps on `div`; result in p (p2 scratch of the same layout)
-hipError_t launch3_jacobi(const Geom3 &g, float *p, float *p2, const float *div, int iters, hipStream_t st);
+// `iters` sweeps on `div`; result in p (p2, and p3 if not null, scratch of the same layout: a third buffer lets an odd number of launches
+// end in p without a copy)
+hipError_t launch3_jacobi(const Geom3 &g, float *p, float *p2, float *p3, const float *div, int iters, hipStream_t st);
 hipError_t launch3_grad_subtract(const Geom3 &g, State3 s, const float *p, hipStream_t st);
 // which 0..3 = u, v, w, density (x 0.995, + optional frame [B][D][H][W] dense at frame_stride_b floats per grid)
 hipError_t launch3_advect(const Geom3 &g, int which, const float *field, float *out, const float *u, const float *v, const float *w,

@@ -487,41 +487,53 @@ static void launch3_jacobi_xt(const Geom3 &g, const float *cur, float *nxt, cons
     hipLaunchKernelGGL((k3_jacobi_xt<T, TXB, TYB, CY>), grid, block, 0, st, g, cur, nxt, div);
 }
 
-hipError_t launch3_jacobi(const Geom3 &g, float *p, float *p2, const float *div, int iters, hipStream_t st) {
-    float *cur = p, *nxt = p2;
+hipError_t launch3_jacobi(const Geom3 &g, float *p, float *p2, float *p3, const float *div, int iters, hipStream_t st) {
     const bool vec = g.W % 4 == 0 && g.pc % 4 == 0 && getenv("SMK_JACOBI3_SCALAR") == nullptr;
     dim3 block(TX3, TY3), grid(cdiv(vec ? g.W / 4 : g.W, TX3), cdiv(g.H, TY3), g.B * g.D);
-    int it = 0;
     // temporally blocked launches first (SMK_JACOBI3_T = 1, 2, 4 caps the sweeps per launch; default 4), single sweeps for the rest
     static const int tmax = [] { const char *e = getenv("SMK_JACOBI3_T"); return e ? atoi(e) : 4; }();
     // four cells per thread (k3_jacobi_v4) where rows are whole quads; SMK_JACOBI3_QUAD=0 keeps the one-cell-per-thread blocked kernel
     static const int quad_env = [] { const char *e = getenv("SMK_JACOBI3_QUAD"); return e ? atoi(e) : 1; }();      // 0 never, 1 always, 2 for the 2-sweep launches only
-    const bool quad_ok = vec && (((uintptr_t)p | (uintptr_t)p2 | (uintptr_t)div) & 15) == 0 && g.sc % 4 == 0;
+    const bool quad_ok = vec && (((uintptr_t)p | (uintptr_t)p2 | (uintptr_t)p3 | (uintptr_t)div) & 15) == 0 && g.sc % 4 == 0;
     const bool quad = quad_ok && quad_env == 1, quad2 = quad_ok && quad_env >= 1;
-    if (g.B <= 65535) {
-        if (tmax >= 4) {
-            // an even number of launches ends in p without a copy: with iters % 4 == 0 and an odd count, trade one 4-sweep launch for two 2-sweep ones
-            int n4 = iters / 4;
-            if (iters % 4 == 0 && (n4 & 1) && n4 >= 1) --n4;
-            for (int k = 0; k < n4; ++k, it += 4) {
-                if (quad) launch3_jacobi_v4<4>(g, cur, nxt, div, st);
-                else launch3_jacobi_xt<4, 64, 16, 2>(g, cur, nxt, div, st);
-                float *t = cur; cur = nxt; nxt = t;
-            }
+    // the launch plan: sweeps per launch.  The result must end in p without a copy.  Two buffers ping-pong, so an even launch count does;
+    // an odd count of three or more goes p -> p2 -> p3 -> p2 -> ... -> p through the third buffer (J = 20: five 4-sweep launches); without a
+    // third buffer one 4-sweep launch is traded for two 2-sweep ones (round 3's plan: 4 x 4 + 2 x 2)
+    int plan[64], n = 0, left = iters;
+    const bool blocked = g.B <= 65535;
+    int n4 = (blocked && tmax >= 4) ? left / 4 : 0;
+    if (n4 > 60) n4 = 60;
+    const bool third = p3 != nullptr && getenv("SMK_JACOBI3_THIRD") == nullptr;
+    if (!third && left % 4 == 0 && (n4 & 1) && n4 * 4 == left) --n4;
+    for (int k = 0; k < n4; ++k) plan[n++] = 4;
+    left -= 4 * n4;
+    if (blocked && tmax >= 2)
+        for (; left >= 2 && n < 62; left -= 2) plan[n++] = 2;
+    float *cur = p;
+    auto target = [&](int i, int total) -> float * {            // where launch i of `total` writes
+        if (i == total - 1 && cur != p) return p;
+        if (third && (total & 1) && total >= 3) return cur == p2 ? p3 : p2;
+        return cur == p ? p2 : p;
+    };
+    const int total = n + left;                                     // (the remaining `left` sweeps run one per launch)
+    for (int i = 0; i < n; ++i) {
+        float *nxt = target(i, total);
+        if (plan[i] == 4) {
+            if (quad) launch3_jacobi_v4<4>(g, cur, nxt, div, st);
+            else launch3_jacobi_xt<4, 64, 16, 2>(g, cur, nxt, div, st);
+        } else {
+            if (quad2) launch3_jacobi_v4<2>(g, cur, nxt, div, st);
+            else launch3_jacobi_xt<2, 64, 16, 1>(g, cur, nxt, div, st);
         }
-        if (tmax >= 2)
-            for (; it + 2 <= iters; it += 2) {
-                if (quad2) launch3_jacobi_v4<2>(g, cur, nxt, div, st);
-                else launch3_jacobi_xt<2, 64, 16, 1>(g, cur, nxt, div, st);
-                float *t = cur; cur = nxt; nxt = t;
-            }
+        cur = nxt;
     }
-    for (; it < iters; ++it) {
+    for (int i = n; i < total; ++i) {
+        float *nxt = target(i, total);
         if (vec) hipLaunchKernelGGL(k3_jacobi4, grid, block, 0, st, g, cur, nxt, div);
         else hipLaunchKernelGGL(k3_jacobi, grid, block, 0, st, g, cur, nxt, div);
-        float *t = cur; cur = nxt; nxt = t;
+        cur = nxt;
     }
-    if (cur != p) {
+    if (cur != p) {                                                 // (one launch in all, or an odd count without a third buffer)
         const hipError_t e = hipMemcpyAsync(p, cur, (size_t)g.B * g.sc * sizeof(float), hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return e;
     }
