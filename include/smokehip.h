@@ -72,7 +72,8 @@ int smk_sim_destroy(smk_sim *sim);
 int smk_sim_status(smk_sim *sim);
 
 /* NavierStokesSimulator.setup_grid (navier_stokes.py:24-35): zero u,v,p,density of the grids whose byte in
- * grid_mask (host, B bytes) is non-zero; NULL = all grids. */
+ * grid_mask (host, B bytes) is non-zero; NULL = all grids.  If a persistent-projection time-out is pending (smk_sim_status), this call
+ * returns SMK_ERR_TIMEOUT once like any other entry point -- but it has carried out the reset, so it need not be repeated. */
 int smk_sim_reset(smk_sim *sim, const uint8_t *grid_mask, void *stream);
 
 typedef struct smk_source {

@@ -267,7 +267,10 @@ int smk_sim_status(smk_sim *sim) {
 
 int smk_sim_reset(smk_sim *sim, const uint8_t *grid_mask, void *stream) {
     SMK_REQUIRE(sim, "null sim");
-    if (int e = sim_entry(sim)) return e;
+    // a pending time-out report is acknowledged here like at every entry point, but the reset -- the recovery the report asks for -- is
+    // still carried out: ONE call both tells the caller and leaves the requested grids zeroed (the message stays in smk_last_error)
+    const int pending = sim_entry(sim);
+    if (pending && pending != SMK_ERR_TIMEOUT) return pending;
     hipStream_t st = (hipStream_t)stream;
     DeviceGuard guard(sim->device);
     int rc = guard.rc;
@@ -277,7 +280,9 @@ int smk_sim_reset(smk_sim *sim, const uint8_t *grid_mask, void *stream) {
         SMK_HIP_TRY(hipMemcpyAsync(sim->dev_mask, grid_mask, sim->g.B, hipMemcpyHostToDevice, st));
         dm = sim->dev_mask;
     }
-    return check_launch(launch_zero_state(sim->g, sim->s, dm, st), "zero_state");
+    const hipError_t le = launch_zero_state(sim->g, sim->s, dm, st);
+    if (le != hipSuccess) return check_launch(le, "zero_state");
+    return pending;                                           // SMK_OK, or SMK_ERR_TIMEOUT once with the reset done
 }
 
 int smk_sim_add_sources(smk_sim *sim, const smk_source *src, int32_t n, void *stream) {

@@ -126,6 +126,22 @@ try:
     out.append("next=no-error")
 except RuntimeError as e:
     out.append("next=%s" % ("raised" if "persistent projection" in str(e) else "other"))
+# (5) a reset issued while the report is still pending: ONE call raises the report and has zeroed the state (no second reset needed)
+ns5 = NavierStokesSimulator((256, 256), batch_size=64, jacobi_iters=100)
+ns5.add_smoke_sources([(b, 100, 100, 8, 1.0) for b in range(64)])
+ns5.step_into(frame, 1)
+torch.cuda.synchronize()
+try:
+    ns5.setup_grid()
+    out.append("reset=no-error")
+except RuntimeError as e:
+    out.append("reset=%s" % ("raised" if "persistent projection" in str(e) else "other"))
+torch.cuda.synchronize()
+out.append("zeroed=%s" % all(float(getattr(ns5, k).abs().sum()) == 0.0 for k in ("u", "v", "p", "density")))
+ns5.add_smoke_sources([(b, 100, 100, 8, 1.0) for b in range(64)])
+ns5.step_into(frame, 1)
+ns5.check()
+out.append("after_reset=%s" % (bool(torch.isfinite(frame).all()) and float(frame.abs().sum()) > 0))
 print("RESULT %.3f %s" % (dt, " ".join(out)))
 """
 
@@ -133,14 +149,15 @@ print("RESULT %.3f %s" % (dt, " ".join(out)))
 def test_a_band_that_never_publishes_times_out_and_is_reported_by_the_call_that_suffered_it():
     """One band never publishes its hand-off (SMK_JACOBI_FAULT=1, 2 ms waits): the launch drains; the affected grid's results are NaN;
     smk_sim_status after a synchronise reports it for THAT step (once); simulate_sequence(20) raises from its own call; a handle that
-    is only destroyed still reports; the handle recovers after a reset on the multi-launch form.  Run once (no retry loops)."""
+    is only destroyed still reports; the handle recovers after a reset on the multi-launch form; a reset issued with the report pending
+    raises it once and HAS reset the state.  Run once (no retry loops)."""
     r = _run({"SMK_JACOBI_FAULT": "1", "SMK_JACOBI_PERSIST": "1"}, _FAULT.format(root=ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1].split()
     assert float(line[1]) < 30.0, line    # bounded: 2 ms per wait under fault injection (first call includes library start-up)
     got = dict(kv.split("=", 1) for kv in line[2:])
     assert got == {"status": "-5", "named": "True", "nan": "True", "again": "0", "recovered": "True", "multilaunch": "True",
-                   "sequence": "raised", "close": "raised", "next": "raised"}, got
+                   "sequence": "raised", "close": "raised", "next": "raised", "reset": "raised", "zeroed": "True", "after_reset": "True"}, got
 
 
 def test_time_steps_recorded_in_a_hip_graph_replay_bit_identically():
