@@ -46,6 +46,34 @@ def test_round3_bench_line_has_the_new_blocks():
     assert d["effective_warmup_steps"]["headline_leg"] == 5
 
 
+def test_round4_bench_line_has_the_new_blocks():
+    """The driver-like line of the round-4 build (profiles/r04/bench_steps20_driverlike.json): configs[4] timed as a pipeline with measured
+    traffic behind its stencil roofline, the encoder's dense-input figures beside the simulated-frame ones, the direct exchange's flat time."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_steps20_driverlike.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "dataset", "config4", "train_step", "inference_ms_per_frame", "encode_only_dense"):
+        assert k in d, k
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1
+    assert abs(d["value"] - 64 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-6
+    for r in (d["roofline"], d["roofline_stencil"], d["roofline_encoder"]):
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    dense = d["encode_only_dense"]
+    assert dense["ms_per_launch"] > d["ms_encode_per_step"] and abs(dense["frac"] - d["roofline_encoder"]["frac_dense"]) < 1e-12
+    c4 = d["config4"]
+    parts = c4["ms_sim_per_step"] + 8 * c4["ms_encode_per_volume"]
+    assert 0.98 * parts <= c4["ms_per_step"] <= 1.1 * parts and abs(c4["value"] - 8 / (c4["ms_per_step"] * 1e-3)) < 1e-6
+    assert c4["ms_sim_per_step"] <= 7.0                                   # VERDICT r3 item 1 (was 9.03)
+    rs = c4["roofline_stencil"]
+    assert rs["traffic"] > 0 and rs["traffic"] < c4["algorithmic_bytes_per_step"] and rs["traffic"] >= rs["compulsory_bytes_per_step"]
+    assert abs(rs["frac_measured"] - rs["traffic"] / (c4["ms_sim_per_step"] * 1e-3) / 1e9 / rs["peak"]) < 1e-9
+    assert c4["ms_encode_per_volume_dense"] > c4["ms_encode_per_volume"]
+    ts = d["train_step"]
+    assert ts["rccl_ranks"] == 1 and "error" not in ts and ts["direct_exchange_flat"]["ms"] <= 0.05        # VERDICT r3 item 6 (was 0.262)
+    inf = d["inference_ms_per_frame"]
+    assert inf["batch4"] < 0.300 and inf["batch1"] < 0.631 and inf["batch64"] <= 0.195                     # round 3's driver record
+
+
 def test_bench_cli_defaults_are_the_baseline_config():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, check=True).stdout
     for flag in ("--gpus", "--steps", "--warmup", "--grid", "--batch", "--jacobi", "--encoder-dtype"):
