@@ -170,7 +170,7 @@ def test_layernorm_and_attention_split_bf16_outputs():
     assert os_.shape == (2, 256, 64, 2, 8) and rel_err(from_split(os_).cpu().numpy(), o.cpu().numpy()) < 2.0 ** -16
 
 
-@pytest.mark.parametrize("B,S", [(1, 32), (3, 32), (2, 16)])
+@pytest.mark.parametrize("B,S", [(1, 32), (3, 32), (2, 16), (12, 32)])      # (B <= 8: the latency-cut small-batch kernels; 12: the tiled ones)
 def test_decoder_head_matches_torch(B, S):
     """smk_decoder_forward (BN-folded direct fp32 kernels) against the PyTorch reconstruction_head in eval mode
     (smokephys_net.py:57-66,117-118), including the tokens -> [B,64,S,S] re-view."""
