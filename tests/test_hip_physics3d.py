@@ -106,6 +106,36 @@ def test_batched_trajectories_bit_exact_vs_per_grid_oracle(shape, J, steps):
     assert np.abs(sim.w.cpu().numpy()).max() > 0
 
 
+@pytest.mark.parametrize("shape,vel,J", [((13, 22, 19), 0.5, 6), ((13, 22, 19), 300.0, 6), ((4, 16, 64), 150.0, 4), ((6, 40, 130), 40.0, 8),
+                                         ((6, 40, 130), 400.0, 8), ((5, 35, 64), 2.0, 5)])
+def test_whole_steps_from_dense_random_states_bit_exact_vs_oracle(shape, vel, J):
+    """smk_sim3d_step -- the z-marching launches: buoyancy + diffusion + divergence, the blocked Jacobi, gradient subtraction + the four
+    advections -- from DENSE random states of two grids, two steps, against the oracle's step().  vel 0.5-40: every cell moves, every
+    back-trace stays in its 2 x 2 x 2 LDS neighbourhood (the fast form, with non-zero weights everywhere); vel 150-400: dt * velocity
+    reaches several cells, so whole batches of units leave through far_value3 (general form on global memory, gradient re-applied per
+    tap) while others of the same launch stay on the fast form.  Shapes: odd everything; exactly one tile; three x-tiles with a 2-wide last
+    one and rows that do not fill the last wave; H not a multiple of the rows per wave."""
+    D, H, W = shape
+    B = 2
+    sim = NavierStokesSimulator3D(shape, batch_size=B, jacobi_iters=J)
+    os_ = [_random_state(shape, 100 * D + W + b, vel) for b in range(B)]
+    for b in range(B):
+        os_[b].jacobi_iters = J
+        _to_device(sim, os_[b], b)
+    steps = 2
+    frames = torch.empty(B, steps, D, H, W, device="cuda")
+    sim.step_into(frames, steps)
+    torch.cuda.synchronize()
+    fr = frames.cpu().numpy()
+    for b in range(B):
+        o = os_[b]
+        for t in range(steps):
+            out = o.step()
+            np.testing.assert_array_equal(fr[b, t], out, err_msg=f"grid {b} frame {t}")
+        _assert_equal(sim, o, f"grid {b}", b)
+        assert np.isfinite(o.density).all() and np.abs(o.u).max() > 0
+
+
 def test_reset_of_a_grid_subset_and_loud_failures():
     sim = NavierStokesSimulator3D((8, 16, 16), batch_size=3)
     sim.add_smoke_source(8, 8, 4, radius=3, intensity=1.0)
