@@ -507,8 +507,8 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None, force_dis
         dr = (time.perf_counter() - t0) / 5
         res["direct_exchange_flat"] = {"bytes": nparam * 4, "ms": dr * 1e3, "algbw_GBs": nparam * 4 / dr / 1e9,
                                        "what": "utils.distributed.direct_exchange_hook on the flat gradient: all_to_all_single straight from the bucket, "
-                                               "smk_reduce_shards (one launch: rank-order fp32 sum / N into the owner's slice), in-place "
-                                               "all_gather_into_tensor; one rank: nothing to move"}
+                                               "smk_reduce_shards (one launch: rank-order fp32 sum / N of the owner's shard), all_gather_into_tensor "
+                                               "into the bucket; one rank: nothing to move"}
         del ddp, flat
         import gc
         gc.collect()                                         # (the first wrapper's reducer hooks go with it)

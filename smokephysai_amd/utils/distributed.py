@@ -85,8 +85,8 @@ def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) ->
     reduced shards, one hop.  Each rank sends and receives (N-1)/N of the bucket twice -- the ring's byte count, in 2 hops instead of 2 (N-1).
 
     No staging copies: with the gradients' own fp32 on the wire the all-to-all reads the bucket where it lies (the first N * (n // N)
-    elements; the < N left over go through one tiny all-reduce), the owner's pass is ONE kernel (`reduce_shards`) that writes the mean
-    straight into the owner's slice of the bucket, and the all-gather is in place on the bucket.  `state.wire_dtype = torch.bfloat16`
+    elements; the < 4 N left over go through one tiny all-reduce), the owner's pass is ONE kernel (`reduce_shards`) that writes the mean
+    of its shard (1 / N of the bucket), and the all-gather delivers straight into the bucket.  `state.wire_dtype = torch.bfloat16`
     halves the bytes on both hops (the sum itself stays fp32) at the price of one conversion pass each way; off by default because the
     averaged gradient is then rounded to 8 bits.  One rank: the mean over one copy is the copy -- with fp32 on the wire nothing is moved
     and nothing is launched (RCCL's own one-rank all-reduce is a no-op too, 0.014 ms; its one-rank all-gather is NOT: it copies the 111 MB
@@ -128,12 +128,14 @@ def direct_exchange_hook(state: DirectExchangeState, bucket: dist.GradBucket) ->
         dist.all_to_all_single(recv, src, group=group)
     else:
         recv = src                                          # one rank: its own shard is all there is
-    in_place = src is main                                  # fp32 on the wire, device tensors: reduce into and gather on the bucket itself
+    in_place = src is main                                  # fp32 on the wire, device tensors: gather straight into the bucket
     out = main if in_place else torch.empty(world * q, dtype=wire, device=src.device)
-    mine = out[rank * q:(rank + 1) * q]
-    if world > 1 or not in_place:
-        reduce_shards(recv, world, q, mine)
+    # the owner's mean goes to a buffer of its own (q elements: 1 / N of the bucket) rather than into out[rank * q : (rank + 1) * q]:
+    # an all-gather whose input aliases its output is legal for NCCL / RCCL but has never met this tree's hardware at N > 1
+    mine = torch.empty(q, dtype=wire, device=src.device)
+    reduce_shards(recv, world, q, mine)
     if world == 1:                                          # (bf16 wire on one rank: the round trip through bf16 only)
+        out[:q].copy_(mine)
         fut = torch.futures.Future()
         fut.set_result(out)
     else:
