@@ -77,8 +77,9 @@ def test_self_launched_two_ranks_gloo_rehearsal():
     c4 = d["config4"]
     assert c4["n_gpus"] == 2 and c4["volumes_per_gpu"] == 4 and c4["value"] > 0
     # measured as a pipeline (step -> encode -> step ...): the whole step is the two parts plus the launch gaps between them
+    # (every component is the MAX over the two ranks -- which share one card here -- so the whole step may undercut the sum of the maxima)
     parts = c4["ms_sim_per_step"] + 4 * c4["ms_encode_per_volume"]
-    assert 0.98 * parts <= c4["ms_per_step"] <= 1.25 * parts, (c4["ms_per_step"], parts)
+    assert 0.6 * parts <= c4["ms_per_step"] <= 1.25 * parts, (c4["ms_per_step"], parts)
     assert c4["ms_encode_per_volume_dense"] > 0 and "pipelined" in c4["timing"]
     ts = d["train_step"]
     assert "error" not in ts, ts
