@@ -170,27 +170,37 @@ hipError_t launch_chaos_addend_batch(const ChaosAddendBatch &a, hipStream_t st) 
 //
 // Workgroup = 256 threads = one (batch, head, 128-query block); wave w owns queries 32w..32w+31 with Q (pre-scaled by
 // scale*log2 e, split) in registers.  K/V tiles of 64 keys are split on the fly and staged through LDS, double buffered:
-// K row-major [key][d] (pitch 144 B), V TRANSPOSED [d][key] (pitch 136 B; a staging thread holds a 4-key x 4-d block, so the
-// transposed image is written with 8-byte stores).
+// K row-major [key][d] (pitch 144 B), V row-major too ([key][d], unpadded 128-byte rows whose 64-byte halves are swapped on keys with
+// bit 1 set) and read back TRANSPOSED by ds_read_b64_tr_b16 -- both images are written with conflict-free 8-byte row stores (round 3's
+// [d][key] image of V cost a 4-way bank conflict on every store, 27 % of the kernel's LDS cycles, and 4 x 4 register transposes).
 //   S^T = mfma(K, Q): the query is the lane (column), 16 keys per 32-key block sit in the lane's accumulator registers, the
 //         other 16 in lane ^ 32 -> row max / sum are lane-local plus one cross-half exchange; alpha is a per-lane scalar.
 //   O^T = mfma(V^T, P): exp2'd accumulator registers 8s..8s+7 ARE the B fragment of k-step s (cdna_hip_programming.md, "An
 //         accumulator tile as the next MFMA's operand"); their fixed k-permutation -- element j of lane half h is key
-//         16s + 8(j>>2) + 4h + (j&3) -- is matched on the A side by reading V^T at keys 16s+4h..+3 and 16s+8+4h..+3
-//         (two ds_read_b64).
+//         16s + 8(j>>2) + 4h + (j&3) -- is matched on the A side by two transposed reads of V, at keys 16s+4h..+3 and 16s+8+4h..+3.
 // O^T leaves each lane with 4 consecutive d of its query per register quad -> 16-byte stores into [B][L][H*64].
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#if defined(SMK_ATT_ABLATE) && (SMK_ATT_ABLATE & 4)      // diagnostic: the MFMAs replaced by one dependent vector op each (operands stay live)
+#define AT_MFMA(A, B, C) ([&] { auto c_ = (C); c_[0] += __builtin_bit_cast(f32x4_t, (A))[0] * __builtin_bit_cast(f32x4_t, (B))[0]; return c_; }())
+#else
+#define AT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+#endif
 
 constexpr int AT_QB = 128, AT_KV = 64;
-constexpr int AT_KPITCH = 144, AT_VPITCH = 136;
-constexpr int AT_KPLANE = 64 * AT_KPITCH, AT_VPLANE = 64 * AT_VPITCH;          // 9216, 8704
-constexpr int AT_BUF = 2 * AT_KPLANE + 2 * AT_VPLANE;                          // 35,840 B per tile (K hi|lo, V^T hi|lo)
-constexpr int AT_LDS = 2 * AT_BUF;                                             // 71,680 B -> 2 workgroups per CU
+constexpr int AT_KPITCH = 144, AT_VPITCH = 128;
+constexpr int AT_KPLANE = 64 * AT_KPITCH, AT_VPLANE = 64 * AT_VPITCH;          // 9216, 8192
+constexpr int AT_BUF = 2 * AT_KPLANE + 2 * AT_VPLANE;                          // 34,816 B per tile (K hi|lo, V hi|lo)
+constexpr int AT_LDS = 2 * AT_BUF;                                             // 69,632 B -> 2 workgroups per CU
 
 __device__ __forceinline__ void at_split4(const float4 &v, bf16x4 &h, bf16x4 &l) {
+#if defined(SMK_ATT_ABLATE) && (SMK_ATT_ABLATE & 2)      // diagnostic build (tools/att_ablate.sh): no split arithmetic, same LDS stores
+    h = __builtin_bit_cast(bf16x4, make_float2(v.x, v.y)); l = __builtin_bit_cast(bf16x4, make_float2(v.z, v.w));
+    return;
+#endif
     const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.k), 0, (int)((size_t)a.B * a.L * a.ldk * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.v), 0, (int)((size_t)a.B * a.L * a.ldv * 4), 0x00020000);
     const int lane_k = (rq * a.ldk + head * 64 + c4 * 4) * 4;                  // K: rows rq + 16j of the tile
-    const int lane_v = (rq * 4 * a.ldv + head * 64 + c4 * 4) * 4;              // V: rows 4rq + i
+    const int lane_v = (rq * a.ldv + head * 64 + c4 * 4) * 4;                  // V: rows rq + 16j, as K
     float4 kst[4], vst[4];
     auto stage_load = [&](int t) {
         const int tt = T0 + (t < NT ? t : NT - 1);                             // past the end: a harmless re-read
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
         for (int j = 0; j < 4; ++j) {
             const u32x4 kv = __builtin_amdgcn_raw_buffer_load_b128(krs, (int)((row0 + 16 * j) * (unsigned)a.ldk * 4u) + lane_k, 0, 0);
             kst[j] = make_float4(__uint_as_float(kv.x), __uint_as_float(kv.y), __uint_as_float(kv.z), __uint_as_float(kv.w));
-            const u32x4 vv = __builtin_amdgcn_raw_buffer_load_b128(vrs, (int)((row0 + j) * (unsigned)a.ldv * 4u) + lane_v, 0, 0);
+            const u32x4 vv = __builtin_amdgcn_raw_buffer_load_b128(vrs, (int)((row0 + 16 * j) * (unsigned)a.ldv * 4u) + lane_v, 0, 0);
             vst[j] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
         }
     };
@@ -266,18 +276,23 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
             *reinterpret_cast<bf16x4 *>(p) = h;
             *reinterpret_cast<bf16x4 *>(p + AT_KPLANE) = l;
         }
-        bf16x4 vh[4], vl[4];                                                   // [key i][d e] of the 4 x 4 block
 #pragma unroll
-        for (int i = 0; i < 4; ++i) at_split4(vst[i], vh[i], vl[i]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                                         // V^T[d 4c4 + e][keys 4rq .. 4rq+3]
+        for (int j = 0; j < 4; ++j) {                                         // V[key rq + 16j][d 4c4..] (64-byte halves swapped on keys with bit 1)
             bf16x4 h, l;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { h[i] = vh[i][e]; l[i] = vl[i][e]; }
-            unsigned char *p = base + 2 * AT_KPLANE + (c4 * 4 + e) * AT_VPITCH + rq * 8;
+            at_split4(vst[j], h, l);
+            unsigned char *p = base + 2 * AT_KPLANE + (rq + 16 * j) * AT_VPITCH + ((c4 * 8) ^ (((rq >> 1) & 1) << 6));
             *reinterpret_cast<bf16x4 *>(p) = h;
             *reinterpret_cast<bf16x4 *>(p + AT_VPLANE) = l;
         }
+    };
+
+    // V fragments by transposed reads (ds_read_b64_tr_b16): 16-lane group g16 = lane >> 4 = (d half g16 & 1, key half hh); lane 4q + pp of it
+    // supplies the address of key row 4hh + q, d 16 (g16 & 1) + 4pp .. + 3, and receives d (lane & 15) of the group's four key rows.
+    // Rows q = 0 .. 3 of one read lie 128 B apart with the halves of rows 2, 3 swapped: four different 64-byte bank segments.
+    const int vrow = (lane >> 2) & 3, vtr_swz = (vrow >> 1) << 6;
+    const int vtr_off = (4 * hh + vrow) * AT_VPITCH + (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+    auto at_tr = [](const unsigned char *p) -> bf16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3))) *)p);
     };
 
     stage_load(0);
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
             __syncthreads();
         }
         const unsigned char *kb_h = smem + (SB ? 0 : (t & 1)) * AT_BUF + r * AT_KPITCH + hh * 16;
-        const unsigned char *vt_h = smem + (SB ? 0 : (t & 1)) * AT_BUF + 2 * AT_KPLANE + r * AT_VPITCH + hh * 8;
+        const unsigned char *vt_h = smem + (SB ? 0 : (t & 1)) * AT_BUF + 2 * AT_KPLANE + vtr_off;
         // ---- S^T = K Q^T (log2 units): sacc[kb][g] = score(query r, key 32kb + (g&3) + 8(g>>2) + 4hh)
         f32x16 sacc[2];
 #pragma unroll
@@ -319,11 +334,11 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
             }
             // product-major: consecutive MFMAs alternate between the two accumulators (each still sums lo*hi, hi*lo, hi*hi in order)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[kb], qh[s], sacc[kb], 0, 0, 0);
+            for (int kb = 0; kb < 2; ++kb) sacc[kb] = AT_MFMA(kl[kb], qh[s], sacc[kb]);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kb], ql[s], sacc[kb], 0, 0, 0);
+            for (int kb = 0; kb < 2; ++kb) sacc[kb] = AT_MFMA(kh[kb], ql[s], sacc[kb]);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[kb], qh[s], sacc[kb], 0, 0, 0);
+            for (int kb = 0; kb < 2; ++kb) sacc[kb] = AT_MFMA(kh[kb], qh[s], sacc[kb]);
         }
         // the staged registers hold tile t+1: split + write it to the other buffer (its last reads ended before the barrier
         // that closed tile t-1), then re-issue the loads for tile t+2
@@ -332,6 +347,15 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
             stage_load(t + 2);
         }
 
+#if defined(SMK_ATT_ABLATE) && (SMK_ATT_ABLATE & 1)      // diagnostic: no softmax arithmetic (P = the scores' bits), same MFMAs and LDS traffic
+        bf16x8 ph[4], pl[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            ph[s4] = __builtin_bit_cast(bf16x8, f32x4_t{sacc[s4 >> 1][8 * (s4 & 1)], sacc[s4 >> 1][8 * (s4 & 1) + 1], sacc[s4 >> 1][8 * (s4 & 1) + 2], sacc[s4 >> 1][8 * (s4 & 1) + 3]});
+            pl[s4] = __builtin_bit_cast(bf16x8, f32x4_t{sacc[s4 >> 1][8 * (s4 & 1) + 4], sacc[s4 >> 1][8 * (s4 & 1) + 5], sacc[s4 >> 1][8 * (s4 & 1) + 6], sacc[s4 >> 1][8 * (s4 & 1) + 7]});
+        }
+        l_run = 1.f;
+#else
         // ---- online softmax (per lane: its query's 32 of the tile's 64 keys; lane ^ 32 holds the other 32)
         float mx = sacc[0][0];
 #pragma unroll
@@ -359,6 +383,7 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g = 0; g < 16; ++g) oacc[db][g] *= alpha;
+#endif
 
         // ---- O^T += V^T P: oacc[db][g] = O(query r, d 32db + (g&3) + 8(g>>2) + 4hh)
 #pragma unroll
@@ -366,18 +391,19 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
             bf16x8 vh[2], vl[2];
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const unsigned char *p0 = vt_h + db * 32 * AT_VPITCH + s4 * 32;          // keys 16 s4 + 4hh .. +3 | +8
-                const bf16x4 h0 = *reinterpret_cast<const bf16x4 *>(p0), h1 = *reinterpret_cast<const bf16x4 *>(p0 + 16);
-                const bf16x4 l0 = *reinterpret_cast<const bf16x4 *>(p0 + AT_VPLANE), l1 = *reinterpret_cast<const bf16x4 *>(p0 + AT_VPLANE + 16);
+                // keys 16 s4 + 4hh + q (and + 8), d 32 db + 16 (g16 & 1) + 4pp .. + 3 -> this lane: d 32 db + r, the four keys in order
+                const unsigned char *p0 = vt_h + s4 * 16 * AT_VPITCH + ((db << 6) ^ vtr_swz);
+                const bf16x4 h0 = at_tr(p0), h1 = at_tr(p0 + 8 * AT_VPITCH);
+                const bf16x4 l0 = at_tr(p0 + AT_VPLANE), l1 = at_tr(p0 + AT_VPLANE + 8 * AT_VPITCH);
                 vh[db] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                 vl[db] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[db], ph[s4], oacc[db], 0, 0, 0);
+            for (int db = 0; db < 2; ++db) oacc[db] = AT_MFMA(vl[db], ph[s4], oacc[db]);
 #pragma unroll
-            for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[db], pl[s4], oacc[db], 0, 0, 0);
+            for (int db = 0; db < 2; ++db) oacc[db] = AT_MFMA(vh[db], pl[s4], oacc[db]);
 #pragma unroll
-            for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[db], ph[s4], oacc[db], 0, 0, 0);
+            for (int db = 0; db < 2; ++db) oacc[db] = AT_MFMA(vh[db], ph[s4], oacc[db]);
         }
         __syncthreads();                                       // tile t+1 visible; every read of tile t's buffer has returned
     }

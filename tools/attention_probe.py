@@ -18,7 +18,10 @@ for B in (1, 4, 64):
     q, k, v = (torch.randn(B, L, D, device="cuda") for _ in range(3))
     out = torch.empty_like(q)
     t_hip = timeit(lambda: hip_attention(q, k, v, H, 0.125, out=out))
+    fl = 4.0 * B * H * L * L * 64
+    if len(sys.argv) > 1 and sys.argv[1] == "hip":          # (tools/att_ablate.sh: the HIP kernel only)
+        print(f"B={B:3d}: hip {t_hip*1e3:8.1f} us ({fl/t_hip/1e9:6.1f} TF/s counted)", flush=True)
+        continue
     q4, k4, v4 = (t.view(B, L, H, 64).transpose(1, 2) for t in (q, k, v))
     t_ref = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q4, k4, v4, scale=0.125).transpose(1, 2).reshape(B, L, D))
-    fl = 4.0 * B * H * L * L * 64
     print(f"B={B:3d}: hip {t_hip*1e3:8.1f} us ({fl/t_hip/1e9:6.1f} TF/s counted)   torch SDPA fp32 + merge-heads copy {t_ref*1e3:8.1f} us ({fl/t_ref/1e9:6.1f} TF/s)", flush=True)
