@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace smk {
 
@@ -1330,8 +1331,277 @@ __global__ __launch_bounds__(AF_THREADS) void k_advect_fused(Geom g, StateView i
     }
 }
 
+// ---- the same launch with wave-autonomous rows (round 4; the organisation of csrc/advect3d.hip's k3_advect_march, one plane) ------------
+// One advected value in the general form, every tap from GLOBAL memory: what a wave falls back to when a back-trace of its units leaves the
+// 2 x 2 LDS neighbourhood (never in the reference's regime).  A real call, so the hot code carries neither its registers nor its loads.
+// Field [Rf][Cf] (pitch `pitch`); (y, x) = the cell; ui, vi = the velocity samples already formed by the caller.
+__device__ __attribute__((noinline)) float far_value2(const float *f, int pitch, int Rf, int Cf, float dt, int y, int x, float ui, float vi) {
+    const float px = clampf((float)x - dt * ui, 0.f, (float)(Cf - 1));
+    const float py = clampf((float)y - dt * vi, 0.f, (float)(Rf - 1));
+    const int x0 = (int)px, y0 = (int)py;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x1 = x1 > Cf - 1 ? Cf - 1 : x1;
+    y1 = y1 > Rf - 1 ? Rf - 1 : y1;
+    const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
+    const float wa = (fx1 - px) * (fy1 - py);
+    const float wb = (px - fx0) * (fy1 - py);
+    const float wc = (fx1 - px) * (py - fy0);
+    const float wd = (px - fx0) * (py - fy0);
+    float r = wa * f[(size_t)y0 * pitch + x0] + wb * f[(size_t)y0 * pitch + x1];
+    r = r + wc * f[(size_t)y1 * pitch + x0];
+    r = r + wd * f[(size_t)y1 * pitch + x1];
+    return r;
+}
+
+// lane i <- lane i+1 of x; lane 63 <- `last` (DPP wave_shl:1 with the destination preloaded)
+__device__ __forceinline__ float shl1_with2(float x, float last) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+// dispatch id -> tile id such that each XCD (ids are dealt round-robin over 8) works through one contiguous range of tiles: the window
+// overlaps of neighbouring tiles are then hits in one L2 (speed only; a bijection on [0, n) for every n)
+__device__ __forceinline__ unsigned xcd_contiguous2(unsigned id, unsigned n) {
+    const unsigned c = id & 7u, q = n >> 3, r = n & 7u;
+    return c * q + (c < r ? c : r) + (id >> 3);
+}
+
+// Workgroup = NW waves = a (NW R) x 64 tile; u2, v2, d2 windows (tile + 1 low, + 2 high; every out-of-grid element holds the CLAMPED in-grid
+// value, which is exactly what bilinear()'s clamped indices read) staged once into LDS, ONE barrier.  A wave then owns R consecutive rows:
+// thread = column, the advected u and v of its rows (+ the next row) live in REGISTERS -- x + 1 comes from the next lane by DPP, lane 63's
+// from the extra-column unit by v_readlane -- so nothing separates the three fields (k_advect_fused: two more barriers and two LDS round
+// trips).  With |dt * velocity| < 1 cell a back-trace lands on floor(p) in {i-1, i}: four taps at immediate offsets from ONE LDS address;
+// the test is one wave-level vote per batch of units, the fall-back the general form per lane (far_value2).  EDGE = false is the same
+// arithmetic with the tests that cannot fail inside the grid removed (existence, the sampling rules' extents, the clamps: an unclamped
+// back-trace that would have needed its clamp fails the neighbourhood test).  Bit-identical to k_advect_fused.
+template <int R, int NW, int BU>
+__global__ __launch_bounds__(NW * 64) void k_advect_rows(Geom g, StateView in, StateView out, float *frames, int64_t fsb,
+                                                         const float *__restrict__ fractal, float fint) {
+    constexpr int TYR = R * NW, TXC = 64, NT = NW * 64;
+    constexpr int WR = TYR + 3, WC = TXC + 3, WP = 68, WPL = WR * WP;
+    constexpr int NST = (WR * WC + NT - 1) / NT;
+    __shared__ float U2s[WPL], V2s[WPL], D2s[WPL];
+    const int H = g.H, W = g.W, pc = g.pc, pv = g.pv;
+    const int ntx = (W + TXC - 1) / TXC, nty = (H + TYR - 1) / TYR;
+    unsigned tile = xcd_contiguous2(blockIdx.x, gridDim.x);
+    const int tix = tile % ntx; tile /= ntx;
+    const int tiy = tile % nty;
+    const int b = tile / nty;
+    const int x0 = tix * TXC, y0 = tiy * TYR;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *u2 = in.u + b * g.su, *v2 = in.v + b * g.sv, *d2 = in.d + b * g.sc;
+    float *uo = out.u + b * g.su, *vo = out.v + b * g.sv, *dn = out.d + b * g.sc;
+    float *fr = frames ? frames + (size_t)b * fsb : nullptr;
+    const float dt = g.dt;
+
+    // ---- stage the windows: every address clamped into its field (no load under a branch), all loads before the first LDS write
+    {
+        float ru[NST], rv[NST], rd[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int e0 = tid + it * NT, e = e0 < WR * WC ? e0 : WR * WC - 1;
+            const int r = e / WC, c = e - r * WC;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            const int yc = clampi(gy, 0, H - 1), xc = clampi(gx, 0, W - 1);
+            ru[it] = u2[(unsigned)(clampi(gy, 0, H) * pc + xc)];
+            rv[it] = v2[(unsigned)(yc * pv + clampi(gx, 0, W))];
+            rd[it] = d2[(unsigned)(yc * pc + xc)];
+        }
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int e0 = tid + it * NT;
+            const int r = e0 / WC, c = e0 - r * WC;
+            if (e0 < WR * WC) { U2s[r * WP + c] = ru[it]; V2s[r * WP + c] = rv[it]; D2s[r * WP + c] = rd[it]; }
+        }
+    }
+    __syncthreads();
+
+    const int rb = wv * R, yb = y0 + rb;                                  // this wave's rows: yb .. yb+R-1 (+ row yb+R for Un, Vn)
+    const int x = x0 + lane;
+    const float fxl = (float)x;
+    const int x4 = 4 * x;
+    auto stb = [&](float *rowbase, float v) {     // one value of this lane's column into a row (uniform base): descriptor base = the row
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), __builtin_amdgcn_make_buffer_rsrc(rowbase, 0, 0x7fffffff, 0x00020000), x4, 0, 0);
+    };
+    const int wbase = (rb + 1) * WP + lane + 1;                           // window index of (row yb, column x); + r WP for row yb + r
+    const int wex = (rb + 1 + (lane <= R ? lane : R)) * WP + TXC + 1;     // extra-column unit: lane = row, column x0 + TXC
+    const float fxe = (float)(x0 + TXC);
+    // is this wave's whole neighbourhood inside the grid?  (rows yb-1 .. yb+R+1 and columns x0-1 .. x0+TXC+1 exist in every field, the
+    // sampling rules hold on all its units, and no coordinate below 2: (int)NaN = 0 must fail the neighbourhood test)
+    const bool inner_w = yb >= 2 && yb + R + 1 <= H - 2 && x0 >= 2 && x0 + TXC + 1 <= W - 2;
+
+    struct Prep { float wx0, wx1, wy0, wy1; int a; };
+    // back-trace -> weights + the LDS address; returns "lands in the neighbourhood".  Field [Rf][Cf].
+    auto prep = [&](auto edge, int Rf, int Cf, int widx, int y, int xx, float fx, float ui, float vi, bool exists, Prep &P) -> bool {
+        constexpr bool EDGE = decltype(edge)::value;
+        float px = fx - dt * ui, py = (float)y - dt * vi;
+        if (EDGE) { px = clampf(px, 0.f, (float)(Cf - 1)); py = clampf(py, 0.f, (float)(Rf - 1)); }
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        float fx1 = fx0 + 1.f, fy1 = fy0 + 1.f;
+        if (EDGE) { fx1 = fminf(fx1, (float)(Cf - 1)); fy1 = fminf(fy1, (float)(Rf - 1)); }
+        P.wx0 = fx1 - px; P.wx1 = px - fx0; P.wy0 = fy1 - py; P.wy1 = py - fy0;
+        int rx = (int)fx0 - xx, ry = (int)fy0 - y;
+        bool fast = (unsigned)((rx + 1) | (ry + 1)) <= 1u;
+        if (EDGE && !exists) { rx = 0; ry = 0; fast = true; }             // a lane without a cell reads its own (in-window) slot; result unused
+        P.a = widx + ry * WP + rx;
+        return fast;
+    };
+    auto finish = [&](const float *win, const Prep &P) -> float {
+        const float t0 = win[P.a], t1 = win[P.a + 1], t2 = win[P.a + WP], t3 = win[P.a + WP + 1];
+        float acc = (P.wx0 * P.wy0) * t0 + (P.wx1 * P.wy0) * t1;
+        acc = acc + (P.wx0 * P.wy1) * t2;
+        acc = acc + (P.wx1 * P.wy1) * t3;
+        return acc;
+    };
+
+    float un[R + 1], unx[R + 1], vn[R + 1];
+    auto body = [&](auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
+        float ui[BU], vi[BU], val[BU];
+        Prep P[BU];
+        bool ex[BU];
+        // ---------------- Un: units 0 .. R = rows yb .. yb+R at column x; unit R+1 = the tile's extra column x0 + TXC (lane = row).  u is [H+1][W]
+        float uex = 0.f;
+#pragma unroll
+        for (int b0 = 0; b0 <= R + 1; b0 += BU) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int r = b0 + j;
+                if (r > R + 1) continue;
+                const bool xt = r == R + 1;
+                const int y = xt ? yb + lane : yb + r, xx = xt ? x0 + TXC : x, w0 = xt ? wex : wbase + r * WP;
+                const float a = 0.5f * U2s[w0] + 0.5f * U2s[w0 + 1];
+                const float c = 0.5f * V2s[w0] + 0.5f * V2s[w0 + WP];
+                ex[j] = (!EDGE && !xt) || ((!xt || lane <= R) && y <= H && xx <= W - 1);
+                ui[j] = ((!EDGE && !xt) || (y <= H - 1 && xx <= W - 2)) ? a : 0.f;
+                vi[j] = ((!EDGE && !xt) || y <= H - 2) ? c : 0.f;
+                if (xt) ok &= prep(std::true_type{}, H + 1, W, w0, y, xx, fxe, ui[j], vi[j], ex[j], P[j]);
+                else ok &= prep(edge, H + 1, W, w0, y, xx, fxl, ui[j], vi[j], ex[j], P[j]);
+            }
+            if (__builtin_expect(__all(ok), 1)) {
+#pragma unroll
+                for (int j = 0; j < BU; ++j)
+                    if (b0 + j <= R + 1) val[j] = finish(U2s, P[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < BU; ++j) {
+                    const int r = b0 + j;
+                    if (r > R + 1) continue;
+                    const bool xt = r == R + 1;
+                    val[j] = ex[j] ? far_value2(u2, pc, H + 1, W, dt, xt ? yb + lane : yb + r, xt ? x0 + TXC : x, ui[j], vi[j]) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int r = b0 + j;
+                if (r > R + 1) continue;
+                if (r == R + 1) { uex = val[j]; continue; }
+                un[r] = val[j];
+                const int y = yb + r;
+                if ((r < R || (EDGE && y == H)) && ex[j]) stb(uo + (size_t)y * pc, val[j]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r <= R; ++r)                                       // Un at x + 1: the next lane's, lane 63 takes the extra column's row r
+            unx[r] = shl1_with2(un[r], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uex), r)));
+        // ---------------- Vn: rows 0 .. R.  v is [H][W+1] (x = W of a narrower last tile is one of these lanes)
+#pragma unroll
+        for (int b0 = 0; b0 <= R; b0 += BU) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int r = b0 + j;
+                if (r > R) continue;
+                const int y = yb + r, w0 = wbase + r * WP;
+                const float a = 0.5f * un[r] + 0.5f * unx[r];
+                const float c = 0.5f * V2s[w0] + 0.5f * V2s[w0 + WP];
+                ex[j] = !EDGE || (y <= H - 1 && x <= W);
+                ui[j] = (!EDGE || x <= W - 2) ? a : 0.f;
+                vi[j] = (!EDGE || (y <= H - 2 && x <= W - 1)) ? c : 0.f;
+                ok &= prep(edge, H, W + 1, w0, y, x, fxl, ui[j], vi[j], ex[j], P[j]);
+            }
+            if (__builtin_expect(__all(ok), 1)) {
+#pragma unroll
+                for (int j = 0; j < BU; ++j)
+                    if (b0 + j <= R) val[j] = finish(V2s, P[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < BU; ++j)
+                    if (b0 + j <= R) val[j] = ex[j] ? far_value2(v2, pv, H, W + 1, dt, yb + b0 + j, x, ui[j], vi[j]) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int r = b0 + j;
+                if (r > R) continue;
+                vn[r] = val[j];
+                if (r < R && ex[j]) stb(vo + (size_t)(yb + r) * pv, val[j]);
+            }
+        }
+        if (EDGE && x0 + TXC == W) {                                       // the field's own extra column x = W (lane = row, rows 0 .. R-1)
+            const int y = yb + lane;
+            if (lane < R && y <= H - 1)                                    // (ui needs x <= W-2, vi x <= W-1: both zero)
+                vo[(unsigned)(y * pv + W)] = far_value2(v2, pv, H, W + 1, dt, y, W, 0.f, 0.f);
+        }
+        // ---------------- density: rows 0 .. R-1 (+ decay, frame)
+#pragma unroll
+        for (int b0 = 0; b0 < R; b0 += BU) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int r = b0 + j;
+                if (r >= R) continue;
+                const int y = yb + r, w0 = wbase + r * WP;
+                const float a = 0.5f * un[r] + 0.5f * unx[r];
+                const float c = 0.5f * vn[r] + 0.5f * vn[r + 1];
+                ex[j] = !EDGE || (y <= H - 1 && x <= W - 1);
+                ui[j] = (!EDGE || x <= W - 2) ? a : 0.f;
+                vi[j] = (!EDGE || y <= H - 2) ? c : 0.f;
+                ok &= prep(edge, H, W, w0, y, x, fxl, ui[j], vi[j], ex[j], P[j]);
+            }
+            if (__builtin_expect(__all(ok), 1)) {
+#pragma unroll
+                for (int j = 0; j < BU; ++j)
+                    if (b0 + j < R) val[j] = finish(D2s, P[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < BU; ++j)
+                    if (b0 + j < R) val[j] = ex[j] ? far_value2(d2, pc, H, W, dt, yb + b0 + j, x, ui[j], vi[j]) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int r = b0 + j;
+                if (r >= R) continue;
+                const int y = yb + r;
+                if (!ex[j]) continue;
+                const float v = val[j] * 0.995f;                              // :171
+                if (fr) {
+                    float f = v;
+                    if (fractal) {                                            // fractal_generator.py:62 (F is [W][H], square)
+                        float t = fint * fractal[(unsigned)(y * W + x)];
+                        t = t * v;
+                        f = v + t;
+                    }
+                    stb(fr + (size_t)y * W, f);
+                }
+                stb(dn + (size_t)y * pc, v);
+            }
+        }
+    };
+    if (inner_w) body(std::false_type{});
+    else body(std::true_type{});
+}
+
 hipError_t launch_advect_fused(const Geom &g, StateView in, StateView out, float *frames, int64_t fsb, const float *fractal, float fint,
                                hipStream_t st) {
+    static int rows_env = -1;            // SMK_ADVECT_ROWS=0: round 2's k_advect_fused (A/B runs)
+    if (rows_env < 0) { const char *sv = getenv("SMK_ADVECT_ROWS"); rows_env = sv ? atoi(sv) : 1; }
+    if (rows_env) {
+        // R x NW = 8 x 4 rows per workgroup (measured at configs[2] against 4 x 4, 4 x 8, 8 x 8, 16 x 2 rows and batches of 5 units: equal within
+        // noise except 16 x 2, +7 %)
+        constexpr int R = 8, NW = 4;
+        const long long n = (long long)cdiv(g.W, 64) * cdiv(g.H, R * NW) * g.B;
+        hipLaunchKernelGGL((k_advect_rows<R, NW, 3>), dim3((unsigned)n), dim3(NW * 64), 0, st, g, in, out, frames, fsb, fractal, fint);
+        return hipGetLastError();
+    }
     dim3 grid(cdiv(g.W, AF_TW), cdiv(g.H, AF_TH), g.B), block(AF_THREADS);
     hipLaunchKernelGGL(k_advect_fused, grid, block, 0, st, g, in, out, frames, fsb, fractal, fint);
     return hipGetLastError();

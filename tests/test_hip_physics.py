@@ -174,6 +174,42 @@ def test_band_plans_at_other_shapes_and_sweep_counts_equal_the_oracle(H, W, J):
             np.testing.assert_array_equal(getattr(sim.ns_solver, k)[b].cpu().numpy(), getattr(o.ns_solver, k), err_msg=k)
 
 
+@pytest.mark.parametrize("H,W,vel,J", [(45, 70, 0.5, 6), (45, 70, 300.0, 6), (32, 64, 150.0, 4), (96, 192, 40.0, 8), (96, 192, 400.0, 8),
+                                       (67, 129, 2.0, 5), (40, 128, 90.0, 3), (64, 64, 120.0, 5)])
+def test_whole_steps_from_dense_random_states_bit_exact_vs_oracle(H, W, vel, J):
+    """smk_sim_step from DENSE random states (every cell moves) of two grids, two steps, against the oracle's step().  vel 0.5-40: every
+    back-trace of the one-launch advection (k_advect_rows) stays in its 2 x 2 LDS neighbourhood, with non-zero weights everywhere; vel
+    90-400: dt * velocity reaches several cells, so whole batches of units leave through far_value2 (the general form on global memory)
+    while others of the same launch stay on the fast form, and the clamps at the field's edges bind.  Shapes: odd everything; exactly one
+    tile; three x-tiles; a 1-wide last tile with rows that do not fill the last wave; W = two full tiles (the field's extra column of v is
+    then the last tile's own unit); a square grid with the fractal multiplier on the emitted frame."""
+    B = 2
+    sim = SmokeSimulator((H, W), batch_size=B, jacobi_iters=J)
+    orcs = []
+    for b in range(B):
+        rng = np.random.RandomState(1000 * H + W + b)
+        o = oracle.OracleSmokeSimulator((H, W), jacobi_iters=J)
+        o.ns_solver.u = (rng.standard_normal((H + 1, W)) * vel).astype(np.float32)
+        o.ns_solver.v = (rng.standard_normal((H, W + 1)) * vel).astype(np.float32)
+        o.ns_solver.p = (rng.standard_normal((H, W)) * 0.1).astype(np.float32)
+        o.ns_solver.density = rng.uniform(0.0, 1.8, (H, W)).astype(np.float32)
+        orcs.append(o)
+    for k in KEYS:
+        setattr(sim.ns_solver, k, torch.from_numpy(np.stack([getattr(o.ns_solver, k) for o in orcs])))
+    steps, fractal = 2, H == W                                         # (the fractal field is defined for square grids only)
+    frames = sim.simulate_sequence(steps, add_fractal=fractal).cpu().numpy()
+    for b, o in enumerate(orcs):
+        for t in range(steps):
+            want = o.simulate_step(add_fractal=fractal)
+            if fractal:      # the multiplier's perlin term is a sin / cos sum: <= 2e-6 from the oracle's (test_fractal_constants), not bit-equal
+                np.testing.assert_allclose(frames[b, t], want, rtol=1e-6, atol=0, err_msg=f"grid {b} step {t}")
+            else:
+                np.testing.assert_array_equal(frames[b, t], want, err_msg=f"grid {b} step {t}")
+        for k in KEYS:
+            np.testing.assert_array_equal(getattr(sim.ns_solver, k)[b].cpu().numpy(), getattr(o.ns_solver, k), err_msg=f"grid {b} {k}")
+        assert np.isfinite(o.ns_solver.density).all() and np.abs(o.ns_solver.u).max() > 0
+
+
 @pytest.mark.parametrize("N", [64, 128, 256])
 def test_fractal_constants(golden, N):
     g = golden(f"fractal_{N}.npz")
