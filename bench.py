@@ -630,6 +630,11 @@ def main(argv=None):
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run):
         raise SystemExit(self_launch(args, argv))
 
+    # the train-step leg's MIOpen convolutions (the reconstruction head): a find-db of the bench's own, so that entries another run left in
+    # the account's (a deterministic run's restricted solvers: smokephysai_amd/utils/miopen_db.py) cannot slow the measured step
+    from smokephysai_amd.utils.miopen_db import use_private_find_db
+    use_private_find_db("smokephys_bench")
+
     # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL prints a five-line version banner when a
     # process group is created), so fd 1 is pointed at stderr for the life of the process and the line goes to a duplicate of the real stdout
     sys.stdout.flush()

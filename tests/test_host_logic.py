@@ -388,3 +388,15 @@ def test_forced_one_rank_group_wraps_and_changes_nothing(tmp_path):
     mp.spawn(_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
     res = torch.load(out)
     assert torch.equal(res["rccl"], res["bare"]) and torch.equal(res["direct"], res["bare"]) and float(res["bare"].abs().sum()) > 0
+
+
+def test_private_miopen_find_db(tmp_path, monkeypatch):
+    """utils/miopen_db.py: a purpose-named find-db directory unless the user already chose one (deterministic runs must not share the
+    account's ordinary find-db: the entries they write slow every later run)."""
+    from smokephysai_amd.utils.miopen_db import use_private_find_db
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    d = use_private_find_db("deterministic")
+    assert d == os.path.join(str(tmp_path), ".config", "miopen_deterministic") and os.path.isdir(d) and os.environ["MIOPEN_USER_DB_PATH"] == d
+    assert use_private_find_db("smokephys_bench") == d                     # already set: the first choice stands
+    assert use_private_find_db("smokephys_bench", force=True).endswith("miopen_smokephys_bench")

@@ -14,6 +14,7 @@ so the test asserts equality and nothing weaker."""
 import json
 import os
 import subprocess
+import tempfile
 import sys
 
 import pytest
@@ -93,7 +94,10 @@ def _env():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
     env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
-                "HSA_ENABLE_IPC_MODE_LEGACY": "0", "SMK_JACOBI_PERSIST": "1"})
+                "HSA_ENABLE_IPC_MODE_LEGACY": "0", "SMK_JACOBI_PERSIST": "1",
+                # the child runs MIOpen restricted to deterministic solvers: what it finds must not land in the account's find-db, where an
+                # ordinary run (bench.py's train-step leg) would reuse it -- 60 -> 485 ms per step (smokephysai_amd/utils/miopen_db.py)
+                "MIOPEN_USER_DB_PATH": tempfile.mkdtemp(prefix="miopen_det_")})
     return env
 
 

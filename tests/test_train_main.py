@@ -26,11 +26,15 @@ def test_main_trains_validates_and_writes_a_reference_schema_checkpoint(tmp_path
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.pop("MIOPEN_USER_DB_PATH", None)        # train.py itself must move a deterministic run's find-db out of the account's (checked below)
+    env["HOME"] = str(tmp_path)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--config", str(path)], cwd=tmp_path, env=env,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     out = r.stdout
     assert "Using device: cuda:0" in out and "Training completed!" in out
+    # mi355x.deterministic restricts MIOpen's solvers: its find results went to a find-db of their own (utils/miopen_db.py), not ~/.config/miopen
+    assert os.path.isdir(tmp_path / ".config" / "miopen_deterministic") and not os.path.exists(tmp_path / ".config" / "miopen")
     for e in (1, 2):
         assert f"Epoch {e}/2" in out
     assert out.count("Train Loss:") == 2 and out.count("Val Loss:") == 2 and out.count("Learning Rate:") == 2   # train.py:262-265

@@ -21,6 +21,9 @@ from smokephysai_amd.utils.distributed import DirectExchangeState, direct_exchan
 
 
 def main():
+    if os.environ.get("SMK_DIAG_DETERMINISTIC") == "1" or os.environ.get("SMK_DIAG_CUDNN_DET") == "1":
+        from smokephysai_amd.utils.miopen_db import use_private_find_db
+        use_private_find_db("deterministic")          # keep the restricted solvers' find results out of the ordinary find-db
     init_distributed("nccl", force=True)
     dev = torch.device("cuda", 0)
     if os.environ.get("SMK_DIAG_DETERMINISTIC") == "1":

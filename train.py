@@ -151,6 +151,10 @@ def main():
         # deterministic solvers.  Every libsmokehip kernel is deterministic either way.
         torch.backends.cudnn.deterministic = True
         torch.backends.cudnn.benchmark = False
+        # ... and keeps what MIOpen finds under that restriction out of the account's ordinary find-db (utils/miopen_db.py: a later
+        # non-deterministic run would reuse the slow entries: 60 -> 485 ms per step measured)
+        from smokephysai_amd.utils.miopen_db import use_private_find_db
+        use_private_find_db("deterministic")
     rank, world, local_rank = init_distributed()
     exp_dir, writer, device = setup_experiment(config, rank, local_rank)
 
