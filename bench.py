@@ -451,10 +451,14 @@ def train_step_leg(dev, N, B, dist, world, backend, steps=4, res=None, force_dis
         return el / n * 1e3
 
     res["stage"] = "warm-up steps"
-    for _ in range(2):
+    for _ in range(3):
         step()
     res["stage"] = "timed steps"
-    ms = timed(steps)
+    # two blocks of `steps`; the lower one is the step's time (a block that contains a one-off stall -- the allocator growing, DDP's bucket
+    # rebuild after its first iterations: +25 ms per step measured on one run in three -- is not the steady state); both are reported
+    blocks = [timed(steps), timed(steps)]
+    ms = min(blocks)
+    res["ms_per_step_blocks"] = blocks
     nparam = sum(p.numel() for p in model.parameters())
     exchanged = dist is not None
     res.update({"ms_per_step": ms, "frames_per_s": world * B / (ms * 1e-3), "batch_per_gpu": B, "global_batch": world * B, "grid": N,
