@@ -8,7 +8,7 @@ from smokephysai_amd.physics import NavierStokesSimulator3D
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dev = torch.device("cuda", 0)
-B, D, H, W, J = 8, 64, 512, 512, 20
+B, D, H, W, J = int(os.environ.get("SMK_SIM3D_B", "8")), 64, 512, 512, 20          # SMK_SIM3D_B: fewer grids (is one grid's projection Infinity-Cache resident?)
 sim = NavierStokesSimulator3D((D, H, W), device=dev, batch_size=B, jacobi_iters=J)
 rng = np.random.RandomState(4)
 sim.add_smoke_sources([(b, int(rng.randint(40, W - 40)), int(rng.randint(40, H - 40)), int(rng.randint(10, D - 10)), 8,
