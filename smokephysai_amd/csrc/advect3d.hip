@@ -72,11 +72,6 @@ __device__ __attribute__((noinline)) float far_value3(const float *f, const floa
     return acc;
 }
 
-// lane i <- lane i+1 of x; lane 63 <- `last` (DPP wave_shl:1 with the destination preloaded)
-__device__ __forceinline__ float shl1_with(float x, float last) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
-}
-
 // One wave = R consecutive rows of a 64-column tile; the workgroup's NW waves stack their rows (tile = NW R x 64) and share the input rings.
 // Within a plane a wave runs Un (its rows + the next one + the tile's extra column), Vn (rows + 1), Wn, then Dn of the previous plane;
 // what the later fields sample of the earlier ones stays in REGISTERS (thread = column: rows are register arrays, x + 1 comes from the

@@ -44,6 +44,19 @@ struct StateView {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- device helpers shared by the stencil kernel files
+// Workgroups are dealt round-robin over the 8 XCDs (ids i and i + 8 share an XCD and its 4 MiB L2: MI355X_MICROARCH.md, speed only).  A
+// kernel whose tiles overlap (halos) or read each other's edge lines wants NEIGHBOURING tiles on one XCD: this maps the dispatch id to a
+// logical tile id such that XCD c works through one contiguous range of tiles, in order.  A bijection on [0, n) for every n.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned id, unsigned n) {
+    const unsigned c = id & 7u, q = n >> 3, r = n & 7u;
+    return c * q + (c < r ? c : r) + (id >> 3);
+}
+// lane i <- lane i+1 of x; lane 63 <- `last` (DPP wave_shl:1 with the destination preloaded)
+__device__ __forceinline__ float shl1_with(float x, float last) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+
 // Launch-time state is PER DEVICE (a process may hold handles on several GPUs): the CU count, and "has this kernel's dynamic-LDS
 // limit been raised / what did the occupancy query say" keyed by (kernel, current device).  Thread-safe (api.hip).
 int device_num_cu();                                         // CUs of the CURRENT device (cached)

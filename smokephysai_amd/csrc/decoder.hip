@@ -176,16 +176,21 @@ __global__ __launch_bounds__(256) void k_convt4s2_small(const float *__restrict_
     *reinterpret_cast<float2 *>(op + OW) = make_float2(v2 > 0.f ? v2 : 0.f, v3 > 0.f ? v3 : 0.f);
 }
 
-// Conv2d(16, 1, 3, padding 1) + Sigmoid: thread = one output pixel
+// Conv2d(16, 1, 3, padding 1) + Sigmoid: thread = one output pixel of a TH x TW tile (TH TW = 256).  8 x 32 tiles: the 32 lanes of one LDS
+// access group read 32 consecutive floats of ONE row (conflict-free at any pitch); with 16 x 16 tiles a group spans two rows 19 floats apart
+// and three banks collide (SQ_LDS_BANK_CONFLICT was half of the kernel's LDS cycles, profiles/r03/inference_b64_pmc_sq.json).
+template <int TH, int TW>
 __global__ __launch_bounds__(256) void k_conv3_sigmoid(const float *__restrict__ in, const float *__restrict__ w3, const float *__restrict__ b3,
                                                       float *__restrict__ out, int H, int W) {
-    __shared__ float tile[16][DC_T + 2][DC_PW];
-    const int tid = threadIdx.x, tj = tid & 15, ti = tid >> 4;
-    const int tiles_x = W / DC_T;
-    const int i0 = (blockIdx.x / tiles_x) * DC_T, j0 = (blockIdx.x % tiles_x) * DC_T, b = blockIdx.z;
+    static_assert(TH * TW == 256, "one thread per output pixel");
+    constexpr int PW = TW + 3;
+    __shared__ float tile[16][TH + 2][PW];
+    const int tid = threadIdx.x, tj = tid % TW, ti = tid / TW;
+    const int tiles_x = W / TW;
+    const int i0 = (blockIdx.x / tiles_x) * TH, j0 = (blockIdx.x % tiles_x) * TW, b = blockIdx.z;
     const float *inb = in + (size_t)b * 16 * H * W;
-    for (int e = tid; e < 16 * (DC_T + 2) * (DC_T + 2); e += 256) {
-        const int pc = e % (DC_T + 2), rest = e / (DC_T + 2), pr = rest % (DC_T + 2), c = rest / (DC_T + 2);
+    for (int e = tid; e < 16 * (TH + 2) * (TW + 2); e += 256) {
+        const int pc = e % (TW + 2), rest = e / (TW + 2), pr = rest % (TH + 2), c = rest / (TH + 2);
         const int ii = i0 - 1 + pr, jj = j0 - 1 + pc;
         tile[c][pr][pc] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? inb[((size_t)c * H + ii) * W + jj] : 0.f;
     }
@@ -219,7 +224,8 @@ hipError_t launch_decoder(const DecoderDev &d, const float *tokens, int B, int S
     }
     // (a no-LDS form of the last convolution for small batches -- every thread its 144 taps from L1 / L2 -- was built and measured 20 us
     //  SLOWER per batch-1 forward, interleaved on one box; removed)
-    hipLaunchKernelGGL(k_conv3_sigmoid, dim3(t3, 1, B), dim3(256), 0, st, tmp2, d.w3, d.b3, recon, 4 * S, 4 * S);
+    if ((4 * S) % 32 == 0) hipLaunchKernelGGL((k_conv3_sigmoid<8, 32>), dim3(t3, 1, B), dim3(256), 0, st, tmp2, d.w3, d.b3, recon, 4 * S, 4 * S);
+    else hipLaunchKernelGGL((k_conv3_sigmoid<DC_T, DC_T>), dim3(t3, 1, B), dim3(256), 0, st, tmp2, d.w3, d.b3, recon, 4 * S, 4 * S);
     return hipGetLastError();
 }
 

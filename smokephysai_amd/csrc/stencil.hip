@@ -1353,16 +1353,6 @@ __device__ __attribute__((noinline)) float far_value2(const float *f, int pitch,
     return r;
 }
 
-// lane i <- lane i+1 of x; lane 63 <- `last` (DPP wave_shl:1 with the destination preloaded)
-__device__ __forceinline__ float shl1_with2(float x, float last) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
-}
-// dispatch id -> tile id such that each XCD (ids are dealt round-robin over 8) works through one contiguous range of tiles: the window
-// overlaps of neighbouring tiles are then hits in one L2 (speed only; a bijection on [0, n) for every n)
-__device__ __forceinline__ unsigned xcd_contiguous2(unsigned id, unsigned n) {
-    const unsigned c = id & 7u, q = n >> 3, r = n & 7u;
-    return c * q + (c < r ? c : r) + (id >> 3);
-}
 
 // Workgroup = NW waves = a (NW R) x 64 tile; u2, v2, d2 windows (tile + 1 low, + 2 high; every out-of-grid element holds the CLAMPED in-grid
 // value, which is exactly what bilinear()'s clamped indices read) staged once into LDS, ONE barrier.  A wave then owns R consecutive rows:
@@ -1381,7 +1371,7 @@ __global__ __launch_bounds__(NW * 64) void k_advect_rows(Geom g, StateView in, S
     __shared__ float U2s[WPL], V2s[WPL], D2s[WPL];
     const int H = g.H, W = g.W, pc = g.pc, pv = g.pv;
     const int ntx = (W + TXC - 1) / TXC, nty = (H + TYR - 1) / TYR;
-    unsigned tile = xcd_contiguous2(blockIdx.x, gridDim.x);
+    unsigned tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tix = tile % ntx; tile /= ntx;
     const int tiy = tile % nty;
     const int b = tile / nty;
@@ -1502,7 +1492,7 @@ __global__ __launch_bounds__(NW * 64) void k_advect_rows(Geom g, StateView in, S
         }
 #pragma unroll
         for (int r = 0; r <= R; ++r)                                       // Un at x + 1: the next lane's, lane 63 takes the extra column's row r
-            unx[r] = shl1_with2(un[r], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uex), r)));
+            unx[r] = shl1_with(un[r], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uex), r)));
         // ---------------- Vn: rows 0 .. R.  v is [H][W+1] (x = W of a narrower last tile is one of these lanes)
 #pragma unroll
         for (int b0 = 0; b0 <= R; b0 += BU) {

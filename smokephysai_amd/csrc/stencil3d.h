@@ -47,12 +47,5 @@ __device__ __forceinline__ int clampi3(int x, int lo, int hi) {
     int t = x < lo ? lo : x;
     return t > hi ? hi : t;
 }
-// Workgroups are dealt round-robin over the 8 XCDs (ids i and i + 8 share an XCD and its 4 MiB L2: MI355X_MICROARCH.md, speed only).  A tile
-// kernel whose tiles overlap (halos) or read each other's edge lines wants NEIGHBOURING tiles on one XCD: this maps the dispatch id to a
-// logical tile id such that XCD c works through one contiguous range of tiles, in order.  A bijection on [0, n) for every n.
-__device__ __forceinline__ unsigned xcd_contiguous(unsigned id, unsigned n) {
-    const unsigned c = id & 7u, q = n >> 3, r = n & 7u;
-    return c * q + (c < r ? c : r) + (id >> 3);
-}
 
 }  // namespace smk
