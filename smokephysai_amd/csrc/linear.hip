@@ -1069,7 +1069,9 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
     a.stamps = nullptr;
     if (c.ln_wsum) {   // LayerNorm fused in front (k_linear_x3<.., LNF>): the tile shapes of the plain layer
         if (c.x_split || c.y_split || c.nseg != 1 || c.res || (c.padd && c.rows_per_group % 32 != 0)) return hipErrorInvalidValue;
-        int nwl = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) >= num_cu) ? 8 : 4;
+        // 128 x 256 tiles (k_linear_b16<8>) from three quarters of a round on: the q | k | v layer at batch 4 is 192 such tiles -- ONE round on 75 %
+        // of the CUs, 34 us -- against three rounds of 64 x 128 tiles on k_linear_x3, 40 us (measured: 1.160 -> 1.111 ms per batch-4 forward)
+        int nwl = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) * 4 >= 3LL * num_cu) ? 8 : 4;
         if (force_nw == 4 || force_nw == 8) nwl = force_nw;
         int mbl = 4;
         while (mbl > 1 && (long long)cdiv(c.M, 32 * mbl) * cdiv(l.N, nwl * 32) < (nwl == 8 ? 1LL : 2LL) * num_cu) mbl >>= 1;
