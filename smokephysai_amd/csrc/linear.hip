@@ -1074,7 +1074,8 @@ hipError_t launch_linear_x3(const LinearDev &l, const LinearCall &c, hipStream_t
         int nwl = (l.N >= 256 && (long long)cdiv(c.M, 128) * cdiv(l.N, 256) * 4 >= 3LL * num_cu) ? 8 : 4;
         if (force_nw == 4 || force_nw == 8) nwl = force_nw;
         int mbl = 4;
-        while (mbl > 1 && (long long)cdiv(c.M, 32 * mbl) * cdiv(l.N, nwl * 32) < (nwl == 8 ? 1LL : 2LL) * num_cu) mbl >>= 1;
+        // (the 8-wave form is built for 128-row tiles: chosen above, it keeps them)
+        while (nwl != 8 && mbl > 1 && (long long)cdiv(c.M, 32 * mbl) * cdiv(l.N, nwl * 32) < 2LL * num_cu) mbl >>= 1;
         if (force_mb == 1 || force_mb == 2 || force_mb == 4) mbl = force_mb;
         if (nwl == 8 && (mbl != 4 || (c.padd && c.rows_per_group % 128 != 0))) { nwl = 4; }
         while (c.padd && mbl > 1 && c.rows_per_group % (32 * mbl) != 0) mbl >>= 1;
