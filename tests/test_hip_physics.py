@@ -175,14 +175,15 @@ def test_band_plans_at_other_shapes_and_sweep_counts_equal_the_oracle(H, W, J):
 
 
 @pytest.mark.parametrize("H,W,vel,J", [(45, 70, 0.5, 6), (45, 70, 300.0, 6), (32, 64, 150.0, 4), (96, 192, 40.0, 8), (96, 192, 400.0, 8),
-                                       (67, 129, 2.0, 5), (40, 128, 90.0, 3), (64, 64, 120.0, 5)])
+                                       (67, 129, 2.0, 5), (40, 128, 90.0, 3), (64, 64, 120.0, 5), (31, 63, 60.0, 3), (33, 65, 60.0, 3), (8, 200, 0.5, 2), (130, 66, 130.0, 2)])
 def test_whole_steps_from_dense_random_states_bit_exact_vs_oracle(H, W, vel, J):
     """smk_sim_step from DENSE random states (every cell moves) of two grids, two steps, against the oracle's step().  vel 0.5-40: every
     back-trace of the one-launch advection (k_advect_rows) stays in its 2 x 2 LDS neighbourhood, with non-zero weights everywhere; vel
     90-400: dt * velocity reaches several cells, so whole batches of units leave through far_value2 (the general form on global memory)
     while others of the same launch stay on the fast form, and the clamps at the field's edges bind.  Shapes: odd everything; exactly one
     tile; three x-tiles; a 1-wide last tile with rows that do not fill the last wave; W = two full tiles (the field's extra column of v is
-    then the last tile's own unit); a square grid with the fractal multiplier on the emitted frame."""
+    then the last tile's own unit); a square grid with the fractal multiplier on the emitted frame; one column short of a tile, one column over it (a 1-wide
+    second tile whose only lane is also v's extra column), fewer rows than one wave owns, five tile rows with a 2-row last one."""
     B = 2
     sim = SmokeSimulator((H, W), batch_size=B, jacobi_iters=J)
     orcs = []
