@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMK_ABI_VERSION 16
+#define SMK_ABI_VERSION 17
 
 typedef enum smk_status {
     SMK_OK = 0,
@@ -263,8 +263,12 @@ int smk_encoder_conv1(smk_encoder *enc, const float *frames, int64_t frame_strid
  * element (x = hi + lo) in the layout the MFMA kernels consume: per row, per group of 8 consecutive features, 8 hi then
  * 8 lo ([rows][features/8][2][8] bf16 -- the same 4 bytes per element as fp32, rows dense).  A producer that writes it
  * (LayerNorm, a linear layer's epilogue, the attention kernel) saves the consuming linear layer the split arithmetic in
- * its K loop. */
-typedef enum smk_format { SMK_FMT_F32 = 0, SMK_FMT_SPLIT_BF16 = 1 } smk_format;
+ * its K loop.
+ * SMK_FMT_SPLIT4_INPLACE (round 4) is the same pair of bf16 per element laid into the fp32 tensor's own storage: every aligned group
+ * of 4 consecutive features holds {hi[0..3], lo[0..3]} in the 16 bytes of its 4 floats (any row pitch, any column range of a row).  The
+ * fused q | k | v layer writes its k and v columns that way (smk_linear_forward_ln_split) and the attention kernel stages them without
+ * split arithmetic (smk_attention_kv): the split is done once per element instead of once per 128-query block. */
+typedef enum smk_format { SMK_FMT_F32 = 0, SMK_FMT_SPLIT_BF16 = 1, SMK_FMT_SPLIT4_INPLACE = 2 } smk_format;
 
 typedef struct smk_linear smk_linear;
 typedef enum smk_activation { SMK_ACT_NONE = 0, SMK_ACT_GELU = 1 /* erf form, nn.GELU() */, SMK_ACT_RELU = 2 } smk_activation;
@@ -317,6 +321,12 @@ int smk_linear_forward(smk_linear *lin, const void *x, int64_t rows, int64_t ldx
 int64_t smk_linear_ln_max_rows(smk_linear *lin);
 int smk_linear_forward_ln(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy, const float *wsum, double eps,
                           const float *periodic_add, int32_t rows_per_group, int32_t period, int32_t activation, void *stream);
+/* The same launch with the output columns >= split_from_col (a multiple of 32, below out_features; negative: none) written as
+ * SMK_FMT_SPLIT4_INPLACE instead of fp32 -- the k | v columns of the fused q | k | v projection (smokephys_net.py:161,
+ * chaos_attention.py:77-79), consumed by smk_attention_kv. */
+int smk_linear_forward_ln_split(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy, const float *wsum, double eps,
+                                const float *periodic_add, int32_t rows_per_group, int32_t period, int32_t activation, int32_t split_from_col,
+                                void *stream);
 
 /* Conv3d(64 -> N, kernel 3, padding 1) + bias + activation as an IMPLICIT GEMM on the split-bf16 MFMA layer kernel -- no patch matrix:
  * src [D][H][W][64] fp32 channels-last, `lin` a layer handle with in_features = 27 * 64 whose weight columns are tap * 64 + c
@@ -473,6 +483,11 @@ int smk_attention(const float *q, const float *k, const float *v, void *out, int
 int64_t smk_attention_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t head_dim);
 int smk_attention_ws(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
                      int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+/* smk_attention_ws with k and v in kv_format = SMK_FMT_F32 or SMK_FMT_SPLIT4_INPLACE (same pointers, pitches and column convention; the
+ * values the kernel multiplies are bit for bit those it would have formed from the fp32 k and v, so the output is identical). */
+int smk_attention_kv(const float *q, const void *k, const void *v, void *out, int32_t B, int32_t L, int32_t H,
+                     int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format, int32_t kv_format,
                      void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Training form of smk_attention (chaos_attention.py:102-112 under autograd, train.py:88-89): the same forward with fp32 output,

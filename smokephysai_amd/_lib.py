@@ -7,11 +7,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMOKEHIP_LIB") or os.path.join(_HERE, "libsmokehip.so")   # SMOKEHIP_LIB: diagnostic builds only
 
-ABI_VERSION = 16                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
+ABI_VERSION = 17                 # include/smokehip.h SMK_ABI_VERSION this binding was written against (tests/test_abi.py holds them equal)
 SMK_ERR_TIMEOUT = -5
 SMK_F32, SMK_BF16X3, SMK_BF16, SMK_I8X3 = 0, 1, 2, 3
 SMK_ACT_NONE, SMK_ACT_GELU, SMK_ACT_RELU = 0, 1, 2
-SMK_FMT_F32, SMK_FMT_SPLIT_BF16 = 0, 1
+SMK_FMT_F32, SMK_FMT_SPLIT_BF16, SMK_FMT_SPLIT4_INPLACE = 0, 1, 2
 STAGE_BUOY_DIFFUSE, STAGE_PROJECT, STAGE_ADVECT_U, STAGE_ADVECT_V, STAGE_ADVECT_D = range(5)
 DTYPES = {"f32": SMK_F32, "fp32": SMK_F32, "float32": SMK_F32, "bf16x3": SMK_BF16X3, "bf16": SMK_BF16, "i8x3": SMK_I8X3}
 
@@ -104,8 +104,12 @@ _SIGNATURES = {
                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "smk_linear_forward_ln": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p,
                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    "smk_linear_forward_ln_split": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "smk_attention_ws": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                          C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p],
+    "smk_attention_kv": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                         C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p],
     "smk_attention_forward_lse": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p],
     "smk_attention_delta": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p],

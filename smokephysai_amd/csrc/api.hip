@@ -1015,7 +1015,14 @@ int64_t smk_linear_ln_max_rows(smk_linear *lin) {
 
 int smk_linear_forward_ln(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy, const float *wsum, double eps,
                           const float *periodic_add, int32_t rows_per_group, int32_t period, int32_t activation, void *stream) {
+    return smk_linear_forward_ln_split(lin, x, rows, ldx, y, ldy, wsum, eps, periodic_add, rows_per_group, period, activation, -1, stream);
+}
+
+int smk_linear_forward_ln_split(smk_linear *lin, const float *x, int64_t rows, int64_t ldx, float *y, int64_t ldy, const float *wsum, double eps,
+                                const float *periodic_add, int32_t rows_per_group, int32_t period, int32_t activation, int32_t split_from_col,
+                                void *stream) {
     SMK_REQUIRE(lin && x && y && wsum, "null lin/x/y/wsum");
+    SMK_REQUIRE(split_from_col < 0 || (split_from_col % 32 == 0 && split_from_col < lin->l.N), "split_from_col: negative (none) or a multiple of 32 below out_features");
     SMK_REQUIRE(rows >= 1 && ldx >= lin->l.K && ldy >= lin->l.N && ldx % 4 == 0 && ldy % 4 == 0, "rows >= 1, row pitches >= features, multiples of 4");
     SMK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wsum) & 15) == 0, "16-byte aligned x / y / wsum");
     SMK_REQUIRE((rows + 256) * ldx < (1LL << 30), "(rows + 256) * ldx < 2^30 floats");
@@ -1030,6 +1037,7 @@ int smk_linear_forward_ln(smk_linear *lin, const float *x, int64_t rows, int64_t
     c.padd = periodic_add; c.rows_per_group = periodic_add ? rows_per_group : 1; c.period = periodic_add ? period : 1;
     c.M = (int)rows; c.act = activation;
     c.ln_wsum = wsum; c.ln_eps = (float)eps;
+    c.split_from = split_from_col < 0 ? -1 : split_from_col;
     return check_launch(launch_linear_x3(lin->l, c, (hipStream_t)stream), "linear_x3 (fused LayerNorm)");
 }
 
@@ -1183,7 +1191,14 @@ int64_t smk_attention_workspace_bytes(int32_t B, int32_t L, int32_t H, int32_t h
 int smk_attention_ws(const float *q, const float *k, const float *v, void *out, int32_t B, int32_t L, int32_t H,
                      int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format,
                      void *workspace, int64_t workspace_bytes, void *stream) {
+    return smk_attention_kv(q, k, v, out, B, L, H, head_dim, ldq, ldk, ldv, ldo, scale, out_format, SMK_FMT_F32, workspace, workspace_bytes, stream);
+}
+
+int smk_attention_kv(const float *q, const void *k, const void *v, void *out, int32_t B, int32_t L, int32_t H,
+                     int32_t head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, double scale, int32_t out_format, int32_t kv_format,
+                     void *workspace, int64_t workspace_bytes, void *stream) {
     SMK_REQUIRE(q && k && v && out, "null q/k/v/out");
+    SMK_REQUIRE(kv_format == SMK_FMT_F32 || kv_format == SMK_FMT_SPLIT4_INPLACE, "kv_format: SMK_FMT_F32 or SMK_FMT_SPLIT4_INPLACE");
     SMK_REQUIRE(B >= 1 && H >= 1 && L >= 128, "B >= 1, H >= 1, L >= 128");
     if (head_dim != 64 || L % 128 != 0) {
         set_error("attention: HIP path is built for head_dim 64 and L a multiple of 128");
@@ -1197,7 +1212,8 @@ int smk_attention_ws(const float *q, const float *k, const float *v, void *out, 
                 "B * L * ld < 2^29 floats (32-bit buffer offsets)");
     AttnArgs a;
     SMK_REQUIRE(out_format == SMK_FMT_F32 || (out_format == SMK_FMT_SPLIT_BF16 && ldo == cols), "out_format (split: ldo == H * head_dim)");
-    a.q = q; a.k = k; a.v = v; a.o = (float *)out; a.o_split = out_format == SMK_FMT_SPLIT_BF16;
+    a.q = q; a.k = (const float *)k; a.v = (const float *)v; a.o = (float *)out; a.o_split = out_format == SMK_FMT_SPLIT_BF16;
+    a.kv_split = kv_format == SMK_FMT_SPLIT4_INPLACE;
     a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv; a.ldo = (int)ldo;
     a.B = B; a.L = L; a.H = H;
     a.scale_log2e = (float)(scale * 1.4426950408889634074);

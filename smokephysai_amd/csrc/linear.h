@@ -28,6 +28,9 @@ struct LinearCall {
     // stages the row and finishes y = rstd (x W'^T - mean ln_wsum) + b' in the epilogue.  Null: the plain layer.
     const float *ln_wsum = nullptr;
     float ln_eps = 0.f;
+    // fp32 y only: columns >= split_from (a multiple of 32; < 0: none) are written as in-place split-bf16 -- every aligned group of 4 columns
+    // holds {hi[0..3], lo[0..3]} (bf16: hi = RNE(v), lo = RNE(v - hi)) in the 16 bytes of its 4 floats (SMK_FMT_SPLIT4_INPLACE, smokehip.h)
+    int split_from = -1;
 };
 
 hipError_t launch_split_linear_weights(const float *w, const float *bias, const LinearDev &l, hipStream_t st, int transposed = 0,

@@ -121,6 +121,20 @@ __device__ __forceinline__ float gelu_erf(float v) {
 #else
 #define LN_DBG(a, bit) 0
 #endif
+// 4 fp32 values as the 16 bytes {hi[0..3], lo[0..3]} (bf16 pairs: hi = RNE(v), lo = RNE(v - hi)): LinearCall::split_from
+__device__ __forceinline__ float4 split4_inplace(const float (&v)[4]) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t vh, vl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        vh[i] = h;
+        vl[i] = (__bf16)(v[i] - (float)h);
+    }
+    const float2 h2 = __builtin_bit_cast(float2, vh), l2 = __builtin_bit_cast(float2, vl);
+    return make_float4(h2.x, h2.y, l2.x, l2.y);
+}
+
 struct LinearArgs {
     LinearDev l;
     LinearCall c;
@@ -520,7 +534,8 @@ __global__ __launch_bounds__(NW * 64 * KS, KS > 2 ? 1 : 2) void k_linear_x3(cons
                     const int L = r + 32 * hi, rr = row - r + 8 * q + (L >> 3);
                     if (rr < M) *reinterpret_cast<float4 *>(y_seg + (long long)rr * a.c.ldy + (ncol - 4 * hi) + (L & 7) * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
-                    *reinterpret_cast<float4 *>(y_seg + (long long)row * a.c.ldy + ncol + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                    const bool sp = a.c.split_from >= 0 && ncol + 8 * q >= a.c.split_from;        // wave-uniform (split_from % 32 == 0)
+                    *reinterpret_cast<float4 *>(y_seg + (long long)row * a.c.ldy + ncol + 8 * q) = sp ? split4_inplace(v) : make_float4(v[0], v[1], v[2], v[3]);
                 }
             };
             // fused LayerNorm: v = rstd ((x - p) W'^T - (mean - p) wsum) + b' for row mi*32 + r, columns 8q + 4hi .. + 3 of the wave's 32
@@ -973,7 +988,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_linear_b16(const LinearArgs a) {
                     } else {
                         finish(v);
                     }
-                    if (row < M) *reinterpret_cast<float4 *>(a.c.y + (long long)row * a.c.ldy + ncol + 16 * nb) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (row < M) {
+                        const bool sp = a.c.split_from >= 0 && ncol + 16 * nb >= a.c.split_from;  // wave-uniform (split_from % 32 == 0)
+                        *reinterpret_cast<float4 *>(a.c.y + (long long)row * a.c.ldy + ncol + 16 * nb) = sp ? split4_inplace(v) : make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 }
             }
         }

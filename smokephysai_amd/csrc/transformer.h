@@ -44,6 +44,7 @@ struct AttnArgs {
     // un-normalised partial output and its (running max, sum) to the workspace, k_attention_combine merges them in split order
     float *ws = nullptr;                 // [nsplit][B L][H 64] partial outputs, then [nsplit][B L][H][2] (max, sum); attention_workspace_bytes
     int nsplit = 1;                      // set by the launcher
+    int kv_split = 0;                    // k and v hold in-place split-bf16 (SMK_FMT_SPLIT4_INPLACE: per 4 columns {hi[0..3], lo[0..3]}) instead of fp32
 };
 hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st);
 // bytes of workspace with which launch_attention_x3 splits the keys over workgroups for this problem on the current device (0: it would not)

@@ -196,11 +196,15 @@ constexpr int AT_KPLANE = 64 * AT_KPITCH, AT_VPLANE = 64 * AT_VPITCH;          /
 constexpr int AT_BUF = 2 * AT_KPLANE + 2 * AT_VPLANE;                          // 34,816 B per tile (K hi|lo, V hi|lo)
 constexpr int AT_LDS = 2 * AT_BUF;                                             // 69,632 B -> 2 workgroups per CU
 
-__device__ __forceinline__ void at_split4(const float4 &v, bf16x4 &h, bf16x4 &l) {
+// presplit: the 16 bytes already hold {hi[0..3], lo[0..3]} (the q | k | v layer's epilogue wrote k and v that way: AttnArgs::kv_split)
+__device__ __forceinline__ void at_split4(const float4 &v, bf16x4 &h, bf16x4 &l, bool presplit = false) {
 #if defined(SMK_ATT_ABLATE) && (SMK_ATT_ABLATE & 2)      // diagnostic build (tools/att_ablate.sh): no split arithmetic, same LDS stores
-    h = __builtin_bit_cast(bf16x4, make_float2(v.x, v.y)); l = __builtin_bit_cast(bf16x4, make_float2(v.z, v.w));
-    return;
+    presplit = true;
 #endif
+    if (presplit) {
+        h = __builtin_bit_cast(bf16x4, make_float2(v.x, v.y)); l = __builtin_bit_cast(bf16x4, make_float2(v.z, v.w));
+        return;
+    }
     const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -266,12 +270,13 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
             vst[j] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
         }
     };
+    const bool kvs = a.kv_split != 0;
     auto stage_store = [&](int buf) {
         unsigned char *base = smem + buf * AT_BUF;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                         // K[key rq + 16j][d 4c4..]
             bf16x4 h, l;
-            at_split4(kst[j], h, l);
+            at_split4(kst[j], h, l, kvs);
             unsigned char *p = base + (rq + 16 * j) * AT_KPITCH + c4 * 8;
             *reinterpret_cast<bf16x4 *>(p) = h;
             *reinterpret_cast<bf16x4 *>(p + AT_KPLANE) = l;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                         // V[key rq + 16j][d 4c4..] (64-byte halves swapped on keys with bit 1)
             bf16x4 h, l;
-            at_split4(vst[j], h, l);
+            at_split4(vst[j], h, l, kvs);
             unsigned char *p = base + 2 * AT_KPLANE + (rq + 16 * j) * AT_VPITCH + ((c4 * 8) ^ (((rq >> 1) & 1) << 6));
             *reinterpret_cast<bf16x4 *>(p) = h;
             *reinterpret_cast<bf16x4 *>(p + AT_VPLANE) = l;

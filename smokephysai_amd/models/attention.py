@@ -15,10 +15,11 @@ def hip_attention_supported(L: int, head_dim: int) -> bool:
 
 
 def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, scale: float,
-                  out: Optional[torch.Tensor] = None, out_split: bool = False) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, out_split: bool = False, kv_split: bool = False) -> torch.Tensor:
     """q, k, v: [B, L, H*64] float32 on a ROCm device (row pitch may exceed H*64, e.g. slices of a fused qkv tensor);
     returns [B, L, H*64] -- the layout `out.transpose(1, 2).contiguous().view(B, L, D)` has in the reference
-    (chaos_attention.py:111-112)."""
+    (chaos_attention.py:111-112).  kv_split: the BITS of k and v are SMK_FMT_SPLIT4_INPLACE (what HipLinearLN.forward_ln(split_from=...)
+    wrote), not fp32 values; the result is bit for bit the one of the fp32 k and v they encode."""
     dev = _lib.require_cuda(q.device, "hip_attention")
     B, L, D = q.shape
     d = D // num_heads
@@ -39,11 +40,11 @@ def hip_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: 
     b0 = 0
     while b0 < B:
         nb = min(bmax, B - b0)
-        _lib.check(L_.smk_attention_ws(q.data_ptr() + b0 * q.stride(0) * 4, k.data_ptr() + b0 * k.stride(0) * 4,
+        _lib.check(L_.smk_attention_kv(q.data_ptr() + b0 * q.stride(0) * 4, k.data_ptr() + b0 * k.stride(0) * 4,
                                        v.data_ptr() + b0 * v.stride(0) * 4, out.data_ptr() + b0 * o_batch_bytes, nb, L,
                                        num_heads, d, q.stride(1), k.stride(1), v.stride(1), ldo, float(scale),
-                                       int(out_split), ws.data_ptr() if ws is not None and nb == min(B, bmax) else None, ws_bytes,
-                                       _lib.stream_ptr(dev)))
+                                       int(out_split), _lib.SMK_FMT_SPLIT4_INPLACE if kv_split else _lib.SMK_FMT_F32,
+                                       ws.data_ptr() if ws is not None and nb == min(B, bmax) else None, ws_bytes, _lib.stream_ptr(dev)))
         b0 += nb
     return out
 

@@ -25,6 +25,9 @@ class HipBody:
         self.addend_bufs: Dict[tuple, torch.Tensor] = {}           # (name, batch) -> [B,5,3D] addend of the fused q|k|v layer
         self.split_activations = os.environ.get("SMK_BODY_SPLIT", "0") == "1"
         self.fuse_layernorm = os.environ.get("SMK_BODY_FUSE_LN", "1") == "1"     # each LayerNorm inside the layer behind it (HipLinearLN)
+        # the fused q | k | v layer writes k and v as in-place split-bf16 and the attention stages them without split arithmetic (once per
+        # element instead of once per 128-query block; same bits, so same output).  SMK_BODY_KV_SPLIT=0: fp32 k and v
+        self.kv_presplit = os.environ.get("SMK_BODY_KV_SPLIT", "1") == "1"
 
     # ---- weight mirrors ----------------------------------------------------------------------------------------
     def linear(self, name: str, lin: nn.Linear) -> HipLinear:
@@ -135,15 +138,17 @@ class HipBody:
         if not addend_ready:
             att.chaos_addend_hip(B, x.device, noise, out=add15)
         qkv_ln = self.linear_ln(name + "chaos_attention.qkv", (att.q_proj, att.k_proj, att.v_proj), layer.norm1) if fuse_ln else None
+        kvs = False
         if qkv_ln is not None and B * L <= qkv_ln.max_rows:
-            qkv = qkv_ln.forward_ln(x, periodic_add=add15, rows_per_group=L)
+            kvs = self.kv_presplit and hip_attention_supported(L, d) and D % 32 == 0
+            qkv = qkv_ln.forward_ln(x, periodic_add=add15, rows_per_group=L, split_from=D if kvs else None)
         else:
             h = self.layernorm(x, layer.norm1, out_split=sp)
             qkv = self.qkv(name + "chaos_attention.qkv", att)(h, periodic_add=add15, rows_per_group=L, x_split=sp)
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         scale = 1.0 / (math.sqrt(d) * att.temperature)
         if hip_attention_supported(L, d):
-            o = hip_attention(q, k, v, H, scale, out_split=sp)             # [B, L, D]: heads already merged
+            o = hip_attention(q, k, v, H, scale, out_split=sp, kv_split=kvs)      # [B, L, D]: heads already merged
         else:
             o = F.scaled_dot_product_attention(q.view(B, L, H, d).transpose(1, 2), k.view(B, L, H, d).transpose(1, 2),
                                                v.view(B, L, H, d).transpose(1, 2), scale=scale)

@@ -162,8 +162,10 @@ class HipLinearLN(HipLinear):
         self.max_rows = int(self._L.smk_linear_ln_max_rows(self._handle))
 
     def forward_ln(self, x: torch.Tensor, activation: Optional[str] = None, periodic_add: Optional[torch.Tensor] = None,
-                   rows_per_group: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x [..., in_features] RAW (not normalised) -> act(LayerNorm(x) W^T + b + periodic_add)."""
+                   rows_per_group: int = 0, out: Optional[torch.Tensor] = None, split_from: Optional[int] = None) -> torch.Tensor:
+        """x [..., in_features] RAW (not normalised) -> act(LayerNorm(x) W^T + b + periodic_add).
+        split_from (a multiple of 32): the output columns from there on are written as SMK_FMT_SPLIT4_INPLACE -- per 4 columns the 16 bytes
+        {hi[0..3], lo[0..3]} (bf16) instead of 4 floats -- for hip_attention(kv_split=True); unsplit4_inplace() decodes them."""
         if x.device != self._dev or x.dtype != torch.float32 or x.shape[-1] != self.in_features:
             raise ValueError(f"HipLinearLN: x must be float32 [..., {self.in_features}] on {self._dev}")
         x2 = x.reshape(-1, self.in_features)
@@ -182,9 +184,25 @@ class HipLinearLN(HipLinear):
                 raise ValueError("HipLinearLN: periodic_add must be [rows / rows_per_group, period, out_features]")
             pa_ptr, period = pa.data_ptr(), pa.shape[1]
         act = {None: _lib.SMK_ACT_NONE, "none": _lib.SMK_ACT_NONE, "gelu": _lib.SMK_ACT_GELU, "relu": _lib.SMK_ACT_RELU}[activation]
-        _lib.check(self._L.smk_linear_forward_ln(self._handle, x2.data_ptr(), rows, x2.stride(0), y2.data_ptr(), y2.stride(0),
-                                                 self.wsum.data_ptr(), self.eps, pa_ptr, rpg, period, act, _lib.stream_ptr(self._dev)))
+        _lib.check(self._L.smk_linear_forward_ln_split(self._handle, x2.data_ptr(), rows, x2.stride(0), y2.data_ptr(), y2.stride(0),
+                                                       self.wsum.data_ptr(), self.eps, pa_ptr, rpg, period, act,
+                                                       -1 if split_from is None else int(split_from), _lib.stream_ptr(self._dev)))
         return y
+
+
+def split4_inplace(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., F] (F % 4 == 0) -> the same storage size holding SMK_FMT_SPLIT4_INPLACE: per 4 features {hi[0..3], lo[0..3]} bf16, returned
+    as a float32 tensor of x's shape whose BITS are that encoding (host-side helper for tests; the q | k | v epilogue writes it itself)."""
+    g = x.contiguous().view(*x.shape[:-1], x.shape[-1] // 4, 4)
+    hi = g.to(torch.bfloat16)
+    lo = (g - hi.to(torch.float32)).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).view(x.shape)
+
+
+def unsplit4_inplace(y: torch.Tensor) -> torch.Tensor:
+    """Decode SMK_FMT_SPLIT4_INPLACE bits (a float32-typed tensor [..., F]) back to fp32 values hi + lo."""
+    g = y.contiguous().view(torch.bfloat16).view(*y.shape[:-1], y.shape[-1] // 4, 8).to(torch.float32)
+    return (g[..., :4] + g[..., 4:]).reshape(y.shape)
 
 
 def hip_linear_wgrad_supported(in_features: int, out_features: int) -> bool:

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/smokehip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "ctypes binding and header disagree"
     want = int(re.search(r"#define\s+SMK_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "smokehip.h")).read()).group(1))
-    assert L.smk_abi_version() == want == _lib.ABI_VERSION == 16
+    assert L.smk_abi_version() == want == _lib.ABI_VERSION == 17
 
 
 def test_no_cpu_fallback():

@@ -228,6 +228,31 @@ def test_layernorm_fused_into_the_linear_layer(rows, K, N, act, padd):
         lin.forward_ln(torch.zeros(96, K, device="cuda"))
 
 
+@pytest.mark.parametrize("rows", [1024, 2048, 4096, 16384])
+def test_fused_layer_writes_its_k_v_columns_as_inplace_split_bf16(rows):
+    """smk_linear_forward_ln_split (HipLinearLN.forward_ln(split_from=D)): the q columns are the fp32 values of the unsplit call bit for bit,
+    the k | v columns hold SMK_FMT_SPLIT4_INPLACE -- exactly the {hi, lo} pairs the attention kernel would have formed from the fp32 values
+    (so the two routes multiply identical numbers).  Row counts that take each of the layer's kernels (32- and 64-row tiles on k_linear_x3,
+    128-row tiles on k_linear_b16), with the periodic addend of the q | k | v layer."""
+    from smokephysai_amd.models.linear import HipLinearLN, split4_inplace, unsplit4_inplace
+    K, D = 512, 512
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = torch.randn(rows, K, device="cuda", generator=g) * 1.3 + torch.randn(rows, 1, device="cuda", generator=g)
+    lin = HipLinearLN(torch.randn(3 * D, K, device="cuda", generator=g) / K ** 0.5, torch.randn(3 * D, device="cuda", generator=g),
+                      torch.rand(K, device="cuda", generator=g) + 0.5, torch.randn(K, device="cuda", generator=g) * 0.3, 1e-5)
+    pa = torch.zeros(rows // 1024, 5, 3 * D, device="cuda")
+    pa[:, :, :D] = torch.randn(rows // 1024, 5, D, device="cuda", generator=g)
+    plain = lin.forward_ln(x, periodic_add=pa, rows_per_group=1024)
+    mixed = lin.forward_ln(x, periodic_add=pa, rows_per_group=1024, split_from=D)
+    assert torch.equal(mixed[:, :D], plain[:, :D])
+    want = split4_inplace(plain[:, D:].contiguous())
+    assert torch.equal(mixed[:, D:].contiguous().view(torch.int32), want.view(torch.int32))
+    dec = unsplit4_inplace(mixed[:, D:].contiguous())
+    assert float((dec - plain[:, D:]).abs().max()) <= 2.0 ** -16 * float(plain[:, D:].abs().max())
+    with pytest.raises(Exception, match="split_from_col"):
+        lin.forward_ln(x, split_from=520)
+
+
 @pytest.mark.parametrize("rows", [1024, 4096])
 def test_fused_layernorm_rows_whose_mean_dwarfs_their_spread(rows):
     """Rows like 50 + 0.1 randn (|mean| = 500 sigma): a one-pass E[x^2] - mean^2 loses its digits there.  The kernel gathers shifted sums

@@ -95,6 +95,25 @@ def test_attention_split_keys_for_small_grids(B, L, H, monkeypatch):
     assert torch.equal(out, hip_attention(q, k, v, H, 0.125))                     # fixed merge order: deterministic
 
 
+@pytest.mark.parametrize("B,L,H", [(1, 1024, 8), (4, 1024, 8), (24, 1024, 8), (2, 256, 4)])
+def test_attention_on_presplit_k_v_equals_the_fp32_route_bit_for_bit(B, L, H):
+    """smk_attention_kv with kv_format SMK_FMT_SPLIT4_INPLACE: k and v arrive as the {hi, lo} pairs the kernel would have formed itself, so
+    the output equals the fp32 route's bit for bit -- on the key-split small-grid form (one frame), the two-wave-group form (batch 4), the
+    single-buffer form (chip-filling grids) and strided slices of one fused q | k | v tensor."""
+    from smokephysai_amd.models.attention import hip_attention
+    from smokephysai_amd.models.linear import split4_inplace
+    g = torch.Generator(device="cuda").manual_seed(B + L + H)
+    D = H * 64
+    qkv = torch.randn(B, L, 3 * D, device="cuda", generator=g)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    ref = hip_attention(q, k, v, H, 0.125)
+    enc = qkv.clone()
+    enc[..., D:] = split4_inplace(qkv[..., D:].contiguous())
+    out = hip_attention(enc[..., :D], enc[..., D:2 * D], enc[..., 2 * D:], H, 0.125, kv_split=True)
+    assert torch.equal(out, ref)
+    assert rel_err(out.cpu().numpy(), _attention_ref(q, k, v, H, 0.125).cpu().numpy()) < 2e-5
+
+
 def test_attention_reads_strided_qkv_and_rejects_other_head_dims():
     from smokephysai_amd.models.attention import hip_attention, hip_attention_supported
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -138,6 +157,10 @@ def test_hip_transformer_layer_matches_reference_golden(golden):
     with torch.no_grad():
         out = body.layer("t.", layer, x.clone(), noise)
         assert rel_err(out.cpu().numpy(), g["layer_out"]) < 1e-4
+        assert body.kv_presplit                               # (default: k | v written split by the q | k | v layer's epilogue)
+        body.kv_presplit = False                              # fp32 k | v, split inside the attention kernel: the same bits
+        assert torch.equal(body.layer("t.", layer, x.clone(), noise), out)
+        body.kv_presplit = True
         body.split_activations = True                         # same layer with split-bf16 activations between the kernels
         out_s = body.layer("t.", layer, x.clone(), noise)
         assert rel_err(out_s.cpu().numpy(), g["layer_out"]) < 1e-4
