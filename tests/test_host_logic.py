@@ -244,12 +244,14 @@ def _multibucket_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_direct_exchange_with_several_buckets_in_flight(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_exchange_with_several_buckets_in_flight(tmp_path, world):
     """The hook never waits on a collective inside a callback, so many buckets per backward cannot deadlock a backend that runs
-    callbacks on its worker threads; three steps of a 12-layer stack in ~10 buckets give the all-reduce's gradients."""
+    callbacks on its worker threads; three steps of a 12-layer stack in ~10 buckets give the all-reduce's gradients.  Three ranks: shard
+    sizes that do not divide the buckets (the tail all-reduce carries the remainder) and a mean by a non-power-of-two."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "mb.pt")
-    mp.spawn(_multibucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_multibucket_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     res = torch.load(out)
     assert res["direct_calls"] >= 10
     assert float((res["direct"] - res["allreduce"]).abs().max()) <= 1e-6 * float(res["allreduce"].abs().max())
