@@ -219,7 +219,8 @@ __device__ __forceinline__ void at_split4(const float4 &v, bf16x4 &h, bf16x4 &l,
 // SB (KS = 1 only): one LDS tile buffer instead of two (35,840 B): three workgroups per CU = 3 waves per SIMD (168 registers), two
 // barriers per tile; the next tile's global loads are still in flight during the MFMAs.  With 2 waves per SIMD the S -> softmax -> PV
 // chain of a wave is exposed (SQ counters: matrix pipe 43 % busy, VALU issue 49 %); a third wave fills part of it.
-template <int KS, bool SB = false>
+// KVS: k and v arrive as in-place split-bf16 (AttnArgs::kv_split): the staging moves the two halves of a 16-byte piece as they are
+template <int KS, bool SB = false, bool KVS = false>
 __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256 * KS, SB ? 3 : 2) void k_attention_x3(const Att
             vst[j] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
         }
     };
-    const bool kvs = a.kv_split != 0;
+    constexpr bool kvs = KVS;
     auto stage_store = [&](int buf) {
         unsigned char *base = smem + buf * AT_BUF;
 #pragma unroll
@@ -531,24 +532,22 @@ size_t attention_workspace_bytes(int B, int L, int H) {
     return n > 1 ? (size_t)n * B * L * H * (64 + 2) * sizeof(float) : 0;
 }
 
-hipError_t launch_attention_x3(const AttnArgs &a0, hipStream_t st) {
+template <bool KVS>
+static hipError_t launch_attention_x3_t(const AttnArgs &a0, hipStream_t st) {
     const int num_cu = device_num_cu();
     AttnArgs a = a0;
     a.nsplit = (a.ws && !a.o_split) ? attention_nsplit(a.B, a.L, a.H, num_cu) : 1;
+    once_per_device((const void *)k_attention_x3<1, false, KVS>, [&] {
+        (void)hipFuncSetAttribute((const void *)k_attention_x3<1, false, KVS>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
+        (void)hipFuncSetAttribute((const void *)k_attention_x3<2, false, KVS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS);
+    });
     if (a.nsplit > 1) {
-        once_per_device((const void *)k_attention_x3<2>, [&] {
-            (void)hipFuncSetAttribute((const void *)k_attention_x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS);
-        });
         const long long rows = (long long)a.B * a.L;
-        hipLaunchKernelGGL(k_attention_x3<2>, dim3(a.B * a.H * (a.L / AT_QB) * a.nsplit), dim3(512), 2 * AT_LDS, st, a);
+        hipLaunchKernelGGL((k_attention_x3<2, false, KVS>), dim3(a.B * a.H * (a.L / AT_QB) * a.nsplit), dim3(512), 2 * AT_LDS, st, a);
         hipLaunchKernelGGL(k_attention_combine, dim3((unsigned)((rows * a.H * 16 + 255) / 256)), dim3(256), 0, st, a.ws, a.o, a.lse, rows, a.H,
                            a.ldo, a.nsplit);
         return hipGetLastError();
     }
-    once_per_device((const void *)k_attention_x3<1>, [&] {
-        (void)hipFuncSetAttribute((const void *)k_attention_x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
-        (void)hipFuncSetAttribute((const void *)k_attention_x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS);
-    });
     const int nwg = a.B * a.H * (a.L / AT_QB);
     static int force_ks = -1;
     if (force_ks < 0) { const char *sv = getenv("SMK_ATTN_KS"); force_ks = sv ? atoi(sv) : 0; }
@@ -557,10 +556,14 @@ hipError_t launch_attention_x3(const AttnArgs &a0, hipStream_t st) {
     if ((force_ks == 1 || force_ks == 2) && (a.L / AT_KV) % force_ks == 0) ks = force_ks;
     static int sb = -1;
     if (sb < 0) { const char *sv = getenv("SMK_ATTN_SB"); sb = sv ? atoi(sv) : 1; }     // measured at B = 64: 553 -> 535 us (interleaved A/B)
-    if (ks == 2) hipLaunchKernelGGL(k_attention_x3<2>, dim3(nwg), dim3(512), 2 * AT_LDS, st, a);
-    else if (sb && nwg > 2 * num_cu) hipLaunchKernelGGL((k_attention_x3<1, true>), dim3(nwg), dim3(256), AT_BUF, st, a);
-    else hipLaunchKernelGGL(k_attention_x3<1>, dim3(nwg), dim3(256), AT_LDS, st, a);
+    if (ks == 2) hipLaunchKernelGGL((k_attention_x3<2, false, KVS>), dim3(nwg), dim3(512), 2 * AT_LDS, st, a);
+    else if (sb && nwg > 2 * num_cu) hipLaunchKernelGGL((k_attention_x3<1, true, KVS>), dim3(nwg), dim3(256), AT_BUF, st, a);
+    else hipLaunchKernelGGL((k_attention_x3<1, false, KVS>), dim3(nwg), dim3(256), AT_LDS, st, a);
     return hipGetLastError();
+}
+
+hipError_t launch_attention_x3(const AttnArgs &a, hipStream_t st) {
+    return a.kv_split ? launch_attention_x3_t<true>(a, st) : launch_attention_x3_t<false>(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
