@@ -70,6 +70,9 @@ def test_round4_bench_line_has_the_new_blocks():
     assert c4["ms_encode_per_volume_dense"] > c4["ms_encode_per_volume"]
     ts = d["train_step"]
     assert ts["rccl_ranks"] == 1 and "error" not in ts and ts["direct_exchange_flat"]["ms"] <= 0.05        # VERDICT r3 item 6 (was 0.262)
+    assert len(ts["ms_per_step_blocks"]) == 2 and ts["ms_per_step"] == min(ts["ms_per_step_blocks"]) < 70.0  # (a poisoned MIOpen find-db read 485)
+    assert d["ms_sim_per_step"] <= 0.18                                   # VERDICT r3 item 8 (was 0.191)
+    assert d["roofline"]["traffic_source"]["stale"] is False and d["roofline"]["pmc"]["stale"] is False      # the counters are of THIS build
     inf = d["inference_ms_per_frame"]
     assert inf["batch4"] < 0.300 and inf["batch1"] < 0.631 and inf["batch64"] <= 0.195                     # round 3's driver record
 
